@@ -1,0 +1,357 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE.
+
+Build-container tooling only: needs /root/reference, never runs on the GPU box,
+never imported by the product.  Run as
+
+    PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py
+
+Recipe follows SURVEY.md section 8(c) / Appendix C: throw-away stubs for the
+python packages the reference imports but this image lacks (fvcore, iopath,
+fairscale, ipdb, simplejson), then the reference modules are used unmodified.
+Weights come from ``oracle.csts_oracle.seeded_tensor`` (a documented per-name
+generator) loaded into the reference modules with ``load_state_dict(strict=True)``,
+so only inputs/outputs are stored, never weights or reference source.
+"""
+import ast
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+sys.dont_write_bytecode = True
+
+
+def _mod(name):
+    m = types.ModuleType(name)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    for n in ("fvcore", "fvcore.common", "iopath", "iopath.common", "fairscale", "fairscale.nn", "ipdb",
+              "simplejson"):
+        _mod(n)
+
+    class Registry:
+        def __init__(self, name):
+            self._m = {}
+
+        def register(self, obj=None):
+            if obj is None:
+                def deco(o):
+                    self._m[o.__name__] = o
+                    return o
+                return deco
+            self._m[obj.__name__] = obj
+            return obj
+
+        def get(self, name):
+            return self._m[name]
+
+    _mod("fvcore.common.registry").Registry = Registry
+
+    class CfgNode(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def clone(self):
+            return copy.deepcopy(self)
+
+        def _merge(self, d):
+            for k, v in d.items():
+                if isinstance(v, dict):
+                    self[k]._merge(v)
+                    continue
+                if isinstance(v, str):
+                    try:
+                        v = ast.literal_eval(v)
+                    except Exception:
+                        pass
+                self[k] = list(v) if isinstance(v, tuple) else v
+
+        def merge_from_file(self, f):
+            self._merge(yaml.safe_load(open(f)))
+
+        def merge_from_list(self, lst):
+            for k, v in zip(lst[0::2], lst[1::2]):
+                node = self
+                parts = k.split(".")
+                for p in parts[:-1]:
+                    node = node[p]
+                try:
+                    v = ast.literal_eval(v) if isinstance(v, str) else v
+                except Exception:
+                    pass
+                node[parts[-1]] = v
+
+    _mod("fvcore.common.config").CfgNode = CfgNode
+
+    class _PM:
+        def open(self, *a, **k):
+            return open(*a, **k)
+
+        def exists(self, p):
+            return os.path.exists(p)
+
+    _mod("iopath.common.file_io").PathManagerFactory = type("PMF", (), {"get": staticmethod(lambda key=None: _PM())})
+    _mod("fairscale.nn.checkpoint").checkpoint_wrapper = lambda m, *a, **k: m
+    torch.Tensor.cuda = lambda self, *a, **k: self        # EgoNCE hard-codes .cuda() (losses.py:158)
+    sys.path.insert(0, "/root/reference")
+
+
+install_stubs()
+torch.set_num_threads(1)   # canonical goldens (1 vs 8 threads differ by 2e-7)
+
+from oracle import csts_oracle as O                                      # noqa: E402
+from slowfast.config.defaults import get_cfg                             # noqa: E402
+from slowfast.models.custom_multimodal_builder import CSTS               # noqa: E402
+from slowfast.models import attention as ref_attn                       # noqa: E402
+from slowfast.models import av_attention as ref_av                      # noqa: E402
+from slowfast.models import stem_helper as ref_stem                     # noqa: E402
+from slowfast.models import losses as ref_losses                        # noqa: E402
+from slowfast.models import common as ref_common                        # noqa: E402
+from slowfast.utils import utils as ref_utils                           # noqa: E402
+
+YAML = "/root/reference/configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"
+
+
+def make_cfg(num_frames=8, extra=()):
+    cfg = get_cfg()
+    cfg.merge_from_file(YAML)
+    cfg.NUM_GPUS = 0
+    cfg.MODEL.LOSS_FUNC = "kldiv+egonce"
+    cfg.DATA.NUM_FRAMES = num_frames
+    for k, v in extra:
+        node = cfg
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def load_seeded(module, prefix="", seed=0):
+    sd = {k: O.seeded_tensor(prefix + k, tuple(v.shape), seed) for k, v in module.state_dict().items()}
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", name, {k: np.asarray(v).shape for k, v in arrs.items()})
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ manifests
+def gen_manifests():
+    for T in (8, 16, 32):
+        m = CSTS(make_cfg(T))
+        man = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        with open(os.path.join(OUT, f"manifest_T{T}.json"), "w") as f:
+            json.dump({"num_params": sum(p.numel() for p in m.parameters()), "entries": man}, f)
+        print("manifest", T, len(man))
+        if T == 8:
+            # also the kldiv-only variant (no vision_proj/audio_proj)
+            cfg = make_cfg(8)
+            cfg.MODEL.LOSS_FUNC = "kldiv"
+            m2 = CSTS(cfg)
+            with open(os.path.join(OUT, "manifest_T8_kldiv.json"), "w") as f:
+                json.dump({"num_params": sum(p.numel() for p in m2.parameters()),
+                           "entries": [[k, list(v.shape)] for k, v in m2.state_dict().items()]}, f)
+            geo = {"pool_kv_stride": cfg.MVIT.POOL_KV_STRIDE,
+                   "blocks": [[b.dim, b.dim_out, b.attn.num_heads] for b in m.blocks]}
+            with open(os.path.join(OUT, "geometry_T8.json"), "w") as f:
+                json.dump(geo, f)
+
+
+# ------------------------------------------------------------------ blocks
+from functools import partial                                            # noqa: E402
+LN6 = partial(torch.nn.LayerNorm, eps=1e-6)
+
+
+def gen_blocks():
+    g = torch.Generator().manual_seed(11)
+    # config 1: 1x3x8x56x56 -> PatchEmbed -> (1,784,96), thw (4,14,14); blocks.0 and blocks.1 geometry
+    clip = torch.randn(1, 3, 8, 56, 56, generator=g)
+    pe = load_seeded(ref_stem.PatchEmbed(3, 96, (3, 7, 7), (2, 4, 4), (1, 3, 3)), "cfg1.patch_embed.")
+    tok = pe(clip)
+    b0 = load_seeded(ref_attn.MultiScaleBlock(96, 192, 1, 4.0, True, norm_layer=LN6, kernel_q=[], kernel_kv=[3, 3, 3],
+                                              stride_q=[], stride_kv=[1, 8, 8], mode="conv", has_cls_embed=False),
+                     "cfg1.b0.").eval()
+    y0, thw0 = b0(tok, [4, 14, 14])
+    b1 = load_seeded(ref_attn.MultiScaleBlock(192, 192, 2, 4.0, True, norm_layer=LN6, kernel_q=[3, 3, 3],
+                                              kernel_kv=[3, 3, 3], stride_q=[1, 2, 2], stride_kv=[1, 4, 4],
+                                              mode="conv", has_cls_embed=False), "cfg1.b1.").eval()
+    y1, thw1 = b1(y0, thw0)
+    save("block_cfg1.npz", clip=t2n(clip), tok=t2n(tok), y0=t2n(y0), thw0=thw0, y1=t2n(y1), thw1=thw1)
+
+    # decoder blocks, both stride kinds
+    x = torch.randn(2, 2 * 4 * 4, 192, generator=g)
+    d1 = load_seeded(ref_attn.MultiScaleDecoderBlock(192, 96, 2, 4.0, True, norm_layer=LN6, kernel_q=[3, 3, 3],
+                                                     kernel_kv=[3, 3, 3], stride_q=[1, 2, 2], stride_kv=[1, 2, 2],
+                                                     mode="conv", has_cls_embed=False), "dec_a.").eval()
+    ya, thwa = d1(x, [2, 4, 4])
+    d2 = load_seeded(ref_attn.MultiScaleDecoderBlock(192, 96, 2, 4.0, True, norm_layer=LN6, kernel_q=[3, 3, 3],
+                                                     kernel_kv=[3, 3, 3], stride_q=[2, 1, 1], stride_kv=[1, 4, 4],
+                                                     mode="conv", has_cls_embed=False), "dec_b.").eval()
+    yb, thwb = d2(x, [2, 4, 4])
+    # head_dim 192 variant (decode_block2 geometry: 4 heads of 192 at dim 768 is too big; use dim 384, 2 heads)
+    x3 = torch.randn(1, 2 * 2 * 2, 384, generator=g)
+    d3 = load_seeded(ref_attn.MultiScaleDecoderBlock(384, 192, 2, 4.0, True, norm_layer=LN6, kernel_q=[3, 3, 3],
+                                                     kernel_kv=[3, 3, 3], stride_q=[1, 2, 2], stride_kv=[1, 2, 2],
+                                                     mode="conv", has_cls_embed=False), "dec_c.").eval()
+    yc, thwc = d3(x3, [2, 2, 2])
+    save("block_decoder.npz", x=t2n(x), ya=t2n(ya), thwa=thwa, yb=t2n(yb), thwb=thwb, x3=t2n(x3), yc=t2n(yc),
+         thwc=thwc)
+
+    # spatial / temporal fusion blocks
+    xs = torch.randn(2, 2 * 2 * 2 + 2, 192, generator=g)        # T=2, H=W=2 -> 8 video + 2 audio tokens
+    kw = dict(mlp_ratio=4.0, qkv_bias=True, norm_layer=LN6, kernel_q=[1, 1, 1], kernel_kv=[1, 1, 1],
+              stride_q=[1, 1, 1], stride_kv=[1, 1, 1], mode="conv", has_cls_embed=False)
+    sp = load_seeded(ref_av.SpatialBlock(192, 192, 2, **kw), "sp.").eval()
+    ys, _ = sp(xs, [2, 2, 2])
+    _, _, attn_s = sp(xs, [2, 2, 2], return_spatial_attn=True)
+    sp2 = load_seeded(ref_av.SpatialBlock(192, 192, 2, return_audio_attn=True, **kw), "sp.").eval()
+    ys2, _, aa = sp2(xs, [2, 2, 2])
+    xt = torch.randn(2, 4, 192, generator=g)
+    tp = load_seeded(ref_av.TemporalBlock(192, 192, 2, **kw), "tp.").eval()
+    yt, _, attn_t = tp(xt, (2, 2, 2), return_temporal_attn=True)
+    save("block_fusion.npz", xs=t2n(xs), ys=t2n(ys), attn_s=t2n(attn_s), ys2=t2n(ys2), audio_attn=t2n(aa),
+         xt=t2n(xt), yt=t2n(yt), attn_t=t2n(attn_t))
+
+    # losses
+    logits = torch.randn(3, 1, 4, 8, 8, generator=g) * 3
+    tgt = torch.rand(3, 4, 8, 8, generator=g)
+    tgt = tgt / tgt.sum(dim=(-1, -2), keepdim=True)
+    p = ref_utils.frame_softmax(logits, temperature=2)
+    kl = ref_losses.KLDiv()(p, tgt)
+    a = torch.randn(3, 16, generator=g)
+    b = torch.randn(3, 16, generator=g)
+    sim = ref_utils.sim_matrix(a, b)
+    nce = ref_losses.EgoNCE()(sim)
+    save("losses.npz", logits=t2n(logits), tgt=t2n(tgt), p=t2n(p), kl=t2n(kl), a=t2n(a), b=t2n(b), sim=t2n(sim),
+         nce=t2n(nce))
+
+
+# ------------------------------------------------------------------ full model
+GRAD_NAMES = [
+    "pos_embed_spatial", "pos_embed_temporal_audio", "patch_embed.proj.weight", "patch_embed_audio.proj.bias",
+    "blocks.0.attn.qkv.weight", "blocks.0.attn.pool_k.weight", "blocks.1.attn.pool_q.weight",
+    "blocks.1.attn.norm_q.weight", "blocks.3.mlp.fc1.weight", "blocks.7.attn.proj.bias", "blocks.13.proj.weight",
+    "blocks.15.norm2.bias", "blocks_audio.1.attn.norm_v.bias", "blocks_audio.3.mlp.fc2.weight",
+    "vision_pool.weight", "audio_pool.weight", "audio_pool2.bias", "temporal_fusion.attn.qkv.weight",
+    "spatial_fusion.mlp.fc2.bias", "decode_block1.attn.upsample_q.weight", "decode_block2.attn.norm_q.weight",
+    "decode_block3.proj.weight", "decode_block4.attn.pool_v.weight", "decode_block4.mlp.fc2.weight",
+    "vision_proj.weight", "audio_proj.bias", "classifier.weight", "classifier.bias",
+]
+
+
+def gen_model():
+    cfg = make_cfg(8)
+    m = load_seeded(CSTS(cfg)).eval()
+    batch = O.synthetic_batch(2, 8, 256, seed=1000)
+    taps = {}
+    hooks = [m.blocks[15].register_forward_hook(lambda mod, i, o: taps.__setitem__("enc_video", o[0])),
+             m.blocks_audio[3].register_forward_hook(lambda mod, i, o: taps.__setitem__("enc_audio", o[0])),
+             m.decode_block1.register_forward_hook(lambda mod, i, o: taps.__setitem__("x_reweight", i[0]))]
+    logits, v, a = m([batch["video"]], batch["audio"], return_embed=True)
+    for h in hooks:
+        h.remove()
+    p = ref_utils.frame_softmax(logits, temperature=2)
+    sim = ref_utils.sim_matrix(v, a)
+    kld = ref_losses.KLDiv()(p, batch["labels_hm"])
+    nce = ref_losses.EgoNCE()(sim)
+    loss = kld + 0.05 * nce
+    m.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    gnorm = {n: float(named[n].grad.norm()) for n in GRAD_NAMES}
+    total = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m.parameters())))
+    # small gradient slices for elementwise comparison
+    gslice = {n.replace(".", "_") + "_g": t2n(named[n].grad.flatten()[:64]) for n in GRAD_NAMES}
+    argmax = p.reshape(2, 8, -1).argmax(-1)
+    save("model_T8_B2.npz", logits=t2n(logits), v_emb=t2n(v), a_emb=t2n(a), heat=t2n(p).astype(np.float32),
+         argmax=t2n(argmax), kld=t2n(kld), nce=t2n(nce), loss=t2n(loss),
+         enc_video=t2n(taps["enc_video"])[:, :, :64], enc_audio=t2n(taps["enc_audio"])[:, :, :64],
+         x_reweight=t2n(taps["x_reweight"])[:, :, :64],
+         grad_names=np.array(GRAD_NAMES), grad_norms=np.array([gnorm[n] for n in GRAD_NAMES]),
+         grad_total_norm=total, **gslice)
+
+    # drop-path (train mode) golden: record the reference's torch.rand draws
+    m.train()
+    rec = []
+    orig_rand = torch.rand
+
+    def rand_rec(*a_, **k_):
+        r = orig_rand(*a_, **k_)
+        rec.append(r.flatten().clone())
+        return r
+    torch.manual_seed(4242)
+    torch.rand = rand_rec
+    try:
+        with torch.no_grad():
+            logits_tr = m([batch["video"]], batch["audio"])
+    finally:
+        torch.rand = orig_rand
+    save("model_T8_B2_droppath.npz", logits=t2n(logits_tr), rand=np.stack([t2n(r) for r in rec]))
+    m.eval()
+
+    # spatial-audio-attn variant + returned attention maps (forward only, B=1)
+    with torch.no_grad():
+        b1 = O.synthetic_batch(1, 8, 256, seed=1001)
+        out = m([b1["video"]], b1["audio"], return_spatial_attn=True, return_temporal_attn=True)
+        save("model_T8_B1_attn.npz", logits=t2n(out[0]), spatial_attn=t2n(out[1]).astype(np.float16),
+             temporal_attn=t2n(out[2]))
+        cfg2 = make_cfg(8, [("MVIT.SPATIAL_AUDIO_ATTN", True)])
+        m2 = load_seeded(CSTS(cfg2)).eval()
+        lg2 = m2([b1["video"]], b1["audio"])
+        save("model_T8_B1_saa.npz", logits=t2n(lg2))
+        del m2
+
+    # T=16 forward, B=1
+    del m
+    cfg16 = make_cfg(16)
+    m16 = load_seeded(CSTS(cfg16)).eval()
+    b16 = O.synthetic_batch(1, 16, 256, seed=1002)
+    with torch.no_grad():
+        lg, v16, a16 = m16([b16["video"]], b16["audio"], return_embed=True)
+    save("model_T16_B1.npz", logits=t2n(lg), v_emb=t2n(v16), a_emb=t2n(a16))
+
+
+def gen_lr():
+    from slowfast.utils import lr_policy
+    cfg = make_cfg(8)
+    pts = [0.0, 0.5, 1.0, 3.25, 7.5, 14.0, 14.99]
+    save("lr_schedule.npz", epochs=np.array(pts), lr=np.array([lr_policy.get_lr_at_epoch(cfg, e) for e in pts]))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["manifest", "blocks", "model", "lr"]
+    if "manifest" in what:
+        gen_manifests()
+    if "blocks" in what:
+        gen_blocks()
+    if "lr" in what:
+        gen_lr()
+    if "model" in what:
+        gen_model()

@@ -1,0 +1,208 @@
+"""Pins the CPU oracle (oracle/csts_oracle.py) against fixtures captured from the
+imported reference by oracle/gen_golden.py.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csts_oracle as O
+from conftest import rel_l2, GOLDEN
+
+TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op association only
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def _spec_params(seed_prefix, spec):
+    """Parameters for a stand-alone block whose reference state_dict keys carry no prefix;
+    the generator was seeded with seed_prefix + key."""
+    names = []
+    C, hd = spec.dim, spec.dim // spec.heads
+    p = spec.prefix
+    names += [("norm1.weight", (C,)), ("norm1.bias", (C,)), ("attn.qkv.weight", (3 * C, C)),
+              ("attn.qkv.bias", (3 * C,)), ("attn.proj.weight", (C, C)), ("attn.proj.bias", (C,))]
+    if spec.kind == "dec":
+        names += [("attn.upsample_q.weight", (hd, 1, 3, 3, 3)), ("attn.norm_q.weight", (hd,)),
+                  ("attn.norm_q.bias", (hd,))]
+    elif spec.has_pool_q:
+        names += [("attn.pool_q.weight", (hd, 1, 3, 3, 3)), ("attn.norm_q.weight", (hd,)), ("attn.norm_q.bias", (hd,))]
+    if spec.has_pool_kv:
+        for t in "kv":
+            names += [(f"attn.pool_{t}.weight", (hd, 1, 3, 3, 3)), (f"attn.norm_{t}.weight", (hd,)),
+                      (f"attn.norm_{t}.bias", (hd,))]
+    names += [("norm2.weight", (C,)), ("norm2.bias", (C,)), ("mlp.fc1.weight", (spec.mlp_hidden, C)),
+              ("mlp.fc1.bias", (spec.mlp_hidden,)), ("mlp.fc2.weight", (spec.dim_out, spec.mlp_hidden)),
+              ("mlp.fc2.bias", (spec.dim_out,))]
+    if spec.dim != spec.dim_out:
+        names += [("proj.weight", (spec.dim_out, C)), ("proj.bias", (spec.dim_out,))]
+    return {p + "." + n: O.seeded_tensor(seed_prefix + n, s) for n, s in names}
+
+
+@pytest.mark.parametrize("T", [8, 16, 32])
+def test_manifest_matches_reference(T):
+    ref = json.load(open(os.path.join(GOLDEN, f"manifest_T{T}.json")))
+    mine = O.param_manifest(num_frames=T)
+    assert [[n, list(s)] for n, s in mine] == ref["entries"]
+    assert sum(int(np.prod(s)) for n, s in mine) == ref["num_params"]
+
+
+def test_manifest_kldiv_only():
+    ref = json.load(open(os.path.join(GOLDEN, "manifest_T8_kldiv.json")))
+    mine = O.param_manifest(num_frames=8, with_nce=False)
+    assert [[n, list(s)] for n, s in mine] == ref["entries"]
+
+
+def test_geometry_matches_reference():
+    ref = json.load(open(os.path.join(GOLDEN, "geometry_T8.json")))
+    G = O.derive_geometry()
+    assert [[i] + list(s.stride_kv) for i, s in enumerate(G["video"])] == ref["pool_kv_stride"]
+    assert [[s.dim, s.dim_out, s.heads] for s in G["video"]] == ref["blocks"]
+
+
+def test_block_cfg1():
+    """BASELINE config 1: single MultiScaleBlock on 1x3x8x56x56 (CPU plumbing case)."""
+    g = _load("block_cfg1.npz")
+    clip = torch.from_numpy(g["clip"])
+    w = O.seeded_tensor("cfg1.patch_embed.proj.weight", (96, 3, 3, 7, 7))
+    b = O.seeded_tensor("cfg1.patch_embed.proj.bias", (96,))
+    tok = O.patch_embed(clip, w, b, (2, 4, 4), (1, 3, 3))
+    assert rel_l2(tok, g["tok"]) < TOL
+    s0 = O.BlockSpec("b0", "enc", 96, 192, 1, (1, 1, 1), (1, 8, 8), False, True, 384)
+    y0, thw0, _ = O.block_forward(tok, [4, 14, 14], _spec_params("cfg1.b0.", s0), s0)
+    assert list(thw0) == list(g["thw0"]) and rel_l2(y0, g["y0"]) < TOL
+    s1 = O.BlockSpec("b1", "enc", 192, 192, 2, (1, 2, 2), (1, 4, 4), True, True, 768)
+    y1, thw1, _ = O.block_forward(y0, thw0, _spec_params("cfg1.b1.", s1), s1)
+    assert list(thw1) == list(g["thw1"]) and rel_l2(y1, g["y1"]) < TOL
+
+
+def test_block_decoder():
+    g = _load("block_decoder.npz")
+    x = torch.from_numpy(g["x"])
+    sa = O.BlockSpec("d", "dec", 192, 96, 2, (1, 2, 2), (1, 2, 2), True, True, 384)
+    ya, thwa, _ = O.block_forward(x, [2, 4, 4], _spec_params("dec_a.", sa), sa)
+    assert list(thwa) == list(g["thwa"]) and rel_l2(ya, g["ya"]) < TOL
+    sb = O.BlockSpec("d", "dec", 192, 96, 2, (2, 1, 1), (1, 4, 4), True, True, 384)
+    yb, thwb, _ = O.block_forward(x, [2, 4, 4], _spec_params("dec_b.", sb), sb)
+    assert list(thwb) == list(g["thwb"]) and rel_l2(yb, g["yb"]) < TOL
+    sc = O.BlockSpec("d", "dec", 384, 192, 2, (1, 2, 2), (1, 2, 2), True, True, 768)
+    yc, thwc, _ = O.block_forward(torch.from_numpy(g["x3"]), [2, 2, 2], _spec_params("dec_c.", sc), sc)
+    assert list(thwc) == list(g["thwc"]) and rel_l2(yc, g["yc"]) < TOL
+
+
+def test_block_fusion():
+    g = _load("block_fusion.npz")
+    xs = torch.from_numpy(g["xs"])
+    ss = O.BlockSpec("s", "spatial", 192, 192, 2, (1, 1, 1), (1, 1, 1), False, False, 768)
+    P = _spec_params("sp.", ss)
+    ys, _, attn = O.block_forward(xs, [2, 2, 2], P, ss, want_attn=True)
+    assert rel_l2(ys, g["ys"]) < TOL and rel_l2(attn, g["attn_s"]) < TOL
+    ys2, _, aa = O.block_forward(xs, [2, 2, 2], P, ss, spatial_audio_attn=True)
+    assert rel_l2(ys2, g["ys2"]) < TOL and rel_l2(aa, g["audio_attn"]) < 1e-4
+    st = O.BlockSpec("t", "temporal", 192, 192, 2, (1, 1, 1), (1, 1, 1), False, False, 768)
+    yt, _, at = O.block_forward(torch.from_numpy(g["xt"]), (2, 2, 2), _spec_params("tp.", st), st, want_attn=True)
+    assert rel_l2(yt, g["yt"]) < TOL and rel_l2(at, g["attn_t"]) < TOL
+
+
+def test_losses():
+    g = _load("losses.npz")
+    p = O.frame_softmax(torch.from_numpy(g["logits"]), 2.0)
+    assert rel_l2(p, g["p"]) < 1e-6
+    assert abs(float(O.kldiv(p, torch.from_numpy(g["tgt"]))) - float(g["kl"])) < 1e-6
+    sim = O.sim_matrix(torch.from_numpy(g["a"]), torch.from_numpy(g["b"]))
+    assert rel_l2(sim, g["sim"]) < 1e-6
+    assert abs(float(O.egonce(sim)) - float(g["nce"])) < 1e-5
+
+
+def test_egonce_zero_at_batch_one():
+    v = torch.randn(1, 256)
+    assert float(O.egonce(O.sim_matrix(v, torch.randn(1, 256)))) == 0.0
+
+
+@pytest.fixture(scope="module")
+def full_model_run():
+    """One fwd+bwd of the oracle at 8x256^2, B=2 (shared by the tests below; ~10 s)."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    P = {k: v.requires_grad_(True) for k, v in O.seeded_params(8, 256).items()}
+    batch = O.synthetic_batch(2, 8, 256, seed=1000)
+    taps = {}
+    logits, v, a = O.csts_forward(P, batch["video"], batch["audio"], 8, 256, return_embed=True, taps=taps)
+    loss, kld, nce = O.csts_loss(logits, v, a, batch["labels_hm"], 0.05)
+    loss.backward()
+    return P, batch, logits, v, a, loss, kld, nce, taps
+
+
+def test_full_model_forward(full_model_run):
+    P, batch, logits, v, a, loss, kld, nce, taps = full_model_run
+    g = _load("model_T8_B2.npz")
+    assert rel_l2(taps["enc_video"][:, :, :64], g["enc_video"]) < TOL
+    assert rel_l2(taps["enc_audio"][:, :, :64], g["enc_audio"]) < TOL
+    assert rel_l2(taps["x_reweight"][:, :, :64], g["x_reweight"]) < TOL
+    assert rel_l2(logits, g["logits"]) < TOL
+    assert rel_l2(v, g["v_emb"]) < TOL and rel_l2(a, g["a_emb"]) < TOL
+    heat = O.frame_softmax(logits.detach(), 2.0)
+    assert rel_l2(heat, g["heat"]) < TOL
+    assert (heat.reshape(2, 8, -1).argmax(-1).numpy() == g["argmax"]).all()
+    assert abs(float(kld) - float(g["kld"])) < 1e-5 * max(1, abs(float(g["kld"])))
+    assert abs(float(nce) - float(g["nce"])) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1, abs(float(g["loss"])))
+
+
+def test_full_model_gradients(full_model_run):
+    P = full_model_run[0]
+    g = _load("model_T8_B2.npz")
+    names = [str(n) for n in g["grad_names"]]
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        gn = float(P[n].grad.norm())
+        if n == "classifier.bias":      # softmax is shift-invariant: true gradient is exactly 0
+            assert gn < 1e-6
+            continue
+        assert abs(gn - ref_norm) <= 2e-4 * max(ref_norm, 1e-12), (n, gn, ref_norm)
+        sl = P[n].grad.flatten()[:64]
+        assert rel_l2(sl, g[n.replace(".", "_") + "_g"]) < 5e-4, n
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in P.values())))
+    assert abs(total - float(g["grad_total_norm"])) < 2e-4 * float(g["grad_total_norm"])
+
+
+def test_droppath_train_mode():
+    g = _load("model_T8_B2_droppath.npz")
+    G = O.derive_geometry()
+    rnd = torch.from_numpy(g["rand"])          # one (B,) draw per drop_path call, in execution order
+    active = [s for s in G["video"] if s.drop_path > 0]
+    assert rnd.shape[0] == 2 * len(active)
+    # reference execution order == video block order (audio / decoder blocks have rate 0)
+    km = {}
+    for i, s in enumerate(active):
+        keep = 1.0 - s.drop_path
+        km[s.prefix] = (torch.floor(keep + rnd[2 * i]), torch.floor(keep + rnd[2 * i + 1]))
+    P = O.seeded_params(8, 256)
+    batch = O.synthetic_batch(2, 8, 256, seed=1000)
+    with torch.no_grad():
+        logits = O.csts_forward(P, batch["video"], batch["audio"], 8, 256, keep_masks=km)
+    assert rel_l2(logits, g["logits"]) < TOL
+
+
+def test_attn_outputs_and_saa_variant():
+    P = O.seeded_params(8, 256)
+    b1 = O.synthetic_batch(1, 8, 256, seed=1001)
+    with torch.no_grad():
+        out = O.csts_forward(P, b1["video"], b1["audio"], 8, 256, return_spatial_attn=True, return_temporal_attn=True)
+        g = _load("model_T8_B1_attn.npz")
+        assert rel_l2(out[0], g["logits"]) < TOL
+        assert rel_l2(out[1], g["spatial_attn"].astype(np.float32)) < 2e-3     # stored as fp16
+        assert rel_l2(out[2], g["temporal_attn"]) < TOL
+        lg = O.csts_forward(P, b1["video"], b1["audio"], 8, 256, spatial_audio_attn=True)
+        assert rel_l2(lg, _load("model_T8_B1_saa.npz")["logits"]) < TOL
+
+
+def test_T16_forward():
+    P = O.seeded_params(16, 256)
+    b = O.synthetic_batch(1, 16, 256, seed=1002)
+    with torch.no_grad():
+        lg, v, a = O.csts_forward(P, b["video"], b["audio"], 16, 256, return_embed=True)
+    g = _load("model_T16_B1.npz")
+    assert lg.shape == (1, 1, 16, 64, 64)
+    assert rel_l2(lg, g["logits"]) < TOL and rel_l2(v, g["v_emb"]) < TOL and rel_l2(a, g["a_emb"]) < TOL
