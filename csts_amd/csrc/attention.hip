@@ -1,0 +1,585 @@
+// Fused pooled multi-head attention for the CSTS path (K6 of SURVEY.md 2.3).
+// Reference: softmax(q k^T * hd^-0.5) v, attention.py:154-158, :384-388 (decoder), av_attention.py:137-141
+// (temporal) and :334-350 (spatial, same-frame block mask).  The N_q x N_kv matrix is never materialised.
+//
+// All three kernels keep the "long" index on the MFMA lane and the "short" (reduced) index in the
+// accumulator registers, so that the score tile is directly the B operand of the second product
+// (no LDS round trip, no cross-lane shuffles except one xor-32 max):
+//   fwd  : S^T = K Q^T  (keys in regs, queries on lanes) -> online softmax -> O^T += V^T P^T
+//   dQ   : S^T, dP^T = V dO^T, dS = P (dP - delta)       -> dQ^T += K^T dS^T
+//   dKdV : S = Q K^T (queries in regs, keys on lanes), dP = dO V^T -> dV^T += dO^T P, dK^T += Q^T dS
+// K/V (or Q/dO) tiles are staged in LDS once per workgroup and shared by its 4 waves; the transposed
+// operand comes from ds_read_b64_tr_b16.  bf16 mode uses v_mfma_f32_32x32x16_bf16, f32 (parity) mode
+// v_mfma_f32_32x32x2_f32 with the accumulator registers consumed directly as the next B operand.
+// Softmax statistics, LSE and delta are fp32.  dK/dV are reduced over query splits by a second,
+// deterministic pass (no atomics).
+#include "common.h"
+
+namespace {
+
+struct AttnP {
+  const void* Q; const void* K; const void* V; void* O; float* LSE;
+  const void* dO; const float* delta; void* dQ; void* dK; void* dV; float* ws;
+  int dt, B, H, Nq, Nk;
+  int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
+  int64_t do_bs, do_ts, do_hs, dq_bs, dq_ts, dq_hs, dk_bs, dk_ts, dk_hs, dv_bs, dv_ts, dv_hs;
+  float scale, scale_log2;
+  int mask_mode, mask_T, mask_HW;
+  int q_chunk, nsplit;
+};
+
+__device__ __forceinline__ int rowoff(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ bool is_masked(const AttnP& p, int q, int k) {
+  if (p.mask_mode == 0) return false;
+  const int thw = p.mask_T * p.mask_HW;
+  const int fq = q < thw ? q / p.mask_HW : q - thw;
+  const int fk = k < thw ? k / p.mask_HW : k - thw;
+  return fq != fk;   // av_attention.py:337-346: -1e8 outside the same-frame blocks
+}
+
+template <int HD, bool F32> struct RowFrag;   // B-operand fragments of one [HD]-row per lane (lane&31 = row)
+template <int HD> struct RowFrag<HD, false> {
+  bf16x8 b[HD / 16];
+  __device__ __forceinline__ void load(const void* base, int64_t off, int h) {
+    const bf16* p = reinterpret_cast<const bf16*>(base) + off;
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) b[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s + 8 * h);
+  }
+};
+template <int HD> struct RowFrag<HD, true> {
+  float f[HD / 2];
+  __device__ __forceinline__ void load(const void* base, int64_t off, int h) {
+    const float* p = reinterpret_cast<const float*>(base) + off;
+    // plain form: f[s] = row[2s + h]
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) f[s] = p[2 * s + h];
+  }
+};
+
+template <bool F32> struct El;
+template <> struct El<false> { typedef bf16 T; };
+template <> struct El<true> { typedef float T; };
+
+// cooperative tile load: ROWS x HD elements -> LDS (row stride LD), rows >= lim zero-filled
+template <int HD, int ROWS, int LD, bool F32>
+__device__ __forceinline__ void load_tile(typename El<F32>::T* S, const void* src, int64_t base, int64_t ts, int row0,
+                                          int lim, int tid) {
+  constexpr int CPR = HD / 8, CHUNKS = ROWS * CPR;
+#pragma unroll
+  for (int c = tid; c < CHUNKS; c += 256) {
+    const int row = c / CPR, col = (c - row * CPR) * 8;
+    if (F32) {
+      float v[8];
+      if (row0 + row < lim) ld8_as_f32(src, CSTS_F32, base + (int64_t)(row0 + row) * ts + col, v);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      float* d = reinterpret_cast<float*>(S) + row * LD + col;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] = v[j];
+    } else {
+      bf16x8 v;
+      if (row0 + row < lim) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(src) + base + (int64_t)(row0 + row) * ts + col);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(S) + row * LD + col) = v;
+    }
+  }
+}
+
+// acc(32x32) += X[32 rows][HD] * frag^T   (rows of X -> accumulator rows/registers, frag rows -> lanes)
+template <int HD, int LD, bool F32>
+__device__ __forceinline__ void score(f32x16& acc, const typename El<F32>::T* X, const RowFrag<HD, F32>& fr, int lane) {
+  const int h = lane >> 5;
+  if constexpr (F32) {
+    const float* Xf = X + (lane & 31) * LD + h;
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xf[2 * s], fr.f[s], acc, 0, 0, 0);
+  } else {
+    const bf16* Xb = X + (lane & 31) * LD + 8 * h;
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xb + 16 * s);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.b[s], acc, 0, 0, 0);
+    }
+  }
+}
+
+// out[dtile](32 x 32, rows = columns dtile*32.. of Y) += Y[32 rows][HD]^T * P   where P (32x32 accumulator
+// layout: row index in registers, lane = column) is consumed as the B operand without leaving registers.
+template <int HD, int LD, bool F32>
+__device__ __forceinline__ void pv(f32x16 (&out)[HD / 32], const typename El<F32>::T* Y, const f32x16& P, int lane) {
+  const int h = lane >> 5;
+  if constexpr (F32) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float* Yr = Y + ((t & 3) + 8 * (t >> 2) + 4 * h) * LD + (lane & 31);
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d) out[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Yr[32 * d], P[t], out[d], 0, 0, 0);
+    }
+  } else {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 bp;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bp[j] = (bf16)P[8 * s + j];
+      // k order inside the step: element j of lane-half h <-> row 16s + 8(j>>2) + 4h + (j&3)
+      const bf16* Yb = Y + (16 * s + 4 * h + qq) * LD + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d) {
+        const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 32 * d));
+        const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 32 * d + 8 * LD));
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
+        bf16x8 a;
+        a[0] = b0[0]; a[1] = b0[1]; a[2] = b0[2]; a[3] = b0[3];
+        a[4] = b1[0]; a[5] = b1[1]; a[6] = b1[2]; a[7] = b1[3];
+        out[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, out[d], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// store a transposed accumulator: lane owns row `tok`, 4 consecutive columns per register quad
+template <int HD>
+__device__ __forceinline__ void store_rows(void* dst, int dt, int64_t off, const f32x16 (&acc)[HD / 32], float mul, int h) {
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int col = d * 32 + 8 * rq + 4 * h;
+      if (dt == CSTS_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + off + col) =
+            make_float4(acc[d][4 * rq] * mul, acc[d][4 * rq + 1] * mul, acc[d][4 * rq + 2] * mul, acc[d][4 * rq + 3] * mul);
+      } else {
+        bf16x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (bf16)(acc[d][4 * rq + j] * mul);
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(dst) + off + col) = v;
+      }
+    }
+  }
+}
+
+template <int HD, bool F32> struct Cfg {
+  static constexpr int KVBLK = (HD == 96) ? 64 : 32;            // rows per LDS tile
+  static constexpr int LD_ROW = F32 ? HD + 1 : HD + 8;           // tiles read row-wise (and possibly transposed)
+  static constexpr int LD_TR = F32 ? HD + 4 : (HD == 96 ? 96 : 224);  // tiles only read transposed
+};
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int HD, bool F32>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  typedef typename El<F32>::T T;
+  typedef Cfg<HD, F32> C;
+  constexpr int KT = C::KVBLK / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* Ks = reinterpret_cast<T*>(smem_raw);
+  T* Vs = Ks + C::KVBLK * C::LD_ROW;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  const bool qvalid = qraw < p.Nq;
+  const int qi = qvalid ? qraw : p.Nq - 1;
+
+  RowFrag<HD, F32> qf;
+  qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
+  f32x16 O[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+  float m = -1e30f, lsum = 0.f;
+  const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+
+  for (int k0 = 0; k0 < p.Nk; k0 += C::KVBLK) {
+    __syncthreads();
+    load_tile<HD, C::KVBLK, C::LD_ROW, F32>(Ks, p.K, kbase, p.k_ts, k0, p.Nk, tid);
+    load_tile<HD, C::KVBLK, C::LD_TR, F32>(Vs, p.V, vbase, p.v_ts, k0, p.Nk, tid);
+    __syncthreads();
+    f32x16 S[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
+      score<HD, C::LD_ROW, F32>(S[kt], Ks + kt * 32 * C::LD_ROW, qf, lane);
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + kt * 32 + rowoff(r, h);
+        float v = S[kt][r] * p.scale_log2;
+        if (key >= p.Nk || is_masked(p, qi, key)) v = -1e30f;
+        S[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    lsum *= alpha;
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(S[kt][r] - m);
+        S[kt][r] = e;
+        lsum += e;
+      }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) pv<HD, C::LD_TR, F32>(O, Vs + kt * 32 * C::LD_TR, S[kt], lane);
+  }
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (qvalid) {
+    store_rows<HD>(p.O, p.dt, (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)head * p.o_hs, O, 1.f / lsum, h);
+    if (h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dQ
+template <int HD, bool F32>
+__global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
+  typedef typename El<F32>::T T;
+  typedef Cfg<HD, F32> C;
+  constexpr int KT = C::KVBLK / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* Ks = reinterpret_cast<T*>(smem_raw);
+  T* Vs = Ks + C::KVBLK * C::LD_ROW;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  const bool qvalid = qraw < p.Nq;
+  const int qi = qvalid ? qraw : p.Nq - 1;
+
+  RowFrag<HD, F32> qf, dof;
+  qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
+  dof.load(p.dO, (int64_t)b * p.do_bs + (int64_t)qi * p.do_ts + (int64_t)head * p.do_hs, h);
+  const float L = p.LSE[((int64_t)b * p.H + head) * p.Nq + qi];
+  const float dl = p.delta[((int64_t)b * p.H + head) * p.Nq + qi];
+  f32x16 acc[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+
+  for (int k0 = 0; k0 < p.Nk; k0 += C::KVBLK) {
+    __syncthreads();
+    load_tile<HD, C::KVBLK, C::LD_ROW, F32>(Ks, p.K, kbase, p.k_ts, k0, p.Nk, tid);
+    load_tile<HD, C::KVBLK, C::LD_ROW, F32>(Vs, p.V, vbase, p.v_ts, k0, p.Nk, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+      score<HD, C::LD_ROW, F32>(S, Ks + kt * 32 * C::LD_ROW, qf, lane);
+      score<HD, C::LD_ROW, F32>(dP, Vs + kt * 32 * C::LD_ROW, dof, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + kt * 32 + rowoff(r, h);
+        const bool dead = key >= p.Nk || is_masked(p, qi, key);
+        const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * p.scale_log2 - L);
+        S[r] = pr * (dP[r] - dl);
+      }
+      pv<HD, C::LD_ROW, F32>(acc, Ks + kt * 32 * C::LD_ROW, S, lane);
+    }
+  }
+  if (qvalid)
+    store_rows<HD>(p.dQ, p.dt, (int64_t)b * p.dq_bs + (int64_t)qi * p.dq_ts + (int64_t)head * p.dq_hs, acc, p.scale, h);
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+template <int HD, bool F32>
+__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
+  typedef typename El<F32>::T T;
+  typedef Cfg<HD, F32> C;
+  constexpr int QBLK = C::KVBLK, QT = QBLK / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* Qs = reinterpret_cast<T*>(smem_raw);
+  T* dOs = Qs + QBLK * C::LD_ROW;
+  float* Ls = reinterpret_cast<float*>(dOs + QBLK * C::LD_ROW);
+  float* Ds = Ls + QBLK;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z / p.H, head = blockIdx.z % p.H;
+  const int split = blockIdx.y;
+  const int kraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  const bool kvalid = kraw < p.Nk;
+  const int ki = kvalid ? kraw : p.Nk - 1;
+
+  RowFrag<HD, F32> kf, vf;
+  kf.load(p.K, (int64_t)b * p.k_bs + (int64_t)ki * p.k_ts + (int64_t)head * p.k_hs, h);
+  vf.load(p.V, (int64_t)b * p.v_bs + (int64_t)ki * p.v_ts + (int64_t)head * p.v_hs, h);
+  f32x16 dK[HD / 32], dV[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dK[d][r] = 0.f; dV[d][r] = 0.f; }
+  const int64_t qbase = (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
+  const int64_t dobase = (int64_t)b * p.do_bs + (int64_t)head * p.do_hs;
+  const int qbeg = split * p.q_chunk, qend = min(p.Nq, qbeg + p.q_chunk);
+  const int64_t statbase = ((int64_t)b * p.H + head) * p.Nq;
+
+  for (int q0 = qbeg; q0 < qend; q0 += QBLK) {
+    __syncthreads();
+    load_tile<HD, QBLK, C::LD_ROW, F32>(Qs, p.Q, qbase, p.q_ts, q0, qend, tid);
+    load_tile<HD, QBLK, C::LD_ROW, F32>(dOs, p.dO, dobase, p.do_ts, q0, qend, tid);
+    if (tid < QBLK) {
+      const bool ok = q0 + tid < qend;
+      Ls[tid] = ok ? p.LSE[statbase + q0 + tid] : 0.f;
+      Ds[tid] = ok ? p.delta[statbase + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+      score<HD, C::LD_ROW, F32>(S, Qs + qt * 32 * C::LD_ROW, kf, lane);
+      score<HD, C::LD_ROW, F32>(dP, dOs + qt * 32 * C::LD_ROW, vf, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = qt * 32 + rowoff(r, h);
+        const int q = q0 + ql;
+        const bool dead = q >= qend || !kvalid || is_masked(p, q, ki);
+        const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * p.scale_log2 - Ls[ql]);
+        S[r] = pr;
+        dP[r] = pr * (dP[r] - Ds[ql]);
+      }
+      pv<HD, C::LD_ROW, F32>(dV, dOs + qt * 32 * C::LD_ROW, S, lane);
+      pv<HD, C::LD_ROW, F32>(dK, Qs + qt * 32 * C::LD_ROW, dP, lane);
+    }
+  }
+  if (!kvalid) return;
+  if (p.nsplit == 1) {
+    store_rows<HD>(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)ki * p.dk_ts + (int64_t)head * p.dk_hs, dK, p.scale, h);
+    store_rows<HD>(p.dV, p.dt, (int64_t)b * p.dv_bs + (int64_t)ki * p.dv_ts + (int64_t)head * p.dv_hs, dV, 1.f, h);
+  } else {
+    // ws layout: [2 (dK,dV)][split][B][H][Nk][HD] fp32
+    const int64_t per = (int64_t)p.B * p.H * p.Nk * HD;
+    const int64_t off = (((int64_t)split * p.B + b) * p.H + head) * (int64_t)p.Nk * HD + (int64_t)ki * HD;
+    store_rows<HD>(p.ws, CSTS_F32, off, dK, p.scale, h);
+    store_rows<HD>(p.ws, CSTS_F32, (int64_t)p.nsplit * per + off, dV, 1.f, h);
+  }
+}
+
+// second pass: dK/dV[b, k, head, :] = sum_split ws[...]
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnP p, int HD) {
+  const int64_t per = (int64_t)p.B * p.H * p.Nk * HD;
+  const int64_t total = 2 * per;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int which = idx >= per;
+    int64_t e = idx - which * per;
+    float s = 0.f;
+    for (int sp = 0; sp < p.nsplit; ++sp) s += p.ws[((int64_t)which * p.nsplit + sp) * per + e];
+    const int d = (int)(e % HD); e /= HD;
+    const int k = (int)(e % p.Nk); e /= p.Nk;
+    const int head = (int)(e % p.H);
+    const int b = (int)(e / p.H);
+    if (which == 0) st_from_f32(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)k * p.dk_ts + (int64_t)head * p.dk_hs + d, s);
+    else st_from_f32(p.dV, p.dt, (int64_t)b * p.dv_bs + (int64_t)k * p.dv_ts + (int64_t)head * p.dv_hs + d, s);
+  }
+}
+
+// delta[b,h,q] = sum_d dO * O   (32 lanes per row)
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p, int HD) {
+  const int sub = threadIdx.x & 31;
+  const int64_t rows = (int64_t)p.B * p.H * p.Nq;
+  const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
+  for (int64_t row = row0; row < rows; row += stride) {
+    const int q = (int)(row % p.Nq);
+    const int64_t bh = row / p.Nq;
+    const int head = (int)(bh % p.H), b = (int)(bh / p.H);
+    const int64_t oo = (int64_t)b * p.o_bs + (int64_t)q * p.o_ts + (int64_t)head * p.o_hs;
+    const int64_t od = (int64_t)b * p.do_bs + (int64_t)q * p.do_ts + (int64_t)head * p.do_hs;
+    float s = 0.f;
+    for (int d = sub; d < HD; d += 32) s += ld_as_f32(p.O, p.dt, oo + d) * ld_as_f32(p.dO, p.dt, od + d);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) const_cast<float*>(p.delta)[row] = s;
+  }
+}
+
+// probabilities for the visualisation outputs (return_spatial_attn / return_temporal_attn), tiny N only
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnP p, int HD, float* probs) {
+  const int64_t total = (int64_t)p.B * p.H * p.Nq * p.Nk;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % p.Nk);
+    int64_t e = idx / p.Nk;
+    const int q = (int)(e % p.Nq); e /= p.Nq;
+    const int head = (int)(e % p.H);
+    const int b = (int)(e / p.H);
+    float s = 0.f;
+    const int64_t qo = (int64_t)b * p.q_bs + (int64_t)q * p.q_ts + (int64_t)head * p.q_hs;
+    const int64_t ko = (int64_t)b * p.k_bs + (int64_t)k * p.k_ts + (int64_t)head * p.k_hs;
+    for (int d = 0; d < HD; ++d) s += ld_as_f32(p.Q, p.dt, qo + d) * ld_as_f32(p.K, p.dt, ko + d);
+    const float L = p.LSE[((int64_t)b * p.H + head) * p.Nq + q];
+    probs[idx] = is_masked(p, q, k) ? 0.f : exp2f(s * p.scale_log2 - L);
+  }
+}
+
+template <int HD, bool F32> size_t smem_fwd() {
+  typedef Cfg<HD, F32> C;
+  return (size_t)C::KVBLK * (C::LD_ROW + C::LD_TR) * (F32 ? 4 : 2);
+}
+template <int HD, bool F32> size_t smem_bwd() {
+  typedef Cfg<HD, F32> C;
+  return (size_t)C::KVBLK * 2 * C::LD_ROW * (F32 ? 4 : 2) + 2 * C::KVBLK * sizeof(float);
+}
+
+int fill(const csts_attn_args* a, AttnP& p) {
+  p.Q = a->Q; p.K = a->K; p.V = a->V; p.O = a->O; p.LSE = a->LSE; p.dO = a->dO; p.delta = a->delta;
+  p.dQ = a->dQ; p.dK = a->dK; p.dV = a->dV; p.ws = nullptr;
+  p.dt = a->dtype; p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
+  p.q_bs = a->q_strides[0]; p.q_ts = a->q_strides[1]; p.q_hs = a->q_strides[2];
+  p.k_bs = a->k_strides[0]; p.k_ts = a->k_strides[1]; p.k_hs = a->k_strides[2];
+  p.v_bs = a->v_strides[0]; p.v_ts = a->v_strides[1]; p.v_hs = a->v_strides[2];
+  p.o_bs = a->o_strides[0]; p.o_ts = a->o_strides[1]; p.o_hs = a->o_strides[2];
+  p.do_bs = a->do_strides[0]; p.do_ts = a->do_strides[1]; p.do_hs = a->do_strides[2];
+  p.dq_bs = a->dq_strides[0]; p.dq_ts = a->dq_strides[1]; p.dq_hs = a->dq_strides[2];
+  p.dk_bs = a->dk_strides[0]; p.dk_ts = a->dk_strides[1]; p.dk_hs = a->dk_strides[2];
+  p.dv_bs = a->dv_strides[0]; p.dv_ts = a->dv_strides[1]; p.dv_hs = a->dv_strides[2];
+  p.scale = a->scale;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.mask_mode = a->mask_mode; p.mask_T = a->mask_T; p.mask_HW = a->mask_HW;
+  p.q_chunk = 0; p.nsplit = 1;
+  return 0;
+}
+
+bool strides_ok(const int64_t* s, int dt) {
+  const int a = dt == CSTS_F32 ? 4 : 8;
+  return s[0] % a == 0 && s[1] % a == 0 && s[2] % a == 0;
+}
+
+void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
+  const int qblk = a->head_dim == 96 ? 64 : 32;
+  const int64_t base = cdiv(a->Nk, 128) * a->B * a->H;
+  int64_t want = std::max<int64_t>(1, 512 / base);
+  want = std::min<int64_t>(want, cdiv(a->Nq, 4 * qblk));
+  want = std::max<int64_t>(want, 1);
+  q_chunk = (int)(cdiv(cdiv(a->Nq, want), qblk) * qblk);
+  nsplit = (int)cdiv(a->Nq, q_chunk);
+}
+
+}  // namespace
+
+#define ATTN_COMMON_CHECKS(a)                                                                           \
+  CSTS_REQUIRE((a) != nullptr, "null args");                                                            \
+  CSTS_REQUIRE((a)->head_dim == 96 || (a)->head_dim == 192, "head_dim must be 96 or 192");              \
+  CSTS_REQUIRE((a)->dtype == CSTS_F32 || (a)->dtype == CSTS_BF16, "bad dtype");                         \
+  CSTS_REQUIRE((a)->B > 0 && (a)->H > 0 && (a)->Nq > 0 && (a)->Nk > 0, "empty problem");                \
+  CSTS_REQUIRE((a)->Q && (a)->K && (a)->V, "null q/k/v");                                               \
+  CSTS_REQUIRE(aligned16((a)->Q) && aligned16((a)->K) && aligned16((a)->V), "q/k/v must be 16-byte aligned"); \
+  CSTS_REQUIRE(strides_ok((a)->q_strides, (a)->dtype) && strides_ok((a)->k_strides, (a)->dtype) &&      \
+                   strides_ok((a)->v_strides, (a)->dtype),                                             \
+               "strides must keep 16-byte row alignment");                                              \
+  if ((a)->mask_mode == CSTS_MASK_SPATIAL)                                                              \
+  CSTS_REQUIRE((a)->Nq == (a)->mask_T * (a)->mask_HW + (a)->mask_T && (a)->Nk == (a)->Nq, "spatial mask needs Nq == Nk == T*HW + T")
+
+enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
+template <int HD, bool F32>
+static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream) {
+  if (which == K_FWD) {
+    const size_t sm = smem_fwd<HD, F32>();
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
+  } else if (which == K_DQ) {
+    const size_t sm = smem_bwd<HD, F32>();
+    hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
+  } else {
+    const size_t sm = smem_bwd<HD, F32>();
+    hipLaunchKernelGGL((attn_dkv_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
+  }
+}
+static void attn_dispatch(int which, const csts_attn_args* a, const AttnP& p, dim3 grid, hipStream_t stream) {
+  const bool f32 = a->dtype == CSTS_F32;
+  if (a->head_dim == 96) {
+    if (f32) attn_launch<96, true>(which, p, grid, stream);
+    else attn_launch<96, false>(which, p, grid, stream);
+  } else {
+    if (f32) attn_launch<192, true>(which, p, grid, stream);
+    else attn_launch<192, false>(which, p, grid, stream);
+  }
+}
+
+extern "C" int csts_attn_fwd(const csts_attn_args* a, hipStream_t stream) {
+  ATTN_COMMON_CHECKS(a);
+  CSTS_REQUIRE(a->O && a->LSE && aligned16(a->O) && strides_ok(a->o_strides, a->dtype), "bad output");
+  AttnP p; fill(a, p);
+  dim3 grid((unsigned)cdiv(a->Nq, 128), a->H, a->B);
+  attn_dispatch(K_FWD, a, p, grid, stream);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t csts_attn_bwd_workspace(const csts_attn_args* a) {
+  if (!a) return 0;
+  int nsplit, q_chunk;
+  dkv_plan(a, nsplit, q_chunk);
+  return nsplit > 1 ? (size_t)2 * nsplit * a->B * a->H * a->Nk * a->head_dim * sizeof(float) : 16;
+}
+
+extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  ATTN_COMMON_CHECKS(a);
+  CSTS_REQUIRE(a->O && a->LSE && a->dO && a->delta && a->dQ && a->dK && a->dV, "null backward operand");
+  CSTS_REQUIRE(aligned16(a->dO) && aligned16(a->dQ) && aligned16(a->dK) && aligned16(a->dV), "alignment");
+  CSTS_REQUIRE(strides_ok(a->do_strides, a->dtype) && strides_ok(a->dq_strides, a->dtype) &&
+                   strides_ok(a->dk_strides, a->dtype) && strides_ok(a->dv_strides, a->dtype) &&
+                   strides_ok(a->o_strides, a->dtype), "strides must keep 16-byte row alignment");
+  AttnP p; fill(a, p);
+  // 1. delta = rowsum(dO * O)
+  {
+    const int64_t rows = (int64_t)a->B * a->H * a->Nq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)std::min<int64_t>(cdiv(rows * 32, 256), 8192)), dim3(256), 0,
+                       stream, p, a->head_dim);
+    CSTS_LAUNCH_CHECK();
+  }
+  // 2. dQ
+  {
+    dim3 grid((unsigned)cdiv(a->Nq, 128), a->H, a->B);
+    attn_dispatch(K_DQ, a, p, grid, stream);
+    CSTS_LAUNCH_CHECK();
+  }
+  // 3. dK, dV (query-split, deterministic reduce)
+  {
+    dkv_plan(a, p.nsplit, p.q_chunk);
+    if (p.nsplit > 1) {
+      CSTS_REQUIRE(workspace != nullptr && ws_bytes >= csts_attn_bwd_workspace(a), "workspace too small");
+      p.ws = reinterpret_cast<float*>(workspace);
+    }
+    dim3 grid((unsigned)cdiv(a->Nk, 128), p.nsplit, a->B * a->H);
+    attn_dispatch(K_DKV, a, p, grid, stream);
+    CSTS_LAUNCH_CHECK();
+    if (p.nsplit > 1) {
+      const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
+                         stream, p, a->head_dim);
+      CSTS_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+extern "C" int csts_attn_probs(const csts_attn_args* a, float* probs, hipStream_t stream) {
+  ATTN_COMMON_CHECKS(a);
+  CSTS_REQUIRE(a->LSE && probs, "null pointer");
+  AttnP p; fill(a, p);
+  const int64_t total = (int64_t)a->B * a->H * a->Nq * a->Nk;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p,
+                     a->head_dim, probs);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,98 @@
+// Shared device/host helpers for the CSTS gfx950 kernel library.
+// Everything here is CDNA4-only (wave64, MFMA, 160 KiB LDS); no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "../../include/csts_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// ---------------------------------------------------------------- errors
+void csts_set_error(const std::string& s);
+#define CSTS_FAIL(msg)                                                         \
+  do {                                                                         \
+    csts_set_error(std::string(__func__) + ": " + (msg));                      \
+    return -1;                                                                 \
+  } while (0)
+#define CSTS_REQUIRE(cond, msg)                                                \
+  do {                                                                         \
+    if (!(cond)) CSTS_FAIL(std::string(msg) + " [" #cond "]");                 \
+  } while (0)
+#define CSTS_LAUNCH_CHECK()                                                    \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) CSTS_FAIL(std::string("launch: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- dtype-generic scalar access
+// dt is wave-uniform at every call site, so the branch is a scalar branch.
+__device__ __forceinline__ float ld_as_f32(const void* p, int dt, int64_t i) {
+  return dt == CSTS_F32 ? reinterpret_cast<const float*>(p)[i] : (float)reinterpret_cast<const bf16*>(p)[i];
+}
+__device__ __forceinline__ void st_from_f32(void* p, int dt, int64_t i, float v) {
+  if (dt == CSTS_F32) reinterpret_cast<float*>(p)[i] = v;
+  else reinterpret_cast<bf16*>(p)[i] = (bf16)v;
+}
+
+// 8 consecutive elements -> 8 floats (16-byte vector loads when aligned)
+__device__ __forceinline__ void ld8_as_f32(const void* p, int dt, int64_t i, float (&o)[8]) {
+  if (dt == CSTS_F32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+    float4 a = q[0], b = q[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+  }
+}
+__device__ __forceinline__ void st8_from_f32(void* p, int dt, int64_t i, const float (&o)[8]) {
+  if (dt == CSTS_F32) {
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i);
+    q[0] = make_float4(o[0], o[1], o[2], o[3]);
+    q[1] = make_float4(o[4], o[5], o[6], o[7]);
+  } else {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)o[j];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p) + i) = v;
+  }
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (reference: nn.GELU(approximate='none'), common.py:21)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// second stage of every cross-block reduction (norm.hip): out[j] = scale * sum_i ws[i][j]
+int csts_reduce_rows_launch(const float* ws, float* out, int64_t nrows, int64_t ncols, float scale, hipStream_t s);

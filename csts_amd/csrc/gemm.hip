@@ -1,0 +1,275 @@
+// MFMA GEMM family for the CSTS path (K3/K9 of SURVEY.md 2.3): every Linear / fusion-conv /
+// patch-embed contraction, forward (NT), data-gradient (NN) and weight-gradient (TN).
+//
+//   NT: C[m,n] = sum_k A[m,k] * B[n,k]      (x @ W^T; reference nn.Linear, attention.py:130,159; common.py:27-33)
+//   NN: C[m,n] = sum_k A[m,k] * B[k,n]      (dY @ W)
+//   TN: C[m,n] = sum_k A[k,m] * B[k,n]      (dY^T @ X, split over k with fp32 atomics)
+//
+// Tile 128x128x32, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 accumulators.
+// bf16 mode: v_mfma_f32_32x32x16_bf16, operands converted to bf16 while staging (fp32 master weights are
+// read directly, no shadow copy).  f32 mode: v_mfma_f32_32x32x2_f32 (exact fp32, the parity mode).
+// Operands whose reduction dim is NOT the contiguous one are kept [k][out] in LDS and fed to the MFMA through
+// ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32), so staging is always a straight 16-byte copy.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT_ = 256;
+// LDS row strides (elements)
+constexpr int KC_LD_BF = BK + 8;     // 80 B rows
+constexpr int OC_LD_BF = 128 + 32;   // 320 B rows: conflict-free ds_read_b64_tr_b16 (bank = 16q + 2p + 8g)
+constexpr int KC_LD_F = BK + 1;      // 33 floats: conflict-free ds_read_b32 over rows
+constexpr int OC_LD_F = 128 + 4;
+
+template <bool F32> struct Cmp;
+template <> struct Cmp<false> { typedef bf16 T; };
+template <> struct Cmp<true> { typedef float T; };
+
+struct Params {
+  const void* A; const void* B; void* C;
+  const float* bias; void* aux; const void* residual; const float* row_scale;
+  int64_t lda, ldb, ldc, ldaux, ldr;
+  int64_t M, N, K, res_row_mod, rows_per_scale, k_chunk;
+  int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
+};
+
+// load 8 consecutive source elements (guarded) as floats
+__device__ __forceinline__ void load8(const void* p, int dt, int64_t idx, int nvalid, bool vec, float (&o)[8]) {
+  if (nvalid >= 8 && vec) {
+    ld8_as_f32(p, dt, idx, o);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (j < nvalid) ? ld_as_f32(p, dt, idx + j) : 0.f;
+  }
+}
+
+template <bool F32> struct Stage {  // register-resident copy of this thread's two chunks of one operand tile
+  float v[2][8];
+};
+
+template <bool KC>
+__device__ __forceinline__ void stage_load(const void* P, int dt, int64_t ld, bool vec, int64_t out0, int64_t out_lim,
+                                           int64_t k0, int64_t k_lim, int tid, float (&v)[2][8]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + NT_ * i;
+    if (KC) {
+      const int row = c >> 2, kc = (c & 3) * 8;
+      const int64_t r = out0 + row, k = k0 + kc;
+      int nvalid = (r < out_lim) ? (int)min((int64_t)8, max((int64_t)0, k_lim - k)) : 0;
+      load8(P, dt, r * ld + k, nvalid, vec, v[i]);
+    } else {
+      const int krow = c >> 4, oc = (c & 15) * 8;
+      const int64_t k = k0 + krow, o = out0 + oc;
+      int nvalid = (k < k_lim) ? (int)min((int64_t)8, max((int64_t)0, out_lim - o)) : 0;
+      load8(P, dt, k * ld + o, nvalid, vec, v[i]);
+    }
+  }
+}
+
+template <bool KC, bool F32>
+__device__ __forceinline__ void stage_store(typename Cmp<F32>::T* S, int tid, const float (&v)[2][8]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + NT_ * i;
+    if (F32) {
+      float* Sf = reinterpret_cast<float*>(S);
+      if (KC) {
+        const int row = c >> 2, kc = (c & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Sf[row * KC_LD_F + kc + j] = v[i][j];
+      } else {
+        const int krow = c >> 4, oc = (c & 15) * 8;
+        float4* d = reinterpret_cast<float4*>(&Sf[krow * OC_LD_F + oc]);
+        d[0] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        d[1] = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+      }
+    } else {
+      bf16* Sb = reinterpret_cast<bf16*>(S);
+      bf16x8 w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (bf16)v[i][j];
+      if (KC) {
+        const int row = c >> 2, kc = (c & 3) * 8;
+        *reinterpret_cast<bf16x8*>(&Sb[row * KC_LD_BF + kc]) = w;
+      } else {
+        const int krow = c >> 4, oc = (c & 15) * 8;
+        *reinterpret_cast<bf16x8*>(&Sb[krow * OC_LD_BF + oc]) = w;
+      }
+    }
+  }
+}
+
+// bf16 MFMA fragment (8 k-values for output index obase + (lane&31)), k-substep ks (16 wide)
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag_bf16(const bf16* S, int obase, int ks, int lane) {
+  if (KC) {
+    return *reinterpret_cast<const bf16x8*>(&S[(obase + (lane & 31)) * KC_LD_BF + ks * 16 + 8 * (lane >> 5)]);
+  } else {
+    // S is [k][out]; transposing read: each 16-lane group fetches a 4(k) x 16(out) block column-major.
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16* a = &S[(ks * 16 + 8 * (g >> 1) + q) * OC_LD_BF + obase + 16 * (g & 1) + 4 * p];
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * OC_LD_BF));
+    bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
+    bf16x8 r;
+    r[0] = b0[0]; r[1] = b0[1]; r[2] = b0[2]; r[3] = b0[3];
+    r[4] = b1[0]; r[5] = b1[1]; r[6] = b1[2]; r[7] = b1[3];
+    return r;
+  }
+}
+// f32 MFMA 32x32x2 fragment: one value, k = 2*ks + (lane>>5)
+template <bool KC>
+__device__ __forceinline__ float frag_f32(const float* S, int obase, int ks, int lane) {
+  if (KC) return S[(obase + (lane & 31)) * KC_LD_F + 2 * ks + (lane >> 5)];
+  return S[(2 * ks + (lane >> 5)) * OC_LD_F + obase + (lane & 31)];
+}
+
+template <bool A_KC, bool B_KC, bool F32>
+__global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
+  typedef typename Cmp<F32>::T T;
+  constexpr int A_ELEMS = F32 ? (A_KC ? BM * KC_LD_F : BK * OC_LD_F) : (A_KC ? BM * KC_LD_BF : BK * OC_LD_BF);
+  constexpr int B_ELEMS = F32 ? (B_KC ? BN * KC_LD_F : BK * OC_LD_F) : (B_KC ? BN * KC_LD_BF : BK * OC_LD_BF);
+  __shared__ __attribute__((aligned(16))) T smem[A_ELEMS + B_ELEMS];
+  T* As = smem;
+  T* Bs = smem + A_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t tile_n = blockIdx.x % p.ntiles_n, tile_m = blockIdx.x / p.ntiles_n;
+  const int64_t m0 = tile_m * BM, n0 = tile_n * BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * p.k_chunk;
+  const int64_t kend = min(p.K, kbeg + p.k_chunk);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float ra[2][8], rb[2][8];
+  stage_load<A_KC>(p.A, p.a_dt, p.lda, p.a_vec, m0, p.M, kbeg, kend, tid, ra);
+  stage_load<B_KC>(p.B, p.b_dt, p.ldb, p.b_vec, n0, p.N, kbeg, kend, tid, rb);
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // previous tile fully consumed
+    stage_store<A_KC, F32>(As, tid, ra);
+    stage_store<B_KC, F32>(Bs, tid, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {  // prefetch next tile into registers; latency hides under the MFMAs below
+      stage_load<A_KC>(p.A, p.a_dt, p.lda, p.a_vec, m0, p.M, k0 + BK, kend, tid, ra);
+      stage_load<B_KC>(p.B, p.b_dt, p.ldb, p.b_vec, n0, p.N, k0 + BK, kend, tid, rb);
+    }
+    if (F32) {
+      const float* Af = reinterpret_cast<const float*>(As);
+      const float* Bf = reinterpret_cast<const float*>(Bs);
+#pragma unroll 4
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        float a0 = frag_f32<A_KC>(Af, wm * 64, ks, lane), a1 = frag_f32<A_KC>(Af, wm * 64 + 32, ks, lane);
+        float b0 = frag_f32<B_KC>(Bf, wn * 64, ks, lane), b1 = frag_f32<B_KC>(Bf, wn * 64 + 32, ks, lane);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    } else {
+      const bf16* Ab = reinterpret_cast<const bf16*>(As);
+      const bf16* Bb = reinterpret_cast<const bf16*>(Bs);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a0 = frag_bf16<A_KC>(Ab, wm * 64, ks, lane), a1 = frag_bf16<A_KC>(Ab, wm * 64 + 32, ks, lane);
+        bf16x8 b0 = frag_bf16<B_KC>(Bb, wn * 64, ks, lane), b1 = frag_bf16<B_KC>(Bb, wn * 64 + 32, ks, lane);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool first_split = (blockIdx.y == 0);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int64_t n = n0 + wn * 64 + nt * 32 + (lane & 31);
+      if (n >= p.N) continue;
+      const float bias = (p.bias != nullptr && first_split) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[mt][nt][r] + bias;
+        if (p.split_k > 1) {
+          atomicAdd(reinterpret_cast<float*>(p.C) + m * p.ldc + n, v);
+          continue;
+        }
+        if (p.epilogue == CSTS_EPI_GELU) {
+          if (p.aux != nullptr) st_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
+          v = gelu_f(v);
+        } else if (p.epilogue == CSTS_EPI_DGELU) {
+          v *= dgelu_f(ld_as_f32(p.aux, p.aux_dt, m * p.ldaux + n));
+        }
+        if (p.row_scale != nullptr) v *= p.row_scale[m / p.rows_per_scale];
+        if (p.residual != nullptr) {
+          const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+          v += ld_as_f32(p.residual, p.r_dt, rm * p.ldr + n);
+        }
+        st_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
+      }
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC>
+void launch(const Params& p, int compute, dim3 grid, hipStream_t s) {
+  if (compute == CSTS_F32) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(NT_), 0, s, p);
+  else hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false>), grid, dim3(NT_), 0, s, p);
+}
+
+}  // namespace
+
+extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
+  CSTS_REQUIRE(a != nullptr, "null args");
+  CSTS_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
+  CSTS_REQUIRE(a->layout >= CSTS_GEMM_NT && a->layout <= CSTS_GEMM_TN, "bad layout");
+  CSTS_REQUIRE(a->A && a->B && a->C, "null operand");
+  CSTS_REQUIRE(a->compute == CSTS_F32 || a->compute == CSTS_BF16, "bad compute dtype");
+  const int split = a->split_k > 1 ? a->split_k : 1;
+  if (split > 1) {
+    CSTS_REQUIRE(a->c_dt == CSTS_F32, "split-k accumulates with fp32 atomics: C must be f32 (pre-zeroed)");
+    CSTS_REQUIRE(a->epilogue == CSTS_EPI_NONE && !a->residual && !a->row_scale, "split-k allows bias only");
+  }
+  if (a->epilogue == CSTS_EPI_DGELU) CSTS_REQUIRE(a->aux != nullptr, "DGELU needs aux (pre-activation)");
+  Params p;
+  p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.residual = a->residual;
+  p.row_scale = a->row_scale;
+  p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux; p.ldr = a->ldr;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.res_row_mod = a->res_row_mod;
+  p.rows_per_scale = a->rows_per_scale > 0 ? a->rows_per_scale : 1;
+  p.a_dt = a->a_dt; p.b_dt = a->b_dt; p.c_dt = a->c_dt; p.aux_dt = a->aux_dt; p.r_dt = a->r_dt;
+  p.epilogue = a->epilogue; p.split_k = split;
+  auto vec_ok = [](const void* ptr, int dt, int64_t ld) {
+    return aligned16(ptr) && (ld % (dt == CSTS_F32 ? 4 : 8) == 0);
+  };
+  p.a_vec = vec_ok(a->A, a->a_dt, a->lda);
+  p.b_vec = vec_ok(a->B, a->b_dt, a->ldb);
+  const int64_t ktiles = cdiv(a->K, BK);
+  p.k_chunk = cdiv(ktiles, split) * BK;
+  const int64_t nsplit = cdiv(a->K, p.k_chunk);
+  p.ntiles_n = (int)cdiv(a->N, BN);
+  const int64_t mtiles = cdiv(a->M, BM);
+  CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
+  dim3 grid((unsigned)(mtiles * p.ntiles_n), (unsigned)nsplit, 1);
+  switch (a->layout) {
+    case CSTS_GEMM_NT: launch<true, true>(p, a->compute, grid, stream); break;
+    case CSTS_GEMM_NN: launch<true, false>(p, a->compute, grid, stream); break;
+    default: launch<false, false>(p, a->compute, grid, stream); break;
+  }
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}

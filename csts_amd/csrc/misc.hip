@@ -1,0 +1,476 @@
+// Layout, reduction and loss kernels around the GEMM/attention core of the CSTS path
+// (K1 im2col, K9 token fold, K10 glue, K11 head + losses of SURVEY.md 2.3).  All HBM-bound, fp32 math.
+#include "common.h"
+
+
+
+namespace {
+
+int grid_for(int64_t total, int per_block = 256) { return (int)std::min<int64_t>(cdiv(total, per_block), 256 * 16); }
+
+// ------------------------------------------------------------------ patch-embed im2col
+// col[(b,to,ho,wo)][k], k = ((ci*KT+kt)*KH+kh)*KW+kw  == flattening of Conv3d weight (Cout, Cin, KT, KH, KW)
+// (stem_helper.py:27-38: Conv3d k(3,7,7) s(2,4,4) p(1,3,3), tokens ordered t -> h -> w)
+struct Im2colP {
+  int B, Cin, T, H, W, KT, KH, KW, st, sh, sw, pt, ph, pw, To, Ho, Wo, K, Kpad;
+};
+__global__ __launch_bounds__(256) void im2col_kernel(Im2colP g, const void* __restrict__ x, int x_dt,
+                                                     void* __restrict__ col, int c_dt) {
+  const int64_t rows = (int64_t)g.B * g.To * g.Ho * g.Wo;
+  const int64_t total = rows * g.Kpad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % g.Kpad);
+    int64_t r = idx / g.Kpad;
+    float v = 0.f;
+    if (k < g.K) {
+      const int wo = (int)(r % g.Wo); r /= g.Wo;
+      const int ho = (int)(r % g.Ho); r /= g.Ho;
+      const int to = (int)(r % g.To);
+      const int b = (int)(r / g.To);
+      int kk = k;
+      const int kw = kk % g.KW; kk /= g.KW;
+      const int kh = kk % g.KH; kk /= g.KH;
+      const int kt = kk % g.KT;
+      const int ci = kk / g.KT;
+      const int t = to * g.st - g.pt + kt, h = ho * g.sh - g.ph + kh, w = wo * g.sw - g.pw + kw;
+      if (t >= 0 && t < g.T && h >= 0 && h < g.H && w >= 0 && w < g.W)
+        v = ld_as_f32(x, x_dt, ((((int64_t)b * g.Cin + ci) * g.T + t) * g.H + h) * g.W + w);
+    }
+    st_from_f32(col, c_dt, idx, v);
+  }
+}
+
+// pos[n][c] = spatial[n % HW][c] + temporal[n / HW][c]   (custom_multimodal_builder.py:362-366)
+__global__ void posembed_kernel(const float* __restrict__ ps, const float* __restrict__ pt, float* __restrict__ pos,
+                                int T, int HW, int C) {
+  const int64_t total = (int64_t)T * HW * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int64_t n = idx / C;
+    pos[idx] = ps[(n % HW) * C + c] + pt[(n / HW) * C + c];
+  }
+}
+
+// ------------------------------------------------------------------ batched transpose [batch][R][Cc] -> [batch][Cc][R]
+// folds tokens for the (1,8,8) fusion convs: A'[(b,t)][ci*HW + hw] = x[b, t*HW + hw, ci]
+// (custom_multimodal_builder.py:420,442,444: permute(0,4,1,2,3) before Conv3d)
+__global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, int in_dt, void* __restrict__ out,
+                                                        int out_dt, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int64_t base = (int64_t)blockIdx.z * R * Cc;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < Cc) ? ld_as_f32(in, in_dt, base + (int64_t)r * Cc + c) : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) st_from_f32(out, out_dt, base + (int64_t)c * R + r, tile[tx][j]);
+  }
+}
+
+// ------------------------------------------------------------------ column sums (bias / pos-embed / classifier grads)
+// out[batch][n] = sum_m rw[m] * X[batch][m][n]    two-stage: ws[chunk][batch*N] then reduce_rows
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ X, int dt, const float* __restrict__ rw,
+                                                     float* __restrict__ ws, int64_t M, int64_t N, int64_t chunk) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t batch = blockIdx.z;
+  const int64_t mbeg = (int64_t)blockIdx.y * chunk, mend = min(M, mbeg + chunk);
+  float s = 0.f;
+  if (n < N) {
+    for (int64_t m = mbeg + ty; m < mend; m += 4) {
+      const float v = ld_as_f32(X, dt, (batch * M + m) * N + n);
+      s += rw ? v * rw[batch * M + m] : v;
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N)
+    ws[((int64_t)blockIdx.y * gridDim.z + batch) * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+// ------------------------------------------------------------------ row softmax with temperature (frame_softmax)
+// slowfast/utils/utils.py:5-12 ; one workgroup per (b,t) row of H*W logits
+template <bool BWD>
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+                                                      float* __restrict__ out, int n, float inv_temp) {
+  __shared__ float red[8];
+  const int64_t row = blockIdx.x;
+  const float* xr = x + row * n;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  auto block_reduce = [&](float v, bool is_max) {
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+  };
+  float mx = -INFINITY;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, xr[i] * inv_temp);
+  mx = block_reduce(mx, true);
+  float s = 0.f;
+  for (int i = tid; i < n; i += 256) s += __expf(xr[i] * inv_temp - mx);
+  s = block_reduce(s, false);
+  const float inv = 1.f / s;
+  if (!BWD) {
+    for (int i = tid; i < n; i += 256) out[row * n + i] = __expf(xr[i] * inv_temp - mx) * inv;
+  } else {
+    const float* dr = dp + row * n;
+    float dot = 0.f;
+    for (int i = tid; i < n; i += 256) dot += dr[i] * __expf(xr[i] * inv_temp - mx) * inv;
+    dot = block_reduce(dot, false);
+    for (int i = tid; i < n; i += 256) {
+      const float p = __expf(xr[i] * inv_temp - mx) * inv;
+      out[row * n + i] = p * (dr[i] - dot) * inv_temp;
+    }
+  }
+}
+
+// KLDiv (losses.py:59-82): row = sum_i p (log(p+eps) - log(q+eps))
+__global__ __launch_bounds__(256) void kldiv_fwd_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                        float* __restrict__ rowloss, int n) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float pv = p[row * n + i];
+    const float lq = q ? logf(q[row * n + i] + 1e-10f) : 0.f;
+    s += pv * (logf(pv + 1e-10f) - lq);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) rowloss[row] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void kldiv_bwd_kernel(const float* __restrict__ p, const float* __restrict__ q,
+                                                        const float* __restrict__ gout, float* __restrict__ dp,
+                                                        int64_t total, float scale) {
+  const float g = gout[0] * scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    const float lq = q ? logf(q[i] + 1e-10f) : 0.f;
+    dp[i] = g * (logf(pv + 1e-10f) + pv / (pv + 1e-10f) - lq);
+  }
+}
+
+// ------------------------------------------------------------------ sim_matrix row normalisation (utils.py:15-24)
+__global__ void rownorm_fwd_kernel(const float* __restrict__ a, float* __restrict__ an, float* __restrict__ nrm, int D,
+                                   float eps) {
+  const int64_t row = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 64) { const float v = a[row * D + i]; s += v * v; }
+  const float n = sqrtf(wave_sum(s));
+  const float d = fmaxf(n, eps);
+  for (int i = threadIdx.x; i < D; i += 64) an[row * D + i] = a[row * D + i] / d;
+  if (threadIdx.x == 0) nrm[row] = n;
+}
+__global__ void rownorm_bwd_kernel(const float* __restrict__ a, const float* __restrict__ nrm,
+                                   const float* __restrict__ dan, float* __restrict__ da, int D, float eps) {
+  const int64_t row = blockIdx.x;
+  const float n = nrm[row];
+  if (n > eps) {
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < D; i += 64) dot += a[row * D + i] * dan[row * D + i];
+    dot = wave_sum(dot);
+    for (int i = threadIdx.x; i < D; i += 64) da[row * D + i] = dan[row * D + i] / n - a[row * D + i] * dot / (n * n * n);
+  } else {
+    for (int i = threadIdx.x; i < D; i += 64) da[row * D + i] = dan[row * D + i] / eps;
+  }
+}
+
+// ------------------------------------------------------------------ EgoNCE (losses.py:157-170)
+// loss = -(1/n) sum_i [ log softmax_row(x/tau)_ii + log softmax_col(x/tau)_ii ]
+__global__ __launch_bounds__(256) void egonce_fwd_kernel(const float* __restrict__ x, float* __restrict__ loss,
+                                                         float* __restrict__ lse_row, float* __restrict__ lse_col, int n,
+                                                         float inv_tau) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float mr = -INFINITY, mc = -INFINITY;
+    for (int j = 0; j < n; ++j) { mr = fmaxf(mr, x[i * n + j] * inv_tau); mc = fmaxf(mc, x[j * n + i] * inv_tau); }
+    float sr = 0.f, sc = 0.f;
+    for (int j = 0; j < n; ++j) { sr += expf(x[i * n + j] * inv_tau - mr); sc += expf(x[j * n + i] * inv_tau - mc); }
+    const float lr = mr + logf(sr), lc = mc + logf(sc);
+    lse_row[i] = lr; lse_col[i] = lc;
+    const float d = x[i * n + i] * inv_tau;
+    acc += (d - lr) + (d - lc);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = -(red[0] + red[1] + red[2] + red[3]) / n;
+}
+__global__ void egonce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ lse_row,
+                                  const float* __restrict__ lse_col, const float* __restrict__ gout,
+                                  float* __restrict__ dx, int n, float inv_tau) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  const int i = idx / n, j = idx % n;
+  const float z = x[idx] * inv_tau;
+  const float dl = (i == j) ? 2.f : 0.f;
+  dx[idx] = -gout[0] / n * inv_tau * (dl - expf(z - lse_row[i]) - expf(z - lse_col[j]));
+}
+
+// ------------------------------------------------------------------ glue (custom_multimodal_builder.py:454-461,493-494)
+// y[b, t*HW+s, c] = x[b, t*HW+s, c] * w[b, t, c]
+__global__ __launch_bounds__(256) void reweight_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int64_t total, int HW, int C) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int64_t bt = idx / C / HW;
+    y[idx] = x[idx] * w[bt * C + c];
+  }
+}
+// dw[b,t,c] = sum_s dy * x
+__global__ __launch_bounds__(256) void reweight_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, int64_t nbtc, int HW, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbtc) return;
+  const int c = (int)(idx % C);
+  const int64_t bt = idx / C;
+  float s = 0.f;
+  for (int i = 0; i < HW; ++i) { const int64_t o = (bt * HW + i) * C + c; s += x[o] * dy[o]; }
+  dw[idx] = s;
+}
+// out[b,c] = mean_n x[b,n,c]   ;  bwd: dx[b,n,c] = dout[b,c] / N
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t nbc,
+                                                         int N, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nbc) return;
+  const int c = (int)(idx % C);
+  const int64_t b = idx / C;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += x[(b * N + n) * C + c];
+  out[idx] = s / N;
+}
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
+                                                             int64_t total, int N, int C) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    const int64_t b = idx / C / N;
+    dx[idx] = dout[b * C + c] / N;
+  }
+}
+// out = alpha*a + beta*b (b optional), dtype-generic; also the cast kernel
+__global__ __launch_bounds__(256) void axpby_kernel(const void* __restrict__ a, int a_dt, const void* __restrict__ b, int b_dt,
+                                                    void* __restrict__ out, int o_dt, int64_t total, float alpha, float beta) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = alpha * ld_as_f32(a, a_dt, i);
+    if (b) v += beta * ld_as_f32(b, b_dt, i);
+    st_from_f32(out, o_dt, i, v);
+  }
+}
+// out[m,n] = x[m,n] * row_scale[m / rows_per_scale]   (backward of the drop-path scaling, common.py:46-59)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ rs,
+                                                         int64_t rows_per_scale, void* __restrict__ out, int o_dt,
+                                                         int64_t total, int64_t N) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    st_from_f32(out, o_dt, i, ld_as_f32(x, x_dt, i) * rs[(i / N) / rows_per_scale]);
+}
+// out[m] = sum_c x[m,c] * w[c] + bias   (classifier Conv3d(96,1,1): custom_multimodal_builder.py:301,481); 32 lanes/row
+__global__ __launch_bounds__(256) void rowdot_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int64_t M, int C) {
+  const int sub = threadIdx.x & 31;
+  const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
+  for (int64_t m = row0; m < M; m += stride) {
+    float s = 0.f;
+    for (int c = sub; c < C; c += 32) s += ld_as_f32(x, x_dt, m * C + c) * w[c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) out[m] = s + (bias ? bias[0] : 0.f);
+  }
+}
+// dx[m,c] = dout[m] * w[c]
+__global__ __launch_bounds__(256) void rowdot_dx_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                        void* __restrict__ dx, int dx_dt, int64_t total, int C) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    st_from_f32(dx, dx_dt, idx, dout[idx / C] * w[idx % C]);
+}
+
+}  // namespace
+
+extern "C" int csts_im2col(const csts_im2col_geom* g, const void* x, int x_dt, void* col, int col_dt, hipStream_t stream) {
+  CSTS_REQUIRE(g && x && col, "null pointer");
+  Im2colP p;
+  p.B = g->B; p.Cin = g->Cin; p.T = g->T; p.H = g->H; p.W = g->W;
+  p.KT = g->kernel[0]; p.KH = g->kernel[1]; p.KW = g->kernel[2];
+  p.st = g->stride[0]; p.sh = g->stride[1]; p.sw = g->stride[2];
+  p.pt = g->padding[0]; p.ph = g->padding[1]; p.pw = g->padding[2];
+  CSTS_REQUIRE(p.B > 0 && p.Cin > 0 && p.st > 0 && p.sh > 0 && p.sw > 0, "bad geometry");
+  p.To = (p.T + 2 * p.pt - p.KT) / p.st + 1;
+  p.Ho = (p.H + 2 * p.ph - p.KH) / p.sh + 1;
+  p.Wo = (p.W + 2 * p.pw - p.KW) / p.sw + 1;
+  p.K = p.Cin * p.KT * p.KH * p.KW;
+  p.Kpad = g->Kpad;
+  CSTS_REQUIRE(p.Kpad >= p.K, "Kpad < K");
+  CSTS_REQUIRE(p.To == g->To && p.Ho == g->Ho && p.Wo == g->Wo, "output grid mismatch");
+  const int64_t total = (int64_t)p.B * p.To * p.Ho * p.Wo * p.Kpad;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p, x, x_dt, col, col_dt);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int csts_posembed_build(const float* spatial, const float* temporal, float* pos, int T, int HW, int C,
+                                   hipStream_t stream) {
+  CSTS_REQUIRE(spatial && temporal && pos && T > 0 && HW > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(posembed_kernel, dim3(grid_for((int64_t)T * HW * C)), dim3(256), 0, stream, spatial, temporal, pos, T, HW, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int csts_transpose_batched(const void* in, int in_dt, void* out, int out_dt, int64_t batch, int R, int Cc,
+                                      hipStream_t stream) {
+  CSTS_REQUIRE(in && out && batch > 0 && batch < 65536 && R > 0 && Cc > 0, "bad args");
+  dim3 grid((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32), (unsigned)batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, in_dt, out, out_dt, R, Cc);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+static void colsum_plan(int64_t M, int64_t& chunk, int64_t& nchunk) {
+  nchunk = std::max<int64_t>(1, std::min<int64_t>(256, M / 64));
+  chunk = cdiv(M, nchunk);
+  nchunk = cdiv(M, chunk);
+}
+extern "C" size_t csts_colsum_workspace(int64_t batch, int64_t M, int64_t N) {
+  int64_t chunk, nchunk;
+  colsum_plan(M, chunk, nchunk);
+  return (size_t)nchunk * batch * N * sizeof(float);
+}
+extern "C" int csts_colsum(const void* X, int dt, const float* row_weight, float* out, int64_t batch, int64_t M, int64_t N,
+                           void* workspace, size_t ws_bytes, hipStream_t stream) {
+  CSTS_REQUIRE(X && out && workspace && batch > 0 && batch < 65536 && M > 0 && N > 0, "bad args");
+  int64_t chunk, nchunk;
+  colsum_plan(M, chunk, nchunk);
+  CSTS_REQUIRE(ws_bytes >= (size_t)nchunk * batch * N * sizeof(float), "workspace too small");
+  float* ws = reinterpret_cast<float*>(workspace);
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)nchunk, (unsigned)batch);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, dt, row_weight, ws, M, N, chunk);
+  CSTS_LAUNCH_CHECK();
+  csts_reduce_rows_launch(ws, out, nchunk, batch * N, 1.f, stream);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int csts_softmax_fwd(const float* x, float* p, int64_t rows, int n, float temperature, hipStream_t stream) {
+  CSTS_REQUIRE(x && p && rows > 0 && n > 0 && temperature > 0.f, "bad args");
+  hipLaunchKernelGGL(softmax_kernel<false>, dim3((unsigned)rows), dim3(256), 0, stream, x, nullptr, p, n, 1.f / temperature);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_softmax_bwd(const float* x, const float* dp, float* dx, int64_t rows, int n, float temperature,
+                                hipStream_t stream) {
+  CSTS_REQUIRE(x && dp && dx && rows > 0 && n > 0 && temperature > 0.f, "bad args");
+  hipLaunchKernelGGL(softmax_kernel<true>, dim3((unsigned)rows), dim3(256), 0, stream, x, dp, dx, n, 1.f / temperature);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_kldiv_fwd(const float* p, const float* q, float* loss, float* rowloss_ws, int64_t rows, int n,
+                              float scale, hipStream_t stream) {
+  CSTS_REQUIRE(p && loss && rowloss_ws && rows > 0 && n > 0, "bad args");
+  hipLaunchKernelGGL(kldiv_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, p, q, rowloss_ws, n);
+  CSTS_LAUNCH_CHECK();
+  csts_reduce_rows_launch(rowloss_ws, loss, rows, 1, scale, stream);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_kldiv_bwd(const float* p, const float* q, const float* grad_out, float* dp, int64_t rows, int n,
+                              float scale, hipStream_t stream) {
+  CSTS_REQUIRE(p && grad_out && dp && rows > 0 && n > 0, "bad args");
+  hipLaunchKernelGGL(kldiv_bwd_kernel, dim3(grid_for(rows * n)), dim3(256), 0, stream, p, q, grad_out, dp, rows * n, scale);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_rownorm_fwd(const float* a, float* a_normed, float* norms, int64_t rows, int D, float eps,
+                                hipStream_t stream) {
+  CSTS_REQUIRE(a && a_normed && norms && rows > 0 && D > 0, "bad args");
+  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)rows), dim3(64), 0, stream, a, a_normed, norms, D, eps);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_rownorm_bwd(const float* a, const float* norms, const float* d_normed, float* da, int64_t rows, int D,
+                                float eps, hipStream_t stream) {
+  CSTS_REQUIRE(a && norms && d_normed && da && rows > 0 && D > 0, "bad args");
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)rows), dim3(64), 0, stream, a, norms, d_normed, da, D, eps);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_egonce_fwd(const float* sim, float* loss, float* lse_row, float* lse_col, int n, float temperature,
+                               hipStream_t stream) {
+  CSTS_REQUIRE(sim && loss && lse_row && lse_col && n > 0 && temperature > 0.f, "bad args");
+  hipLaunchKernelGGL(egonce_fwd_kernel, dim3(1), dim3(256), 0, stream, sim, loss, lse_row, lse_col, n, 1.f / temperature);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_egonce_bwd(const float* sim, const float* lse_row, const float* lse_col, const float* grad_out,
+                               float* dsim, int n, float temperature, hipStream_t stream) {
+  CSTS_REQUIRE(sim && lse_row && lse_col && grad_out && dsim && n > 0, "bad args");
+  hipLaunchKernelGGL(egonce_bwd_kernel, dim3((unsigned)cdiv((int64_t)n * n, 256)), dim3(256), 0, stream, sim, lse_row, lse_col,
+                     grad_out, dsim, n, 1.f / temperature);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_reweight_fwd(const float* x, const float* w, float* y, int64_t BT, int HW, int C, hipStream_t stream) {
+  CSTS_REQUIRE(x && w && y && BT > 0 && HW > 0 && C > 0, "bad args");
+  const int64_t total = BT * HW * C;
+  hipLaunchKernelGGL(reweight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, w, y, total, HW, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_reweight_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int64_t BT, int HW,
+                                 int C, hipStream_t stream) {
+  CSTS_REQUIRE(x && w && dy && BT > 0 && HW > 0 && C > 0, "bad args");
+  const int64_t total = BT * HW * C;
+  if (dx) hipLaunchKernelGGL(reweight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, w, dx, total, HW, C);
+  if (dw) hipLaunchKernelGGL(reweight_dw_kernel, dim3((unsigned)cdiv(BT * C, 256)), dim3(256), 0, stream, x, dy, dw, BT * C, HW, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_token_mean_fwd(const float* x, float* out, int64_t B, int N, int C, hipStream_t stream) {
+  CSTS_REQUIRE(x && out && B > 0 && N > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)cdiv(B * C, 256)), dim3(256), 0, stream, x, out, B * C, N, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_token_mean_bwd(const float* dout, float* dx, int64_t B, int N, int C, hipStream_t stream) {
+  CSTS_REQUIRE(dout && dx && B > 0 && N > 0 && C > 0, "bad args");
+  const int64_t total = B * N * C;
+  hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dout, dx, total, N, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, int64_t n, float alpha,
+                          float beta, hipStream_t stream) {
+  CSTS_REQUIRE(a && out && n > 0, "bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, a_dt, b, b_dt, out, out_dt, n, alpha, beta);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
+                               int64_t M, int64_t N, hipStream_t stream) {
+  CSTS_REQUIRE(x && row_scale && out && rows_per_scale > 0 && M > 0 && N > 0, "bad args");
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(M * N)), dim3(256), 0, stream, x, x_dt, row_scale, rows_per_scale, out,
+                     out_dt, M * N, N);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_rowdot_fwd(const void* x, int x_dt, const float* w, const float* bias, float* out, int64_t M, int C,
+                               hipStream_t stream) {
+  CSTS_REQUIRE(x && w && out && M > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(rowdot_kernel, dim3(grid_for(M * 32)), dim3(256), 0, stream, x, x_dt, w, bias, out, M, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_rowdot_dx(const float* dout, const float* w, void* dx, int dx_dt, int64_t M, int C, hipStream_t stream) {
+  CSTS_REQUIRE(dout && w && dx && M > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(rowdot_dx_kernel, dim3(grid_for(M * C)), dim3(256), 0, stream, dout, w, dx, dx_dt, M * C, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}

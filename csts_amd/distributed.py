@@ -1,0 +1,147 @@
+"""Collectives of the training step (slowfast/utils/distributed.py:15-90 and the implicit DDP all-reduce of
+slowfast/models/build.py:44-46), MI355X-first: one process per GPU, torch.distributed backend "nccl" (= RCCL
+over xGMI), gradient buckets reduced in gradient-READY order on RCCL's own stream while backward continues.
+
+The EgoNCE embedding gather has a correct backward here: the reference's AllGather_multi.backward slices with
+a hard-coded rank 0 (distributed.py:23,28-32) and silently mis-routes gradients on ranks != 0; here every rank
+takes the rows of the all-reduced gradient that belong to it."""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _AllGatherWithGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tensor):
+        world = dist.get_world_size()
+        out = [torch.empty_like(tensor) for _ in range(world)]
+        dist.all_gather(out, tensor.contiguous())
+        ctx.rank = dist.get_rank()
+        ctx.bs = tensor.shape[0]
+        return torch.cat(out, 0)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        # every rank computed the loss on the full gathered batch: d(sum of per-rank losses)/d(local rows) is the SUM
+        # over ranks of that rank's grad rows; DDP-style averaging of the loss is applied by the caller's grad mean.
+        g = grad_output.contiguous()
+        dist.all_reduce(g)
+        return g[ctx.bs * ctx.rank: ctx.bs * (ctx.rank + 1)]
+
+
+def all_gather_with_grad(tensors: List[torch.Tensor]) -> List[torch.Tensor]:
+    """distributed.py:35-49 (used for the EgoNCE embeddings, train_avgaze_net.py:82-83)."""
+    if not is_dist():
+        return list(tensors)
+    return [_AllGatherWithGrad.apply(t) for t in tensors]
+
+
+def all_gather(tensors):
+    """distributed.py:52-71."""
+    if not is_dist():
+        return list(tensors)
+    world = dist.get_world_size()
+    out = []
+    for t in tensors:
+        buf = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(buf, t.contiguous())
+        out.append(torch.cat(buf, dim=0))
+    return out
+
+
+def all_reduce(tensors, average=True):
+    """distributed.py:74-90.  All scalars go out as ONE fused collective."""
+    if not is_dist():
+        return tensors
+    flat = torch.stack([t.detach().reshape(()).float() for t in tensors])
+    dist.all_reduce(flat)
+    if average:
+        flat /= dist.get_world_size()
+    return [flat[i] for i in range(len(tensors))]
+
+
+class GradAllReduce(nn.Module):
+    """Data-parallel wrapper: bucketed mean all-reduce of gradients overlapped with backward.
+
+    Buckets are filled in the order gradients become READY (reverse registration order is used to assign
+    parameters to buckets once, after the first backward the observed order is kept), flattened into one
+    contiguous fp32 buffer per bucket and reduced asynchronously; ``finish()`` waits and scatters the means back.
+    The three 37.7 M-parameter fusion convs (60 % of all gradient bytes) become ready right after the decoder
+    backward, so their buckets travel over xGMI underneath the whole trunk backward."""
+
+    def __init__(self, module: nn.Module, bucket_mb: int = 64):
+        super().__init__()
+        self.module = module
+        self.world = dist.get_world_size() if is_dist() else 1
+        self.bucket_bytes = int(bucket_mb) * (1 << 20)
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        self._assign(list(reversed(self._params)))
+        self._ready_order: List[torch.nn.Parameter] = []
+        self._observed = False
+        self._pending = []
+        for p in self._params:
+            p.register_post_accumulate_grad_hook(self._hook)
+        if is_dist():   # replicas start identical
+            for p in module.parameters():
+                dist.broadcast(p.data, src=0)
+
+    def _assign(self, ordered):
+        self._buckets, self._bucket_of = [], {}
+        cur, cur_bytes = [], 0
+        for p in ordered:
+            nb = p.numel() * 4
+            if cur and cur_bytes + nb > self.bucket_bytes:
+                self._buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self._buckets.append(cur)
+        for bi, b in enumerate(self._buckets):
+            for p in b:
+                self._bucket_of[p] = bi
+        self._count = [0] * len(self._buckets)
+
+    def _hook(self, p):
+        if not self._observed:
+            self._ready_order.append(p)
+        bi = self._bucket_of[p]
+        self._count[bi] += 1
+        if self._count[bi] == len(self._buckets[bi]):
+            self._launch(bi)
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        ps = self._buckets[bi]
+        flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+        flat /= self.world
+        work = dist.all_reduce(flat, async_op=True)
+        self._pending.append((work, flat, ps))
+
+    def finish(self):
+        """Wait for the outstanding buckets and write the averaged gradients back (call after backward)."""
+        for work, flat, ps in self._pending:
+            work.wait()
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._pending = []
+        self._count = [0] * len(self._buckets)
+        if not self._observed and self._ready_order:
+            self._observed = True
+            if len(self._ready_order) == len(self._params):
+                self._assign(self._ready_order)     # keep the measured gradient-ready order from now on
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)

@@ -1,0 +1,145 @@
+"""ctypes binding of libcsts_hip.so (C ABI declared in include/csts_hip.h).
+
+The library is the product: if it is missing or fails to load, importing users get a loud
+RuntimeError -- there is no CPU / eager fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsts_hip.so")
+
+F32, BF16 = 0, 1
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+MASK_NONE, MASK_SPATIAL = 0, 1
+
+vp = C.c_void_p
+i64 = C.c_int64
+sz = C.c_size_t
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("layout", C.c_int),
+                ("A", vp), ("a_dt", C.c_int), ("lda", i64),
+                ("B", vp), ("b_dt", C.c_int), ("ldb", i64),
+                ("C", vp), ("c_dt", C.c_int), ("ldc", i64),
+                ("M", i64), ("N", i64), ("K", i64),
+                ("bias", vp), ("epilogue", C.c_int),
+                ("aux", vp), ("aux_dt", C.c_int), ("ldaux", i64),
+                ("residual", vp), ("r_dt", C.c_int), ("ldr", i64), ("res_row_mod", i64),
+                ("row_scale", vp), ("rows_per_scale", i64),
+                ("compute", C.c_int), ("split_k", C.c_int)]
+
+
+class DwconvGeom(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("HD", C.c_int),
+                ("Tf", C.c_int), ("Hf", C.c_int), ("Wf", C.c_int),
+                ("Tc", C.c_int), ("Hc", C.c_int), ("Wc", C.c_int),
+                ("st", C.c_int), ("sh", C.c_int), ("sw", C.c_int),
+                ("fine_batch_stride", i64), ("fine_token_stride", i64),
+                ("coarse_batch_stride", i64), ("coarse_token_stride", i64)]
+
+
+class PoolGeom(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int),
+                ("Ti", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
+                ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("st", C.c_int), ("sh", C.c_int), ("sw", C.c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("LSE", vp),
+                ("dO", vp), ("delta", vp), ("dQ", vp), ("dK", vp), ("dV", vp),
+                ("dtype", C.c_int), ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int),
+                ("head_dim", C.c_int),
+                ("q_strides", i64 * 3), ("k_strides", i64 * 3), ("v_strides", i64 * 3), ("o_strides", i64 * 3),
+                ("do_strides", i64 * 3), ("dq_strides", i64 * 3), ("dk_strides", i64 * 3), ("dv_strides", i64 * 3),
+                ("scale", C.c_float),
+                ("mask_mode", C.c_int), ("mask_T", C.c_int), ("mask_HW", C.c_int)]
+
+
+class Im2colGeom(C.Structure):
+    _fields_ = [("B", C.c_int), ("Cin", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("kernel", C.c_int * 3), ("stride", C.c_int * 3), ("padding", C.c_int * 3),
+                ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Kpad", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/csts_hip.h declares
+_I, _F = C.c_int, C.c_float
+SYMBOLS = {
+    "csts_last_error": (C.c_char_p, []),
+    "csts_abi_version": (_I, []),
+    "csts_gemm": (_I, [C.POINTER(GemmArgs), vp]),
+    "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
+    "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
+    "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),
+    "csts_reduce_rows": (_I, [vp, vp, i64, i64, _F, vp]),
+    "csts_dwconv_strided": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),
+    "csts_dwconv_transposed": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),
+    "csts_dwconv_wgrad_workspace": (sz, [C.POINTER(DwconvGeom)]),
+    "csts_dwconv_wgrad": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, _I, vp, vp, sz, vp]),
+    "csts_maxpool_fwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, vp, vp]),
+    "csts_maxpool_bwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, vp, vp]),
+    "csts_trilinear_fwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, _I, vp, _I, vp]),
+    "csts_trilinear_bwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, _I, vp]),
+    "csts_attn_fwd": (_I, [C.POINTER(AttnArgs), vp]),
+    "csts_attn_bwd_workspace": (sz, [C.POINTER(AttnArgs)]),
+    "csts_attn_bwd": (_I, [C.POINTER(AttnArgs), vp, sz, vp]),
+    "csts_attn_probs": (_I, [C.POINTER(AttnArgs), vp, vp]),
+    "csts_im2col": (_I, [C.POINTER(Im2colGeom), vp, _I, vp, _I, vp]),
+    "csts_posembed_build": (_I, [vp, vp, vp, _I, _I, _I, vp]),
+    "csts_transpose_batched": (_I, [vp, _I, vp, _I, i64, _I, _I, vp]),
+    "csts_colsum_workspace": (sz, [i64, i64, i64]),
+    "csts_colsum": (_I, [vp, _I, vp, vp, i64, i64, i64, vp, sz, vp]),
+    "csts_axpby": (_I, [vp, _I, vp, _I, vp, _I, i64, _F, _F, vp]),
+    "csts_scale_rows": (_I, [vp, _I, vp, i64, vp, _I, i64, i64, vp]),
+    "csts_reweight_fwd": (_I, [vp, vp, vp, i64, _I, _I, vp]),
+    "csts_reweight_bwd": (_I, [vp, vp, vp, vp, vp, i64, _I, _I, vp]),
+    "csts_token_mean_fwd": (_I, [vp, vp, i64, _I, _I, vp]),
+    "csts_token_mean_bwd": (_I, [vp, vp, i64, _I, _I, vp]),
+    "csts_rowdot_fwd": (_I, [vp, _I, vp, vp, vp, i64, _I, vp]),
+    "csts_rowdot_dx": (_I, [vp, vp, vp, _I, i64, _I, vp]),
+    "csts_softmax_fwd": (_I, [vp, vp, i64, _I, _F, vp]),
+    "csts_softmax_bwd": (_I, [vp, vp, vp, i64, _I, _F, vp]),
+    "csts_kldiv_fwd": (_I, [vp, vp, vp, vp, i64, _I, _F, vp]),
+    "csts_kldiv_bwd": (_I, [vp, vp, vp, vp, i64, _I, _F, vp]),
+    "csts_rownorm_fwd": (_I, [vp, vp, vp, i64, _I, _F, vp]),
+    "csts_rownorm_bwd": (_I, [vp, vp, vp, vp, i64, _I, _F, vp]),
+    "csts_egonce_fwd": (_I, [vp, vp, vp, vp, _I, _F, vp]),
+    "csts_egonce_bwd": (_I, [vp, vp, vp, vp, vp, _I, _F, vp]),
+}
+
+_lib = None
+
+
+class CstsError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libcsts_hip.so (once).  Raises loudly when it is absent: build it with
+    ``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C csts_amd/csrc``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CstsError(f"{LIB_PATH} not found: the HIP kernel library is required (no CPU fallback). "
+                        "Build it with `make -C csts_amd/csrc` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise CstsError(f"{LIB_PATH} does not export {name}: stale build?")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().csts_last_error()
+        raise CstsError(f"{what} failed: {msg.decode() if msg else rc}")

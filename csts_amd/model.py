@@ -1,0 +1,369 @@
+"""CSTS model: reference-identical nn.Module surface, MI355X-native forward/backward.
+
+Drop-in for ``slowfast.models.custom_multimodal_builder.CSTS`` (custom_multimodal_builder.py:19-498):
+same constructor argument (cfg), same ``forward(x, y, return_embed, return_spatial_attn,
+return_temporal_attn)`` contract, same ``state_dict`` names / shapes / order (524 entries), same
+parameter initialisation, registered under the same registry name.  torch.nn modules are used ONLY as
+parameter containers (names, shapes, default init); their forward() is never called -- all compute goes
+through csts_amd.ops -> libcsts_hip.so.  Compute mode comes from ``cfg.CSTS_AMD.COMPUTE``:
+"fp32" (exact-fp32 MFMA, parity mode) or "bf16" (bf16 MFMA, fp32 residual stream / statistics).
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch.nn.init import trunc_normal_
+
+from . import ops
+from . import lib as L
+from .registry import MODEL_REGISTRY
+
+
+def round_width(width, multiplier, min_width=1, divisor=1):
+    """Channel / head rounding rule (slowfast/models/utils.py:8-21)."""
+    if not multiplier:
+        return width
+    width *= multiplier
+    min_width = min_width or divisor
+    out = max(min_width, int(width + divisor / 2) // divisor * divisor)
+    if out < 0.9 * width:
+        out += divisor
+    return int(out)
+
+
+class Runtime:
+    """Per-model compute configuration."""
+
+    def __init__(self, compute: str):
+        compute = str(compute).lower()
+        if compute not in ("fp32", "bf16"):
+            raise ValueError(f"CSTS_AMD.COMPUTE must be 'fp32' or 'bf16', got {compute!r}")
+        self.name = compute
+        self.compute = L.F32 if compute == "fp32" else L.BF16
+        self.act_dt = self.compute            # dtype of GEMM inputs / q,k,v / MLP hidden
+        self.stream_dt = L.F32                # residual stream, LN statistics, softmax, losses
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden, dim_out):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim_out)
+
+
+class _Attention(nn.Module):
+    """Parameters of MultiScaleAttention (attention.py:88-116) / MultiScaleDecoderAttention (:330-361) /
+    Spatial- and TemporalAttention (av_attention.py:88-117, :286-314)."""
+
+    def __init__(self, dim, heads, kind, has_pool_q, has_pool_kv, stride_q, stride_kv):
+        super().__init__()
+        hd = dim // heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        if kind == "dec":
+            outpad = [0 if s == 1 else s - 1 for s in stride_q]
+            self.upsample_q = nn.ConvTranspose3d(hd, hd, 3, stride=tuple(stride_q), padding=1, output_padding=tuple(outpad),
+                                                 groups=hd, bias=False)
+            self.norm_q = nn.LayerNorm(hd)
+        elif has_pool_q:
+            self.pool_q = nn.Conv3d(hd, hd, 3, stride=tuple(stride_q), padding=1, groups=hd, bias=False)
+            self.norm_q = nn.LayerNorm(hd)
+        if has_pool_kv:
+            self.pool_k = nn.Conv3d(hd, hd, 3, stride=tuple(stride_kv), padding=1, groups=hd, bias=False)
+            self.norm_k = nn.LayerNorm(hd)
+            self.pool_v = nn.Conv3d(hd, hd, 3, stride=tuple(stride_kv), padding=1, groups=hd, bias=False)
+            self.norm_v = nn.LayerNorm(hd)
+
+
+class Block(nn.Module):
+    """One transformer block of the path.  kind: 'enc' (MultiScaleBlock, attention.py:165-248), 'dec'
+    (MultiScaleDecoderBlock, :395-479), 'spatial' / 'temporal' (av_attention.py:373-473 / :156-250)."""
+
+    def __init__(self, kind, dim, dim_out, heads, stride_q, stride_kv, has_pool_q, has_pool_kv, mlp_hidden, drop_path, rt):
+        super().__init__()
+        self.kind, self.dim, self.dim_out, self.heads = kind, dim, dim_out, heads
+        self.stride_q, self.stride_kv = tuple(stride_q), tuple(stride_kv)
+        self.has_pool_q, self.has_pool_kv = has_pool_q, has_pool_kv
+        self.drop_prob = float(drop_path)
+        self.rt = rt
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim, heads, kind, has_pool_q, has_pool_kv, stride_q, stride_kv)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, mlp_hidden, dim_out)
+        if dim != dim_out:
+            self.proj = nn.Linear(dim, dim_out)
+
+    def _drop_scales(self, B, device, keep_masks):
+        """Two independent per-sample scales (attention branch, MLP branch), drop_path of common.py:46-59."""
+        if self.drop_prob == 0.0 or not (self.training or keep_masks is not None):
+            return None, None
+        keep = 1.0 - self.drop_prob
+        if keep_masks is not None:
+            m1, m2 = keep_masks
+            m1, m2 = m1.to(device=device, dtype=torch.float32), m2.to(device=device, dtype=torch.float32)
+        else:
+            m1 = torch.floor(keep + torch.rand(B, dtype=torch.float32, device=device))
+            m2 = torch.floor(keep + torch.rand(B, dtype=torch.float32, device=device))
+        return (m1 / keep).contiguous(), (m2 / keep).contiguous()
+
+    def forward(self, x, thw, keep_masks=None, want_attn=False, spatial_audio_attn=False):
+        rt = self.rt
+        a = self.attn
+        B, N, Cc = x.shape
+        H = self.heads
+        thw = list(thw)
+        xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt)
+        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute)
+        mask_mode, mT, mHW = L.MASK_NONE, 0, 0
+        if self.kind == "spatial":
+            mask_mode, mT, mHW = L.MASK_SPATIAL, thw[0], thw[1] * thw[2]
+        akind = "dec" if self.kind == "dec" else ("enc" if self.kind == "enc" else "plain")
+        meta = (B, N, Cc, H, thw, akind, self.stride_q, self.stride_kv, self.has_pool_q or self.kind == "dec",
+                self.has_pool_kv, mask_mode, mT, mHW, rt.act_dt)
+        wq = getattr(a, "upsample_q", None) or getattr(a, "pool_q", None)
+        nq = getattr(a, "norm_q", None)
+        pk, nk = getattr(a, "pool_k", None), getattr(a, "norm_k", None)
+        pv, nv = getattr(a, "pool_v", None), getattr(a, "norm_v", None)
+        o, lse = ops.attention_inner(
+            qkv,
+            wq.weight if wq is not None else None, nq.weight if nq is not None else None, nq.bias if nq is not None else None,
+            pk.weight if pk is not None else None, nk.weight if nk is not None else None, nk.bias if nk is not None else None,
+            pv.weight if pv is not None else None, nv.weight if nv is not None else None, nv.bias if nv is not None else None,
+            meta)
+        if self.kind == "dec":
+            q_thw = [t * s for t, s in zip(thw, self.stride_q)]
+            x_res = ops.trilinear(x, thw, self.stride_q)
+        elif self.kind == "enc" and self.has_pool_q:
+            q_thw = [(t - 1) // s + 1 for t, s in zip(thw, self.stride_q)]
+            x_res = ops.maxpool_skip(x, thw, self.stride_q)
+        else:
+            q_thw = thw
+            x_res = x
+        Nq = o.shape[1]
+        s_attn, s_mlp = self._drop_scales(B, x.device, keep_masks)
+        x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x_res, row_scale=s_attn, rows_per_scale=Nq, out_dt=L.F32,
+                        compute=rt.compute)
+        xn2 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt)
+        base = x1
+        if self.dim != self.dim_out:
+            base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute)
+        out = ops.mlp(xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=base,
+                      row_scale=s_mlp, rows_per_scale=Nq, act_dt=rt.act_dt, out_dt=L.F32, compute=rt.compute)
+        extra = None
+        if want_attn or spatial_audio_attn:
+            with torch.no_grad():
+                probs = ops.attention_probs(qkv.detach(), B, N, Cc, H, lse, mask_mode, mT, mHW)
+            if spatial_audio_attn:   # av_attention.py:360-370 (min-max rescaled audio->pixel attention)
+                T, HW = thw[0], thw[1] * thw[2]
+                aa = torch.stack([probs[:, :, T * HW + t, HW * t:HW * (t + 1)] for t in range(T)], dim=2)
+                amax, amin = aa.max(dim=-1, keepdim=True)[0], aa.min(dim=-1, keepdim=True)[0]
+                extra = ((aa - amin) / (amax - amin + 1e-8)).reshape(B, H, T, thw[1], thw[2])
+            else:
+                extra = probs
+        return out, q_thw, extra
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim_in, dim_out, kernel, stride, padding):
+        super().__init__()
+        self.proj = nn.Conv3d(dim_in, dim_out, kernel_size=tuple(kernel), stride=tuple(stride), padding=tuple(padding))
+        self.kernel, self.stride, self.padding = tuple(kernel), tuple(stride), tuple(padding)
+
+
+@MODEL_REGISTRY.register()
+class CSTS(nn.Module):
+    """Audio-visual MViT with spatial/temporal fusion and transformer decoder (gaze anticipation)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        assert cfg.DATA.TRAIN_CROP_SIZE == cfg.DATA.TEST_CROP_SIZE        # custom_multimodal_builder.py:28
+        self.cfg = cfg
+        if cfg.MVIT.NORM != "layernorm":
+            raise NotImplementedError("Only supports layernorm.")          # :63
+        if cfg.MVIT.CLS_EMBED_ON or not cfg.MVIT.SEP_POS_EMBED or cfg.MVIT.PATCH_2D or cfg.MVIT.POOL_FIRST \
+                or cfg.MVIT.MODE != "conv" or cfg.MVIT.DROPOUT_RATE > 0 or cfg.MVIT.NORM_STEM:
+            raise NotImplementedError("csts_amd implements the configuration of the shipped CSTS YAMLs: no class "
+                                      "token, separable pos-embed, 3-D patches, conv pooling, no dropout, no stem norm")
+        amd = getattr(cfg, "CSTS_AMD", None)
+        self.rt = Runtime(amd.COMPUTE if amd is not None else "bf16")
+        rt = self.rt
+        S, T = cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.NUM_FRAMES
+        self.patch_stride = list(cfg.MVIT.PATCH_STRIDE)
+        embed_dim, num_heads, depth = cfg.MVIT.EMBED_DIM, cfg.MVIT.NUM_HEADS, cfg.MVIT.DEPTH
+        mlp_ratio = cfg.MVIT.MLP_RATIO
+        dpr_rate = cfg.MVIT.DROPPATH_RATE
+        self.spatial_audio_attn = cfg.MVIT.SPATIAL_AUDIO_ATTN
+        self.patch_embed = _PatchEmbed(cfg.DATA.INPUT_CHANNEL_NUM[0], embed_dim, cfg.MVIT.PATCH_KERNEL, cfg.MVIT.PATCH_STRIDE,
+                                       cfg.MVIT.PATCH_PADDING)
+        self.patch_embed_audio = _PatchEmbed(1, embed_dim, cfg.MVIT.PATCH_KERNEL, cfg.MVIT.PATCH_STRIDE,
+                                             cfg.MVIT.PATCH_PADDING)
+        self.input_dims = [T, S, S]
+        assert self.input_dims[1] == self.input_dims[2]                   # :84
+        self.patch_dims = [self.input_dims[i] // self.patch_stride[i] for i in range(3)]
+        pd = self.patch_dims
+        self.pos_embed_spatial = nn.Parameter(torch.zeros(1, pd[1] * pd[2], embed_dim))
+        self.pos_embed_temporal = nn.Parameter(torch.zeros(1, pd[0], embed_dim))
+        self.pos_embed_spatial_audio = nn.Parameter(torch.zeros(1, pd[1] * pd[2], embed_dim))
+        self.pos_embed_temporal_audio = nn.Parameter(torch.zeros(1, pd[0], embed_dim))
+
+        # ---- video encoder geometry (:115-180)
+        dim_mul, head_mul = [1.0] * (depth + 1), [1.0] * (depth + 1)
+        for i, m in cfg.MVIT.DIM_MUL:
+            dim_mul[int(i)] = m
+        for i, m in cfg.MVIT.HEAD_MUL:
+            head_mul[int(i)] = m
+        stride_q = [[] for _ in range(depth)]
+        for row in cfg.MVIT.POOL_Q_STRIDE:
+            stride_q[int(row[0])] = list(row[1:])
+        if cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE is not None:                   # :136-142 (also mutates cfg, like the reference)
+            skv = list(cfg.MVIT.POOL_KV_STRIDE_ADAPTIVE)
+            cfg.MVIT.POOL_KV_STRIDE = []
+            for i in range(depth):
+                if len(stride_q[i]) > 0:
+                    skv = [max(skv[d] // stride_q[i][d], 1) for d in range(3)]
+                cfg.MVIT.POOL_KV_STRIDE.append([i] + skv)
+        stride_kv = [[] for _ in range(depth)]
+        for row in cfg.MVIT.POOL_KV_STRIDE:
+            stride_kv[int(row[0])] = list(row[1:])
+        if cfg.MVIT.POOL_KVQ_KERNEL is None or list(cfg.MVIT.POOL_KVQ_KERNEL) != [3, 3, 3]:
+            raise NotImplementedError("csts_amd pools with the 3x3x3 kernels of the shipped YAMLs (POOL_KVQ_KERNEL)")
+        dpr = torch.linspace(0, dpr_rate, depth).tolist()
+        self.blocks = nn.ModuleList()
+        heads, dim = num_heads, embed_dim
+        for i in range(depth):
+            heads = round_width(heads, head_mul[i])
+            dim = round_width(dim, dim_mul[i], divisor=heads)
+            dim_out = round_width(dim, dim_mul[i + 1], divisor=round_width(heads, head_mul[i + 1]))
+            has_q = len(stride_q[i]) > 0
+            has_kv = len(stride_kv[i]) > 0
+            self.blocks.append(Block("enc", dim, dim_out, heads, stride_q[i] if has_q else (1, 1, 1),
+                                     stride_kv[i] if has_kv else (1, 1, 1), has_q, has_kv, int(dim * mlp_ratio), dpr[i], rt))
+        # ---- audio encoder (:184-216)
+        a_dim, a_out, a_heads = [96, 192, 384, 768], [192, 384, 768, 768], [1, 2, 4, 8]
+        a_sq = [None, (1, 2, 2), (1, 2, 2), (1, 2, 2)]
+        a_skv = [(1, 8, 8), (1, 4, 4), (1, 2, 2), (1, 1, 1)]
+        self.blocks_audio = nn.ModuleList([
+            Block("enc", a_dim[i], a_out[i], a_heads[i], a_sq[i] or (1, 1, 1), a_skv[i], a_sq[i] is not None, True,
+                  int(a_dim[i] * mlp_ratio), 0.0, rt) for i in range(4)])
+        token_dim = self.blocks[-1].dim_out
+        if "nce" in cfg.MODEL.LOSS_FUNC:                                   # :221-224
+            self.vision_proj = nn.Linear(token_dim, 256)
+            self.audio_proj = nn.Linear(token_dim, 256)
+        fk = (1, pd[1] // 8, pd[2] // 8) if getattr(amd, "FUSION_KERNEL_FROM_GRID", False) else (1, 8, 8)
+        self.vision_pool = nn.Conv3d(token_dim, token_dim, kernel_size=fk, stride=1)     # :227-229
+        self.audio_pool = nn.Conv3d(token_dim, token_dim, kernel_size=fk, stride=1)
+        self.audio_pool2 = nn.Conv3d(token_dim, token_dim, kernel_size=fk, stride=1)
+        self.temporal_fusion = Block("temporal", token_dim, token_dim, heads, (1, 1, 1), (1, 1, 1), False, False,
+                                     int(token_dim * mlp_ratio), 0.0, rt)
+        self.spatial_fusion = Block("spatial", token_dim, token_dim, heads, (1, 1, 1), (1, 1, 1), False, False,
+                                    int(token_dim * mlp_ratio), 0.0, rt)
+        # ---- decoder (:271-299); MLP hidden = 4 * dim_out (attention.py:444)
+        d_in, d_out, d_heads = [768, 768, 384, 192], [768, 384, 192, 96], [8, 4, 4, 2]
+        d_sq = [(1, 2, 2), (1, 2, 2), (1, 2, 2), (2, 1, 1)]
+        d_skv = [(1, 2, 2), (1, 4, 4), (1, 8, 8), (1, 16, 16)]
+        for i in range(4):
+            setattr(self, f"decode_block{i + 1}",
+                    Block("dec", d_in[i], d_out[i], d_heads[i], d_sq[i], d_skv[i], True, True, int(d_out[i] * mlp_ratio), 0.0, rt))
+        self.classifier = nn.Conv3d(96, 1, kernel_size=1)
+        # ---- init (:304-325): trunc_normal(.02) pos-embeds and Linear weights, LN 1/0; convs keep torch default
+        for p_ in (self.pos_embed_spatial, self.pos_embed_temporal, self.pos_embed_spatial_audio, self.pos_embed_temporal_audio):
+            trunc_normal_(p_, std=0.02)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        """custom_multimodal_builder.py:327-341."""
+        if self.cfg.MVIT.ZERO_DECAY_POS_CLS:
+            return {"pos_embed_spatial", "pos_embed_temporal", "pos_embed_class"}
+        return {}
+
+    # ------------------------------------------------------------------ forward (custom_multimodal_builder.py:343-498)
+    def forward(self, x, y, return_embed=False, return_spatial_attn=False, return_temporal_attn=False, keep_masks=None):
+        rt = self.rt
+        inpt = x[0]
+        if not inpt.is_cuda:
+            raise L.CstsError("CSTS (csts_amd) runs on MI355X only: inputs must be GPU tensors; there is no CPU fallback")
+        km = keep_masks or {}
+        pe, pa = self.patch_embed, self.patch_embed_audio
+        xt = ops.patch_embed(inpt.float(), pe.proj.weight, pe.proj.bias, self.pos_embed_spatial, self.pos_embed_temporal,
+                             pe.kernel, pe.stride, pe.padding, rt.act_dt, rt.compute)
+        yt = ops.patch_embed(y.float(), pa.proj.weight, pa.proj.bias, self.pos_embed_spatial_audio,
+                             self.pos_embed_temporal_audio, pa.kernel, pa.stride, pa.padding, rt.act_dt, rt.compute)
+        T, H, W = self.patch_dims
+        thw, thw_a = [T, H, W], [T, H, W]
+        inter = [(xt, thw)]
+
+        def run(t, shape, blocks, names):
+            for blk, nm in zip(blocks, names):
+                t, shape, _ = blk(t, shape, km.get(nm))
+            return t, shape
+
+        vb, ab = self.blocks, self.blocks_audio
+        vn = [f"blocks.{i}" for i in range(len(vb))]
+        an = [f"blocks_audio.{i}" for i in range(len(ab))]
+        # video / audio stages interleaved as in the reference (:387-411); the two trunks are independent until fusion
+        xt, thw = run(xt, thw, vb[:1], vn[:1]); inter.append((xt, thw)); yt, thw_a = run(yt, thw_a, ab[:1], an[:1])
+        xt, thw = run(xt, thw, vb[1:3], vn[1:3]); inter.append((xt, thw)); yt, thw_a = run(yt, thw_a, ab[1:2], an[1:2])
+        xt, thw = run(xt, thw, vb[3:14], vn[3:14]); inter.append((xt, thw)); yt, thw_a = run(yt, thw_a, ab[2:3], an[2:3])
+        xt, thw = run(xt, thw, vb[14:], vn[14:]); yt, thw_a = run(yt, thw_a, ab[3:], an[3:])
+
+        # ---- spatial fusion (:415-432)
+        B, Nv, Cc = xt.shape
+        Tn, HW = thw[0], thw[1] * thw[2]
+        HWa = thw_a[1] * thw_a[2]
+        y_sp = ops.fusion_conv(yt, self.audio_pool.weight, self.audio_pool.bias, thw_a[0], HWa, rt.act_dt, rt.compute)
+        av_sp = torch.cat([xt, y_sp], dim=1)
+        av_sp, _, sp_extra = self.spatial_fusion(av_sp, thw, want_attn=return_spatial_attn,
+                                                 spatial_audio_attn=self.spatial_audio_attn)
+        x_spatial = av_sp[:, :Nv, :]
+        # ---- temporal fusion (:435-451)
+        x_t = xt
+        if self.spatial_audio_attn:
+            wmap = sp_extra.mean(dim=1).reshape(B, Nv, 1)       # (B, T, H, W) -> per-token weight
+            x_t = xt * wmap
+        x_tmp = ops.fusion_conv(x_t, self.vision_pool.weight, self.vision_pool.bias, Tn, HW, rt.act_dt, rt.compute)
+        y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute)
+        av_t = torch.cat([x_tmp, y_tmp], dim=1)
+        av_t, _, t_extra = self.temporal_fusion(av_t, (2, 2, 2), want_attn=return_temporal_attn)
+        # ---- re-weight (:454-461)
+        x_w, y_w = av_t[:, :Tn, :], av_t[:, Tn:, :]
+        x_rw = ops.reweight(x_spatial, x_w, Tn, HW)
+        y_rw = ops.reweight(yt, y_w, thw_a[0], HWa)
+        # ---- decoder (:466-475)
+        feat, dthw = x_rw, list(thw)
+        for i in range(4):
+            blk = getattr(self, f"decode_block{i + 1}")
+            feat, dthw, _ = blk(feat, dthw, km.get(f"decode_block{i + 1}"))
+            if i < 3:
+                feat = ops.add(feat, inter[-1 - i][0])
+        # ---- head (:476-481)
+        en, en_thw = inter[0]
+        logits = ops.classifier_head(feat, en, self.classifier.weight, self.classifier.bias, en_thw)
+
+        if not return_embed and not return_spatial_attn and not return_temporal_attn:
+            return logits
+        if not return_embed:
+            out = [logits]
+            if return_spatial_attn:
+                out.append(sp_extra)
+            if return_temporal_attn:
+                out.append(t_extra)
+            return out
+        v_emb = ops.linear(ops.token_mean(x_rw), self.vision_proj.weight, self.vision_proj.bias, out_dt=L.F32, compute=L.F32)
+        a_emb = ops.linear(ops.token_mean(y_rw), self.audio_proj.weight, self.audio_proj.bias, out_dt=L.F32, compute=L.F32)
+        return [logits, v_emb, a_emb]

@@ -1,0 +1,866 @@
+"""torch.autograd Functions over the libcsts_hip.so C ABI.
+
+PyTorch is plumbing here (device memory from the caching allocator, the current HIP stream, the
+autograd tape); every FLOP of the CSTS path runs in the hand-written gfx950 kernels.  There is no
+eager fallback: tensors must be on a GPU and the library must load, otherwise these raise.
+Each Function cites the reference op it replaces (paths under the reference repo).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+
+F32, BF16 = L.F32, L.BF16
+
+
+def _lib():
+    return L.load()
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise L.CstsError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt: int):
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], off_elems: int = 0):
+    if t is None:
+        return None
+    return t.data_ptr() + off_elems * t.element_size()
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.CstsError("csts_amd ops need GPU tensors (no CPU fallback); got a CPU tensor")
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------- raw wrappers
+def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
+         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1):
+    a = L.GemmArgs()
+    a.layout = layout
+    a.A, a.a_dt, a.lda = _p(A, a_off), _dt(A), lda
+    a.B, a.b_dt, a.ldb = _p(B, b_off), _dt(B), ldb
+    a.C, a.c_dt, a.ldc = _p(Cm), _dt(Cm), ldc
+    a.M, a.N, a.K = M, N, K
+    a.bias = _p(bias)
+    a.epilogue = epilogue
+    a.aux, a.aux_dt, a.ldaux = _p(aux), (_dt(aux) if aux is not None else 0), (N if aux is not None else 0)
+    a.residual, a.r_dt, a.ldr = _p(residual), (_dt(residual) if residual is not None else 0), ldr
+    a.res_row_mod = res_row_mod
+    a.row_scale, a.rows_per_scale = _p(row_scale), rows_per_scale
+    a.compute, a.split_k = compute, split_k
+    L.check(_lib().csts_gemm(C.byref(a), _stream()), "csts_gemm")
+
+
+def colsum(X: torch.Tensor, batch: int, M: int, N: int, row_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty(batch * N, dtype=torch.float32, device=X.device)
+    nbytes = _lib().csts_colsum_workspace(batch, M, N)
+    ws = _ws(nbytes, X.device)
+    L.check(_lib().csts_colsum(_p(X), _dt(X), _p(row_weight), _p(out), batch, M, N, _p(ws), ws.numel(), _stream()),
+            "csts_colsum")
+    return out
+
+
+def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, rows_per_scale: int, M: int, N: int) -> torch.Tensor:
+    out = torch.empty_like(x)
+    L.check(_lib().csts_scale_rows(_p(x), _dt(x), _p(row_scale), rows_per_scale, _p(out), _dt(out), M, N, _stream()),
+            "csts_scale_rows")
+    return out
+
+
+def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
+    tiles = math.ceil(M_out / 128) * math.ceil(N_out / 128)
+    return max(1, min(1024 // max(tiles, 1), math.ceil(Kred / 256)))
+
+
+def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int) -> torch.Tensor:
+    """dW[N,K] = dY[M,N]^T X[M,K] (fp32, split over M with fp32 atomics)."""
+    split = _wgrad_split(N, K, M)
+    dW = (torch.zeros if split > 1 else torch.empty)(N, K, dtype=torch.float32, device=dY.device)
+    gemm(L.GEMM_TN, dY, 0, N, X, 0, K, dW, K, N, K, M, compute=compute, split_k=split)
+    return dW
+
+
+# ----------------------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(Function):
+    """nn.LayerNorm over the last dim (attention.py:192,214 eps 1e-6; :108,112,116 eps 1e-5)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float, out_dt: int):
+        _need_gpu(x, gamma, beta)
+        x = x.contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        y = torch.empty(x.shape, dtype=torch_dtype(out_dt), device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L.check(_lib().csts_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), out_dt, _p(mean), _p(rstd), rows, Cc,
+                                          eps, _stream()), "csts_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+        ws = _ws(_lib().csts_layernorm_bwd_workspace(rows, Cc), x.device)
+        L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
+                                          _p(dgb), _p(dgb, Cc), _p(ws), ws.numel(), rows, Cc, _stream()),
+                "csts_layernorm_bwd")
+        return dx, dgb[:Cc], dgb[Cc:], None, None
+
+
+def layer_norm(x, gamma, beta, eps, out_dt):
+    return LayerNormFn.apply(x, gamma, beta, eps, out_dt)
+
+
+# ----------------------------------------------------------------------------------------- Linear
+class LinearFn(Function):
+    """y = (x W^T + b) * row_scale + residual  (nn.Linear: attention.py:130,159,232,246; drop_path + residual
+    of attention.py:242,247 folded into the epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int):
+        _need_gpu(x, W)
+        x = x.contiguous()
+        W = W.contiguous()
+        K = x.shape[-1]
+        N = W.shape[0]
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], N, dtype=torch_dtype(out_dt), device=x.device)
+        if residual is not None:
+            residual = residual.contiguous()
+        gemm(L.GEMM_NT, x, 0, K, W, 0, K, y, N, M, N, K, compute=compute, bias=b, residual=residual, ldr=N,
+             row_scale=row_scale, rows_per_scale=rows_per_scale)
+        ctx.save_for_backward(x, W, row_scale)
+        ctx.meta = (M, N, K, rows_per_scale, compute, b is not None, residual is not None,
+                    residual.dtype if residual is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, row_scale = ctx.saved_tensors
+        M, N, K, rps, compute, has_b, has_res, res_dtype = ctx.meta
+        dy = dy.contiguous()
+        dys = scale_rows(dy, row_scale, rps, M, N) if row_scale is not None else dy
+        dx = dW = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dys, 0, N, W, 0, K, dx, K, M, K, N, compute=compute)
+        if ctx.needs_input_grad[1]:
+            dW = _wgrad(dys, x, M, N, K, compute).to(W.dtype)
+        if has_b and ctx.needs_input_grad[2]:
+            db = colsum(dys, 1, M, N)
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy if dy.dtype == res_dtype else dy.to(res_dtype)
+        return dx, dW, db, dres, None, None, None, None
+
+
+def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32):
+    return LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute)
+
+
+class MlpFn(Function):
+    """fc2(GELU_erf(fc1(x))) * row_scale + residual  (Mlp.forward common.py:26-34; attention.py:244-247).
+    GELU lives in fc1's epilogue, GELU' in the epilogue of fc2's data-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, residual, row_scale, rows_per_scale: int, act_dt: int, out_dt: int, compute: int):
+        _need_gpu(x, W1, W2)
+        x = x.contiguous()
+        K = x.shape[-1]
+        Hd = W1.shape[0]
+        N = W2.shape[0]
+        M = x.numel() // K
+        h = torch.empty(M, Hd, dtype=torch_dtype(act_dt), device=x.device)   # pre-activation
+        g = torch.empty_like(h)
+        gemm(L.GEMM_NT, x, 0, K, W1, 0, K, g, Hd, M, Hd, K, compute=compute, bias=b1, epilogue=L.EPI_GELU, aux=h)
+        y = torch.empty(*x.shape[:-1], N, dtype=torch_dtype(out_dt), device=x.device)
+        if residual is not None:
+            residual = residual.contiguous()
+        gemm(L.GEMM_NT, g, 0, Hd, W2, 0, Hd, y, N, M, N, Hd, compute=compute, bias=b2, residual=residual, ldr=N,
+             row_scale=row_scale, rows_per_scale=rows_per_scale)
+        ctx.save_for_backward(x, W1, W2, h, g, row_scale)
+        ctx.meta = (M, K, Hd, N, rows_per_scale, compute, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1, W2, h, g, row_scale = ctx.saved_tensors
+        M, K, Hd, N, rps, compute, has_res = ctx.meta
+        dy = dy.contiguous()
+        dys = scale_rows(dy, row_scale, rps, M, N) if row_scale is not None else dy
+        dW2 = _wgrad(dys, g, M, N, Hd, compute)
+        db2 = colsum(dys, 1, M, N)
+        dh = torch.empty_like(h)
+        gemm(L.GEMM_NN, dys, 0, N, W2, 0, Hd, dh, Hd, M, Hd, N, compute=compute, epilogue=L.EPI_DGELU, aux=h)
+        dW1 = _wgrad(dh, x, M, Hd, K, compute)
+        db1 = colsum(dh, 1, M, Hd)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(L.GEMM_NN, dh, 0, Hd, W1, 0, K, dx, K, M, K, Hd, compute=compute)
+        return dx, dW1, db1, dW2, db2, (dy if has_res else None), None, None, None, None, None
+
+
+def mlp(x, W1, b1, W2, b2, *, residual=None, row_scale=None, rows_per_scale=1, act_dt=F32, out_dt=F32, compute=F32):
+    return MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute)
+
+
+# ----------------------------------------------------------------------------------------- attention inner
+def _conv_geom(B, Cc, HD, fine_thw, stride, f_bs, f_ts, c_bs, c_ts) -> L.DwconvGeom:
+    g = L.DwconvGeom()
+    g.B, g.C, g.HD = B, Cc, HD
+    g.Tf, g.Hf, g.Wf = fine_thw
+    g.st, g.sh, g.sw = stride
+    g.Tc, g.Hc, g.Wc = [(f - 1) // s + 1 for f, s in zip(fine_thw, stride)]
+    g.fine_batch_stride, g.fine_token_stride = f_bs, f_ts
+    g.coarse_batch_stride, g.coarse_token_stride = c_bs, c_ts
+    return g
+
+
+def _ln_rows_fwd(c, gamma, beta, HD, act_dt):
+    rows = c.numel() // HD
+    y = torch.empty(c.shape, dtype=torch_dtype(act_dt), device=c.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=c.device)
+    rstd = torch.empty_like(mean)
+    L.check(_lib().csts_layernorm_fwd(_p(c), _dt(c), _p(gamma), _p(beta), _p(y), act_dt, _p(mean), _p(rstd), rows, HD, 1e-5,
+                                      _stream()), "csts_layernorm_fwd(head)")
+    return y, mean, rstd
+
+
+def _ln_rows_bwd(dy, c, gamma, mean, rstd, HD):
+    rows = c.numel() // HD
+    dc = torch.empty_like(c)
+    dgb = torch.empty(2 * HD, dtype=torch.float32, device=c.device)
+    ws = _ws(_lib().csts_layernorm_bwd_workspace(rows, HD), c.device)
+    L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(c), _dt(c), _p(gamma), _p(mean), _p(rstd), _p(dc), _dt(dc), _p(dgb),
+                                      _p(dgb, HD), _p(ws), ws.numel(), rows, HD, _stream()), "csts_layernorm_bwd(head)")
+    return dc, dgb[:HD], dgb[HD:]
+
+
+class AttnInnerFn(Function):
+    """Everything between the qkv Linear and the output projection of MultiScaleAttention /
+    MultiScaleDecoderAttention / SpatialAttention / TemporalAttention (attention.py:130-158, :374-388;
+    av_attention.py:127-141, :324-350): conv-pool (or ConvTranspose upsample of q) + LayerNorm(hd) of
+    q/k/v read straight from the token-major qkv buffer, then the fused attention core.
+    kind: 'enc' | 'dec' | 'plain'.  Returns o (B, Nq, C)."""
+
+    @staticmethod
+    def forward(ctx, qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta):
+        _need_gpu(qkv)
+        (B, N, Cc, H, thw, kind, stride_q, stride_kv, has_pool_q, has_pool_kv, mask_mode, mask_T, mask_HW, act_dt) = meta
+        qkv = qkv.contiguous()
+        HD = Cc // H
+        dev = qkv.device
+        lib = _lib()
+        s = _stream()
+        saved = {}
+
+        def slot_view(slot):   # (tensor, elem offset, strides) of q/k/v inside the qkv buffer
+            return (qkv, slot * Cc, (N * 3 * Cc, 3 * Cc, HD), N)
+
+        def pooled(slot, w, gamma, beta, stride, transposed):
+            if transposed:   # decoder q: ConvTranspose3d, fine = output grid
+                fine_thw = [t * st for t, st in zip(thw, stride)]
+                Nf = fine_thw[0] * fine_thw[1] * fine_thw[2]
+                g = _conv_geom(B, Cc, HD, fine_thw, stride, Nf * Cc, Cc, N * 3 * Cc, 3 * Cc)
+                c = torch.empty(B, Nf, Cc, dtype=qkv.dtype, device=dev)
+                L.check(lib.csts_dwconv_transposed(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(w), _p(c), _dt(c), s),
+                        "csts_dwconv_transposed")
+                n_out = Nf
+                out_thw = fine_thw
+            else:
+                g = _conv_geom(B, Cc, HD, list(thw), stride, N * 3 * Cc, 3 * Cc, 0, Cc)
+                n_out = g.Tc * g.Hc * g.Wc
+                g.coarse_batch_stride = n_out * Cc
+                c = torch.empty(B, n_out, Cc, dtype=qkv.dtype, device=dev)
+                L.check(lib.csts_dwconv_strided(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(w), _p(c), _dt(c), s),
+                        "csts_dwconv_strided")
+                out_thw = [g.Tc, g.Hc, g.Wc]
+            y, mean, rstd = _ln_rows_fwd(c, gamma, beta, HD, act_dt)
+            saved[slot] = (c, mean, rstd, g)
+            return (y, 0, (n_out * Cc, Cc, HD), n_out), out_thw
+
+        if kind == "dec":
+            qd, _ = pooled(0, wq, gq, bq, stride_q, True)
+        elif has_pool_q:
+            qd, _ = pooled(0, wq, gq, bq, stride_q, False)
+        else:
+            qd = slot_view(0)
+        if has_pool_kv:
+            kd, _ = pooled(1, wk, gk, bk, stride_kv, False)
+            vd, _ = pooled(2, wv, gv, bv, stride_kv, False)
+        else:
+            kd, vd = slot_view(1), slot_view(2)
+        Nq, Nk = qd[3], kd[3]
+        o = torch.empty(B, Nq, Cc, dtype=qkv.dtype, device=dev)
+        lse = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+        a = L.AttnArgs()
+        a.Q, a.K, a.V = _p(qd[0], qd[1]), _p(kd[0], kd[1]), _p(vd[0], vd[1])
+        a.O, a.LSE = _p(o), _p(lse)
+        a.dtype, a.B, a.H, a.Nq, a.Nk, a.head_dim = _dt(qkv), B, H, Nq, Nk, HD
+        a.q_strides = (C.c_int64 * 3)(*qd[2])
+        a.k_strides = (C.c_int64 * 3)(*kd[2])
+        a.v_strides = (C.c_int64 * 3)(*vd[2])
+        a.o_strides = (C.c_int64 * 3)(Nq * Cc, Cc, HD)
+        a.scale = HD ** -0.5
+        a.mask_mode, a.mask_T, a.mask_HW = mask_mode, mask_T, mask_HW
+        L.check(lib.csts_attn_fwd(C.byref(a), s), "csts_attn_fwd")
+        ctx.meta = meta
+        ctx.saved_slots = saved
+        ctx.descr = (qd, kd, vd, Nq, Nk)
+        ctx.save_for_backward(qkv, o, lse, wq, gq, wk, gk, wv, gv)
+        ctx.mark_non_differentiable(lse)
+        return o, lse
+
+    @staticmethod
+    def backward(ctx, do, _dlse):
+        (B, N, Cc, H, thw, kind, stride_q, stride_kv, has_pool_q, has_pool_kv, mask_mode, mask_T, mask_HW, act_dt) = ctx.meta
+        qkv, o, lse, wq, gq, wk, gk, wv, gv = ctx.saved_tensors
+        qd, kd, vd, Nq, Nk = ctx.descr
+        saved = ctx.saved_slots
+        HD = Cc // H
+        dev = qkv.device
+        lib = _lib()
+        s = _stream()
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+
+        def grad_target(slot, n_rows):   # where attention bwd writes d(q|k|v)
+            if slot in saved:
+                t = torch.empty(B, n_rows, Cc, dtype=qkv.dtype, device=dev)
+                return t, 0, (n_rows * Cc, Cc, HD)
+            return dqkv, slot * Cc, (N * 3 * Cc, 3 * Cc, HD)
+
+        tq, tk, tv = grad_target(0, Nq), grad_target(1, Nk), grad_target(2, Nk)
+        a = L.AttnArgs()
+        a.Q, a.K, a.V = _p(qd[0], qd[1]), _p(kd[0], kd[1]), _p(vd[0], vd[1])
+        a.O, a.LSE, a.dO, a.delta = _p(o), _p(lse), _p(do), _p(delta)
+        a.dQ, a.dK, a.dV = _p(tq[0], tq[1]), _p(tk[0], tk[1]), _p(tv[0], tv[1])
+        a.dtype, a.B, a.H, a.Nq, a.Nk, a.head_dim = _dt(qkv), B, H, Nq, Nk, HD
+        a.q_strides = (C.c_int64 * 3)(*qd[2])
+        a.k_strides = (C.c_int64 * 3)(*kd[2])
+        a.v_strides = (C.c_int64 * 3)(*vd[2])
+        a.o_strides = (C.c_int64 * 3)(Nq * Cc, Cc, HD)
+        a.do_strides = (C.c_int64 * 3)(Nq * Cc, Cc, HD)
+        a.dq_strides = (C.c_int64 * 3)(*tq[2])
+        a.dk_strides = (C.c_int64 * 3)(*tk[2])
+        a.dv_strides = (C.c_int64 * 3)(*tv[2])
+        a.scale = HD ** -0.5
+        a.mask_mode, a.mask_T, a.mask_HW = mask_mode, mask_T, mask_HW
+        ws = _ws(lib.csts_attn_bwd_workspace(C.byref(a)), dev)
+        L.check(lib.csts_attn_bwd(C.byref(a), _p(ws), ws.numel(), s), "csts_attn_bwd")
+
+        grads = {}
+
+        def pooled_bwd(slot, dy, w, gamma, transposed):
+            c, mean, rstd, g = saved[slot]
+            dc, dg, db = _ln_rows_bwd(dy, c, gamma, mean, rstd, HD)
+            wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
+            wws = _ws(wsz, dev)
+            dw = torch.empty(HD * 27, dtype=torch.float32, device=dev)
+            if transposed:   # fine = dc (output side), coarse = qkv slot
+                L.check(lib.csts_dwconv_strided(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
+                        "csts_dwconv_strided(bwd)")
+                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(dc), _dt(dc), _p(qkv, slot * Cc), _dt(qkv), _p(dw), _p(wws),
+                                              wws.numel(), s), "csts_dwconv_wgrad")
+            else:            # fine = qkv slot, coarse = dc
+                L.check(lib.csts_dwconv_transposed(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
+                        "csts_dwconv_transposed(bwd)")
+                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(dc), _dt(dc), _p(dw), _p(wws),
+                                              wws.numel(), s), "csts_dwconv_wgrad")
+            grads[slot] = (dw.view(HD, 1, 3, 3, 3), dg, db)
+
+        if 0 in saved:
+            pooled_bwd(0, tq[0], wq, gq, kind == "dec")
+        if 1 in saved:
+            pooled_bwd(1, tk[0], wk, gk, False)
+            pooled_bwd(2, tv[0], wv, gv, False)
+        gq_ = grads.get(0, (None, None, None))
+        gk_ = grads.get(1, (None, None, None))
+        gv_ = grads.get(2, (None, None, None))
+        return (dqkv, gq_[0], gq_[1], gq_[2], gk_[0], gk_[1], gk_[2], gv_[0], gv_[1], gv_[2], None)
+
+
+def attention_inner(qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta):
+    return AttnInnerFn.apply(qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta)
+
+
+def attention_probs(qkv, B, N, Cc, H, lse, mask_mode, mask_T, mask_HW):
+    """Probabilities of an un-pooled attention (fusion blocks) for return_spatial_attn / return_temporal_attn
+    (av_attention.py:150-153,358-359); forward-only visualisation output."""
+    HD = Cc // H
+    probs = torch.empty(B, H, N, N, dtype=torch.float32, device=qkv.device)
+    a = L.AttnArgs()
+    a.Q, a.K, a.V = _p(qkv, 0), _p(qkv, Cc), _p(qkv, 2 * Cc)
+    a.LSE = _p(lse)
+    a.dtype, a.B, a.H, a.Nq, a.Nk, a.head_dim = _dt(qkv), B, H, N, N, HD
+    st = (C.c_int64 * 3)(N * 3 * Cc, 3 * Cc, HD)
+    a.q_strides = st
+    a.k_strides = st
+    a.v_strides = st
+    a.scale = HD ** -0.5
+    a.mask_mode, a.mask_T, a.mask_HW = mask_mode, mask_T, mask_HW
+    L.check(_lib().csts_attn_probs(C.byref(a), _p(probs), _stream()), "csts_attn_probs")
+    return probs
+
+
+# ----------------------------------------------------------------------------------------- resampling
+def _pool_geom(B, Cc, thw_in, thw_out, stride) -> L.PoolGeom:
+    g = L.PoolGeom()
+    g.B, g.C = B, Cc
+    g.Ti, g.Hi, g.Wi = thw_in
+    g.To, g.Ho, g.Wo = thw_out
+    g.st, g.sh, g.sw = stride
+    return g
+
+
+class MaxPoolFn(Function):
+    """pool_skip MaxPool3d on tokens (attention.py:193-195,234-236,240)."""
+
+    @staticmethod
+    def forward(ctx, x, thw, stride):
+        _need_gpu(x)
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        k = [s + 1 if s > 1 else 1 for s in stride]
+        out = [(d + 2 * (kk // 2) - kk) // s + 1 for d, kk, s in zip(thw, k, stride)]
+        g = _pool_geom(B, Cc, thw, out, stride)
+        y = torch.empty(B, out[0] * out[1] * out[2], Cc, dtype=x.dtype, device=x.device)
+        arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        L.check(_lib().csts_maxpool_fwd(C.byref(g), _p(x), _dt(x), _p(y), _p(arg), _stream()), "csts_maxpool_fwd")
+        ctx.save_for_backward(arg)
+        ctx.g = g
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        L.check(_lib().csts_maxpool_bwd(C.byref(ctx.g), _p(dy), _dt(dy), _p(arg), _p(dx), _stream()), "csts_maxpool_bwd")
+        return dx, None, None
+
+
+class TrilinearFn(Function):
+    """nn.Upsample(scale_factor=stride, mode='trilinear') on tokens (attention.py:463-467,471); with `addend`
+    it is also feat + F.interpolate(en_feat) of custom_multimodal_builder.py:479."""
+
+    @staticmethod
+    def forward(ctx, x, thw, stride, addend):
+        _need_gpu(x)
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        out = [d * s for d, s in zip(thw, stride)]
+        g = _pool_geom(B, Cc, thw, out, stride)
+        y = torch.empty(B, out[0] * out[1] * out[2], Cc, dtype=x.dtype, device=x.device)
+        if addend is not None:
+            addend = addend.contiguous()
+        L.check(_lib().csts_trilinear_fwd(C.byref(g), _p(x), _dt(x), _p(addend), _dt(addend) if addend is not None else 0,
+                                          _p(y), _dt(y), _stream()), "csts_trilinear_fwd")
+        ctx.g = g
+        ctx.shape = x.shape
+        ctx.has_add = addend is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        L.check(_lib().csts_trilinear_bwd(C.byref(ctx.g), _p(dy), _dt(dy), _p(dx), _dt(dx), _stream()), "csts_trilinear_bwd")
+        return dx, None, None, (dy if ctx.has_add else None)
+
+
+def maxpool_skip(x, thw, stride):
+    return MaxPoolFn.apply(x, list(thw), list(stride))
+
+
+def trilinear(x, thw, stride, addend=None):
+    return TrilinearFn.apply(x, list(thw), list(stride), addend)
+
+
+# ----------------------------------------------------------------------------------------- patch embed
+class PatchEmbedFn(Function):
+    """PatchEmbed.forward (stem_helper.py:35-38) + separable pos-embed add (custom_multimodal_builder.py:362-370):
+    im2col -> MFMA GEMM with bias and the (broadcast) positional embedding in the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pos_s, pos_t, kernel, stride, padding, act_dt: int, compute: int):
+        _need_gpu(x, W)
+        x = x.contiguous()
+        B, Cin, T, H, Wd = x.shape
+        Cout = W.shape[0]
+        K = Cin * kernel[0] * kernel[1] * kernel[2]
+        Kpad = (K + 31) // 32 * 32
+        g = L.Im2colGeom()
+        g.B, g.Cin, g.T, g.H, g.W = B, Cin, T, H, Wd
+        g.kernel = (C.c_int * 3)(*kernel)
+        g.stride = (C.c_int * 3)(*stride)
+        g.padding = (C.c_int * 3)(*padding)
+        out = [(d + 2 * p - k) // s + 1 for d, p, k, s in zip((T, H, Wd), padding, kernel, stride)]
+        g.To, g.Ho, g.Wo = out
+        g.Kpad = Kpad
+        N = out[0] * out[1] * out[2]
+        M = B * N
+        col = torch.empty(M, Kpad, dtype=torch_dtype(act_dt), device=x.device)
+        L.check(_lib().csts_im2col(C.byref(g), _p(x), _dt(x), _p(col), act_dt, _stream()), "csts_im2col")
+        Wp = torch.zeros(Cout, Kpad, dtype=torch.float32, device=x.device)
+        Wp[:, :K] = W.reshape(Cout, K)            # weight-layout plumbing (42 K elements)
+        pos = torch.empty(N, Cout, dtype=torch.float32, device=x.device)
+        HW = out[1] * out[2]
+        L.check(_lib().csts_posembed_build(_p(pos_s), _p(pos_t), _p(pos), out[0], HW, Cout, _stream()), "csts_posembed_build")
+        y = torch.empty(B, N, Cout, dtype=torch.float32, device=x.device)
+        gemm(L.GEMM_NT, col, 0, Kpad, Wp, 0, Kpad, y, Cout, M, Cout, Kpad, compute=compute, bias=b, residual=pos, ldr=Cout,
+             res_row_mod=N)
+        ctx.save_for_backward(col)
+        ctx.meta = (B, N, out[0], HW, Cout, K, Kpad, compute, tuple(W.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (col,) = ctx.saved_tensors
+        B, N, T, HW, Cout, K, Kpad, compute, wshape = ctx.meta
+        dy = dy.contiguous()
+        M = B * N
+        dWp = _wgrad(dy, col, M, Cout, Kpad, compute)
+        dW = dWp[:, :K].reshape(wshape)
+        db = colsum(dy, 1, M, Cout)
+        dpos = colsum(dy, 1, B, N * Cout)                       # sum over batch -> (N*Cout)
+        dps = colsum(dpos, 1, T, HW * Cout).view(1, HW, Cout)   # sum over t
+        dpt = colsum(dpos, T, HW, Cout).view(1, T, Cout)        # sum over hw, per t
+        return None, dW, db, dps, dpt, None, None, None, None, None
+
+
+def patch_embed(x, W, b, pos_s, pos_t, kernel, stride, padding, act_dt, compute):
+    return PatchEmbedFn.apply(x, W, b, pos_s, pos_t, list(kernel), list(stride), list(padding), act_dt, compute)
+
+
+# ----------------------------------------------------------------------------------------- fusion conv
+class FusionConvFn(Function):
+    """Conv3d(C, C, kernel (1,8,8)) over the folded token grid -> (B, T, C)
+    (custom_multimodal_builder.py:227-229,420-421,442-445): token fold (batched transpose) + skinny split-K GEMM
+    that streams the 37.7 M-parameter weight once, in its native (Cout, Cin*H*W) layout."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, T: int, HW: int, act_dt: int, compute: int):
+        _need_gpu(x, W)
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        Cout = W.shape[0]
+        BT = B * T
+        K = Cc * HW
+        A = torch.empty(BT, K, dtype=torch_dtype(act_dt), device=x.device)
+        L.check(_lib().csts_transpose_batched(_p(x), _dt(x), _p(A), act_dt, BT, HW, Cc, _stream()), "csts_transpose_batched")
+        y = torch.zeros(B, T, Cout, dtype=torch.float32, device=x.device)
+        Wv = W.reshape(Cout, K)
+        split = max(1, min(128, K // 256))
+        gemm(L.GEMM_NT, A, 0, K, Wv, 0, K, y, Cout, BT, Cout, K, compute=compute, bias=b, split_k=split)
+        ctx.save_for_backward(A, W)
+        ctx.meta = (B, T, HW, Cc, Cout, compute, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        A, W = ctx.saved_tensors
+        B, T, HW, Cc, Cout, compute, xdtype = ctx.meta
+        BT, K = B * T, Cc * HW
+        dy = dy.contiguous()
+        Wv = W.reshape(Cout, K)
+        dW = torch.empty(Cout, K, dtype=torch.float32, device=dy.device)
+        gemm(L.GEMM_TN, dy, 0, Cout, A, 0, K, dW, K, Cout, K, BT, compute=compute)
+        db = colsum(dy, 1, BT, Cout)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty_like(A)
+            gemm(L.GEMM_NN, dy, 0, Cout, Wv, 0, K, dA, K, BT, K, Cout, compute=compute)
+            dx = torch.empty(B, T * HW, Cc, dtype=xdtype, device=dy.device)
+            L.check(_lib().csts_transpose_batched(_p(dA), _dt(dA), _p(dx), _dt(dx), BT, Cc, HW, _stream()),
+                    "csts_transpose_batched(bwd)")
+        return dx, dW.view(W.shape), db, None, None, None, None
+
+
+def fusion_conv(x, W, b, T, HW, act_dt, compute):
+    return FusionConvFn.apply(x, W, b, T, HW, act_dt, compute)
+
+
+# ----------------------------------------------------------------------------------------- glue
+class ReweightFn(Function):
+    """x.view(B,T,H,W,C) * w[:, :, None, None, :]  (custom_multimodal_builder.py:454-461)."""
+
+    @staticmethod
+    def forward(ctx, x, w, T: int, HW: int):
+        _need_gpu(x, w)
+        x = x.contiguous().float()
+        w = w.contiguous().float()
+        B, N, Cc = x.shape
+        y = torch.empty_like(x)
+        L.check(_lib().csts_reweight_fwd(_p(x), _p(w), _p(y), B * T, HW, Cc, _stream()), "csts_reweight_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.meta = (B * T, HW, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        BT, HW, Cc = ctx.meta
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        L.check(_lib().csts_reweight_bwd(_p(x), _p(w), _p(dy), _p(dx), _p(dw), BT, HW, Cc, _stream()), "csts_reweight_bwd")
+        return dx, dw, None, None
+
+
+class TokenMeanFn(Function):
+    """x.mean(dim=1)  (custom_multimodal_builder.py:493-494)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = x.contiguous().float()
+        B, N, Cc = x.shape
+        out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        L.check(_lib().csts_token_mean_fwd(_p(x), _p(out), B, N, Cc, _stream()), "csts_token_mean_fwd")
+        ctx.meta = (B, N, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, Cc = ctx.meta
+        dout = dout.contiguous().float()
+        dx = torch.empty(B, N, Cc, dtype=torch.float32, device=dout.device)
+        L.check(_lib().csts_token_mean_bwd(_p(dout), _p(dx), B, N, Cc, _stream()), "csts_token_mean_bwd")
+        return dx
+
+
+class AddFn(Function):
+    """a + b (decoder encoder-skip adds, custom_multimodal_builder.py:467,470,473)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        a = a.contiguous()
+        b = b.contiguous()
+        out = torch.empty_like(a)
+        L.check(_lib().csts_axpby(_p(a), _dt(a), _p(b), _dt(b), _p(out), _dt(out), a.numel(), 1.0, 1.0, _stream()), "csts_axpby")
+        ctx.bdtype = b.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, (d if d.dtype == ctx.bdtype else d.to(ctx.bdtype))
+
+
+def cast(x: torch.Tensor, dt: int) -> torch.Tensor:
+    out = torch.empty(x.shape, dtype=torch_dtype(dt), device=x.device)
+    x = x.contiguous()
+    L.check(_lib().csts_axpby(_p(x), _dt(x), None, 0, _p(out), dt, x.numel(), 1.0, 0.0, _stream()), "csts_axpby(cast)")
+    return out
+
+
+def reweight(x, w, T, HW):
+    return ReweightFn.apply(x, w, T, HW)
+
+
+def token_mean(x):
+    return TokenMeanFn.apply(x)
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+# ----------------------------------------------------------------------------------------- head + losses
+class ClassifierFn(Function):
+    """classifier(feat + F.interpolate(en_feat, (2T', H, W), 'trilinear'))  with classifier = Conv3d(96, 1, 1)
+    (custom_multimodal_builder.py:476-481)."""
+
+    @staticmethod
+    def forward(ctx, feat, en_feat, w, b, thw_en):
+        _need_gpu(feat, en_feat)
+        feat = feat.contiguous()
+        en_feat = en_feat.contiguous()
+        B, N2, Cc = feat.shape
+        out_thw = [thw_en[0] * 2, thw_en[1], thw_en[2]]
+        g = _pool_geom(B, Cc, thw_en, out_thw, (2, 1, 1))
+        z = torch.empty_like(feat)
+        L.check(_lib().csts_trilinear_fwd(C.byref(g), _p(en_feat), _dt(en_feat), _p(feat), _dt(feat), _p(z), _dt(z), _stream()),
+                "csts_trilinear_fwd(head)")
+        logits = torch.empty(B * N2, dtype=torch.float32, device=feat.device)
+        wf = w.reshape(-1).contiguous()
+        L.check(_lib().csts_rowdot_fwd(_p(z), _dt(z), _p(wf), _p(b), _p(logits), B * N2, Cc, _stream()), "csts_rowdot_fwd")
+        ctx.save_for_backward(z, wf)
+        ctx.g = g
+        ctx.meta = (B, N2, Cc, tuple(w.shape), en_feat.shape, en_feat.dtype)
+        return logits.view(B, 1, out_thw[0], out_thw[1], out_thw[2])
+
+    @staticmethod
+    def backward(ctx, dl):
+        z, wf = ctx.saved_tensors
+        B, N2, Cc, wshape, enshape, endtype = ctx.meta
+        dl = dl.contiguous().view(-1).float()
+        M = B * N2
+        dz = torch.empty_like(z)
+        L.check(_lib().csts_rowdot_dx(_p(dl), _p(wf), _p(dz), _dt(dz), M, Cc, _stream()), "csts_rowdot_dx")
+        dw = colsum(z, 1, M, Cc, row_weight=dl).view(wshape)
+        db = colsum(dl, 1, M, 1)
+        den = torch.empty(enshape, dtype=endtype, device=dl.device)
+        L.check(_lib().csts_trilinear_bwd(C.byref(ctx.g), _p(dz), _dt(dz), _p(den), _dt(den), _stream()), "csts_trilinear_bwd(head)")
+        return dz, den, dw, db, None
+
+
+def classifier_head(feat, en_feat, w, b, thw_en):
+    return ClassifierFn.apply(feat, en_feat, w, b, list(thw_en))
+
+
+class FrameSoftmaxFn(Function):
+    """frame_softmax(logits, temperature): softmax over H*W per (b, t)  (slowfast/utils/utils.py:5-12)."""
+
+    @staticmethod
+    def forward(ctx, logits, temperature: float):
+        _need_gpu(logits)
+        x = logits.contiguous().float()
+        n = x.shape[-1] * x.shape[-2]
+        rows = x.numel() // n
+        p = torch.empty_like(x)
+        L.check(_lib().csts_softmax_fwd(_p(x), _p(p), rows, n, temperature, _stream()), "csts_softmax_fwd")
+        ctx.save_for_backward(x)
+        ctx.meta = (rows, n, temperature)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (x,) = ctx.saved_tensors
+        rows, n, temperature = ctx.meta
+        dp = dp.contiguous().float()
+        dx = torch.empty_like(x)
+        L.check(_lib().csts_softmax_bwd(_p(x), _p(dp), _p(dx), rows, n, temperature, _stream()), "csts_softmax_bwd")
+        return dx, None
+
+
+class KLDivFn(Function):
+    """KLDiv.forward (slowfast/models/losses.py:59-82): sum_t KL(p || q) / (T log HW), mean over batch."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _need_gpu(pred)
+        p = pred.contiguous().float()
+        B, T, H, W = p.shape[0], p.shape[2], p.shape[3], p.shape[4]
+        n = H * W
+        rows = p.numel() // n
+        q = target.contiguous().float() if target is not None else None
+        scale = 1.0 / (T * math.log(n) * B)
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        ws = torch.empty(rows, dtype=torch.float32, device=p.device)
+        L.check(_lib().csts_kldiv_fwd(_p(p), _p(q), _p(loss), _p(ws), rows, n, scale, _stream()), "csts_kldiv_fwd")
+        if q is None:   # uniform prior: - log(1/HW) per frame (losses.py:69-73)
+            loss = loss + math.log(n) * T * B * scale
+        ctx.save_for_backward(p, q)
+        ctx.meta = (rows, n, scale)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q = ctx.saved_tensors
+        rows, n, scale = ctx.meta
+        g = g.contiguous().float().view(1)
+        dp = torch.empty_like(p)
+        L.check(_lib().csts_kldiv_bwd(_p(p), _p(q), _p(g), _p(dp), rows, n, scale, _stream()), "csts_kldiv_bwd")
+        return dp, None
+
+
+class RowNormFn(Function):
+    """a / max(||a||, eps) per row (sim_matrix, slowfast/utils/utils.py:20-22)."""
+
+    @staticmethod
+    def forward(ctx, a, eps: float):
+        _need_gpu(a)
+        a = a.contiguous().float()
+        rows, D = a.shape
+        an = torch.empty_like(a)
+        nrm = torch.empty(rows, dtype=torch.float32, device=a.device)
+        L.check(_lib().csts_rownorm_fwd(_p(a), _p(an), _p(nrm), rows, D, eps, _stream()), "csts_rownorm_fwd")
+        ctx.save_for_backward(a, nrm)
+        ctx.eps = eps
+        return an
+
+    @staticmethod
+    def backward(ctx, dan):
+        a, nrm = ctx.saved_tensors
+        dan = dan.contiguous().float()
+        da = torch.empty_like(a)
+        L.check(_lib().csts_rownorm_bwd(_p(a), _p(nrm), _p(dan), _p(da), a.shape[0], a.shape[1], ctx.eps, _stream()),
+                "csts_rownorm_bwd")
+        return da, None
+
+
+class EgoNCEFn(Function):
+    """EgoNCE.forward (slowfast/models/losses.py:157-170), temperature 0.05."""
+
+    @staticmethod
+    def forward(ctx, sim, temperature: float):
+        _need_gpu(sim)
+        x = sim.contiguous().float()
+        n = x.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        lr = torch.empty(n, dtype=torch.float32, device=x.device)
+        lc = torch.empty_like(lr)
+        L.check(_lib().csts_egonce_fwd(_p(x), _p(loss), _p(lr), _p(lc), n, temperature, _stream()), "csts_egonce_fwd")
+        ctx.save_for_backward(x, lr, lc)
+        ctx.meta = (n, temperature)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lr, lc = ctx.saved_tensors
+        n, temperature = ctx.meta
+        g = g.contiguous().float().view(1)
+        dx = torch.empty_like(x)
+        L.check(_lib().csts_egonce_bwd(_p(x), _p(lr), _p(lc), _p(g), _p(dx), n, temperature, _stream()), "csts_egonce_bwd")
+        return dx, None
+
+
+def frame_softmax(logits, temperature):
+    return FrameSoftmaxFn.apply(logits, float(temperature))
+
+
+def kldiv(pred, target=None):
+    return KLDivFn.apply(pred, target)
+
+
+def sim_matrix(a, b, eps=1e-8):
+    an = RowNormFn.apply(a, eps)
+    bn = RowNormFn.apply(b, eps)
+    return linear(an, bn, None, out_dt=F32, compute=F32)
+
+
+def egonce(sim, temperature=0.05):
+    return EgoNCEFn.apply(sim, float(temperature))

@@ -1,0 +1,126 @@
+"""Thin training-step harness: this package's counterpart of tools/train_avgaze_net.py:25-155 (reference Python
+never ships to the GPU box).  It reproduces the timed iteration -- LR set, forward, frame_softmax + KLDiv +
+LOSS_ALPHA * EgoNCE, backward (+ RCCL gradient all-reduce), L2 clip 1.0, AdamW -- without the reference's
+per-iteration host syncs (isnan / .item() / metric gathers run only when asked).  Optimizer and LR schedule are
+stock torch (a fused device optimizer is a "next" row)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import distributed as du
+from . import losses
+from .distributed import GradAllReduce
+
+
+def get_lr_at_epoch(cfg, cur_epoch: float) -> float:
+    """Cosine schedule with optional linear warm-up (slowfast/utils/lr_policy.py:9-53)."""
+    s = cfg.SOLVER
+    assert s.LR_POLICY == "cosine", "only the cosine policy of the CSTS YAMLs is implemented"
+
+    def cosine(e):
+        offset = s.WARMUP_EPOCHS if s.COSINE_AFTER_WARMUP else 0.0
+        assert s.COSINE_END_LR < s.BASE_LR
+        return s.COSINE_END_LR + (s.BASE_LR - s.COSINE_END_LR) * (math.cos(math.pi * (e - offset) / (s.MAX_EPOCH - offset)) + 1.0) * 0.5
+
+    lr = cosine(cur_epoch)
+    if cur_epoch < s.WARMUP_EPOCHS:
+        lr_end = cosine(s.WARMUP_EPOCHS)
+        alpha = (lr_end - s.WARMUP_START_LR) / s.WARMUP_EPOCHS
+        lr = cur_epoch * alpha + s.WARMUP_START_LR
+    return lr
+
+
+def set_lr(optimizer, new_lr: float):
+    for g in optimizer.param_groups:
+        g["lr"] = new_lr
+
+
+def construct_optimizer(model, cfg):
+    """AdamW(eps 1e-8) with zero weight decay on 1-D parameters and biases
+    (slowfast/models/optimizer.py:11-108 for OPTIMIZING_METHOD adamw, ZERO_WD_1D_PARAM)."""
+    assert cfg.SOLVER.OPTIMIZING_METHOD == "adamw", "the CSTS YAMLs train with adamw"
+    core = model.module if isinstance(model, GradAllReduce) else model
+    skip = core.no_weight_decay() if hasattr(core, "no_weight_decay") else {}
+    decay, no_decay = [], []
+    for name, m in core.named_modules():
+        for pn, p in m.named_parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            full = f"{name}.{pn}" if name else pn
+            if full in skip or (cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or full.endswith(".bias"))):
+                no_decay.append(p)
+            else:
+                decay.append(p)
+    groups = [g for g in ({"params": decay, "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
+                          {"params": no_decay, "weight_decay": 0.0}) if g["params"]]
+    return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+
+
+def compute_loss(cfg, model, video, audio, labels_hm, keep_masks=None):
+    """train_avgaze_net.py:70-93."""
+    if cfg.MODEL.LOSS_FUNC == "kldiv+egonce":
+        logits, v_emb, a_emb = model([video], audio, return_embed=True, keep_masks=keep_masks) \
+            if keep_masks is not None else model([video], audio, return_embed=True)
+        if du.is_dist():
+            v_emb, a_emb = du.all_gather_with_grad([v_emb, a_emb])
+        preds = losses.frame_softmax(logits, temperature=2)
+        kld = losses.KLDiv()(preds, labels_hm)
+        nce = losses.EgoNCE()(losses.sim_matrix(v_emb, a_emb))
+        return kld + cfg.MODEL.LOSS_ALPHA * nce, kld, nce, preds
+    logits = model([video], audio)
+    preds = losses.frame_softmax(logits, temperature=2)
+    kld = losses.get_loss_func(cfg.MODEL.LOSS_FUNC)()(preds, labels_hm)
+    return kld, kld, None, preds
+
+
+def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: Optional[float] = None, keep_masks=None):
+    """One iteration: forward + loss + backward (+ gradient all-reduce) [+ clip + AdamW when an optimizer is given].
+    Returns (loss, kld, nce) as device tensors (no host sync)."""
+    if optimizer is not None and lr is not None:
+        set_lr(optimizer, lr)
+    for p in model.parameters():
+        p.grad = None
+    loss, kld, nce, _ = compute_loss(cfg, model, batch["video"], batch["audio"], batch["labels_hm"], keep_masks)
+    loss.backward()
+    if isinstance(model, GradAllReduce):
+        model.finish()
+    if optimizer is not None:
+        if cfg.SOLVER.CLIP_GRAD_VAL:
+            torch.nn.utils.clip_grad_value_(model.parameters(), cfg.SOLVER.CLIP_GRAD_VAL)
+        elif cfg.SOLVER.CLIP_GRAD_L2NORM:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)
+        optimizer.step()
+    return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
+
+
+def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device) -> Dict[str, torch.Tensor]:
+    """Synthetic clips generated ON DEVICE following the dataset contract (SURVEY.md 8(d);
+    ego4d_avgaze_forecast.py:214-221,294-335): normalised uint8 video, log-power STFT windows of 24 kHz noise
+    (n_fft 511, hop 120, win 240: data/preprocess.py:276-290), 19x19-Gaussian gaze heatmaps."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    T, S = num_frames, crop
+    u = torch.randint(0, 256, (B, 3, T, S, S), generator=g, device=device).float()
+    video = (u / 255.0 - 0.45) / 0.225
+    n = 24000 * 5
+    wav = 0.1 * torch.randn(B, n, generator=g, device=device) + 0.05 * torch.sin(
+        2 * math.pi * 440.0 * torch.arange(n, device=device) / 24000.0)[None]
+    spec = torch.stft(wav, n_fft=511, hop_length=120, win_length=240, window=torch.hann_window(240, device=device),
+                      center=True, pad_mode="constant", return_complex=True)
+    logp = torch.log(spec.abs() ** 2 + 1e-6)
+    cols = logp.shape[-1]
+    audio = torch.empty(B, 1, T, S, S, device=device)
+    for t in range(T):
+        c = max(128, min(cols - 129, int(round((t + 0.5) / T * cols))))
+        audio[:, 0, t] = logp[:, :S, c - S // 2:c + S // 2]
+    yy, xx = torch.meshgrid(torch.arange(64.0, device=device), torch.arange(64.0, device=device), indexing="ij")
+    cx = (torch.rand(B, T, generator=g, device=device) * 63).round()
+    cy = (torch.rand(B, T, generator=g, device=device) * 63).round()
+    dx = xx[None, None] - cx[..., None, None]
+    dy = yy[None, None] - cy[..., None, None]
+    k = torch.exp(-(dx ** 2 + dy ** 2) / (2 * 3.2 ** 2)) * (dx.abs() <= 9) * (dy.abs() <= 9)
+    hm = k / k.sum(dim=(-1, -2), keepdim=True)
+    labels = torch.stack([cx / 63, cy / 63, torch.zeros_like(cx)], dim=-1).double()
+    return {"video": video, "audio": audio, "labels_hm": hm, "labels": labels}

@@ -1,0 +1,172 @@
+/* csts_hip.h -- C ABI of libcsts_hip.so, the MI355X (gfx950) kernel library behind the CSTS hot path.
+ *
+ * The reference (BolinLai/CSTS) owns no native code: its "FFI" for this path is the set of torch.nn ops
+ * its model calls.  Each entry point below replaces one such op (forward and backward),
+ * and cites the reference call site it stands in for (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory unless stated otherwise.
+ *   - tensors are token-major: (B, N = T*H*W, C) row-major, C fastest; "dt" arguments are CSTS_F32 / CSTS_BF16.
+ *   - every function enqueues work on `stream` and returns immediately: 0 on success, negative on a
+ *     rejected call (then csts_last_error() -- thread local -- describes why).  No allocation, no
+ *     synchronisation, no global state: workspaces are supplied by the caller (size queries alongside),
+ *     calls are safe from any host thread (e.g. the autograd worker) and are hipGraph-capturable.
+ */
+#ifndef CSTS_HIP_H
+#define CSTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+enum { CSTS_F32 = 0, CSTS_BF16 = 1 };
+enum { CSTS_GEMM_NT = 0, CSTS_GEMM_NN = 1, CSTS_GEMM_TN = 2 };
+enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
+enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
+
+const char* csts_last_error(void);
+int csts_abi_version(void);
+
+/* ---- GEMM: nn.Linear (attention.py:88-89,130,159; common.py:20-33; custom_multimodal_builder.py:223-224),
+ *      the (1,8,8) fusion Conv3d as a skinny GEMM (custom_multimodal_builder.py:227-229) and the patch-embed
+ *      Conv3d after im2col (stem_helper.py:27-38); plus their data- and weight-gradients.
+ *      NT: C = A[M,K] B[N,K]^T ; NN: C = A[M,K] B[K,N] ; TN: C = A[K,M]^T B[K,N].
+ *      epilogue: v = acc + bias[n]; GELU: aux[m,n] = v, v = gelu_erf(v); DGELU: v *= gelu'(aux[m,n]);
+ *                v *= row_scale[m / rows_per_scale] (drop-path, common.py:46-59); v += residual[m % res_row_mod, n].
+ *      split_k > 1: fp32 atomic accumulation into a pre-zeroed f32 C (bias only). */
+typedef struct {
+  int layout;
+  const void* A; int a_dt; int64_t lda;
+  const void* B; int b_dt; int64_t ldb;
+  void* C; int c_dt; int64_t ldc;
+  int64_t M, N, K;
+  const float* bias;
+  int epilogue;
+  void* aux; int aux_dt; int64_t ldaux;
+  const void* residual; int r_dt; int64_t ldr; int64_t res_row_mod;
+  const float* row_scale; int64_t rows_per_scale;
+  int compute;   /* CSTS_BF16: v_mfma_f32_32x32x16_bf16 ; CSTS_F32: v_mfma_f32_32x32x2_f32 (exact fp32) */
+  int split_k;
+} csts_gemm_args;
+int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
+
+/* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
+ *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */
+int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt, float* mean,
+                       float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
+size_t csts_layernorm_bwd_workspace(int64_t rows, int C);
+int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, int dx_dt, float* dgamma, float* dbeta, void* workspace,
+                       size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
+int csts_reduce_rows(const float* ws, float* out, int64_t nrows, int64_t ncols, float scale, hipStream_t stream);
+
+/* ---- depthwise 3x3x3 token stencils: attention_pool's Conv3d (attention.py:11-49,104-116) and
+ *      attention_upsample's ConvTranspose3d (attention.py:251-289,344-348).  "fine" is the larger grid.
+ *      weight is the reference layout (hd, 1, 3, 3, 3) fp32, shared by all heads (channel c uses c % HD). */
+typedef struct {
+  int B, C, HD;
+  int Tf, Hf, Wf, Tc, Hc, Wc;      /* coarse = floor((fine-1)/stride)+1 */
+  int st, sh, sw;
+  int64_t fine_batch_stride, fine_token_stride, coarse_batch_stride, coarse_token_stride;  /* elements */
+} csts_dwconv_geom;
+int csts_dwconv_strided(const csts_dwconv_geom* g, const void* fine, int fine_dt, const float* weight, void* coarse,
+                        int coarse_dt, hipStream_t stream);     /* pool fwd ; upsample bwd-data */
+int csts_dwconv_transposed(const csts_dwconv_geom* g, const void* coarse, int coarse_dt, const float* weight, void* fine,
+                           int fine_dt, hipStream_t stream);    /* upsample fwd ; pool bwd-data */
+size_t csts_dwconv_wgrad_workspace(const csts_dwconv_geom* g);
+int csts_dwconv_wgrad(const csts_dwconv_geom* g, const void* fine, int fine_dt, const void* coarse, int coarse_dt,
+                      float* dweight, void* workspace, size_t ws_bytes, hipStream_t stream);
+
+/* ---- residual-path resampling: MaxPool3d skip (attention.py:193-195,234-236,240), nn.Upsample trilinear skip
+ *      (attention.py:463-467,471) and F.interpolate of the patch feature (custom_multimodal_builder.py:479).
+ *      maxpool: kernel = stride+1 where stride>1 else 1, padding = kernel/2.  trilinear: out = in*stride,
+ *      align_corners=False; optional fused `addend` (same shape as y). */
+typedef struct {
+  int B, C;
+  int Ti, Hi, Wi, To, Ho, Wo;
+  int st, sh, sw;
+} csts_pool_geom;
+int csts_maxpool_fwd(const csts_pool_geom* g, const void* x, int dt, void* y, uint8_t* argmax, hipStream_t stream);
+int csts_maxpool_bwd(const csts_pool_geom* g, const void* dy, int dt, const uint8_t* argmax, void* dx, hipStream_t stream);
+int csts_trilinear_fwd(const csts_pool_geom* g, const void* x, int x_dt, const void* addend, int addend_dt, void* y,
+                       int y_dt, hipStream_t stream);
+int csts_trilinear_bwd(const csts_pool_geom* g, const void* dy, int dy_dt, void* dx, int dx_dt, hipStream_t stream);
+
+/* ---- fused attention core softmax(q k^T scale [same-frame mask]) v  (attention.py:154-158,384-388;
+ *      av_attention.py:137-141,334-350).  q/k/v/o are (B, N, H, hd) views given by element strides
+ *      {batch, token, head}; hd contiguous.  LSE/delta are fp32 (B, H, Nq); LSE is in the log2 domain. */
+typedef struct {
+  const void* Q; const void* K; const void* V; void* O; float* LSE;
+  const void* dO; float* delta; void* dQ; void* dK; void* dV;
+  int dtype, B, H, Nq, Nk, head_dim;
+  int64_t q_strides[3], k_strides[3], v_strides[3], o_strides[3];
+  int64_t do_strides[3], dq_strides[3], dk_strides[3], dv_strides[3];
+  float scale;
+  int mask_mode, mask_T, mask_HW;
+} csts_attn_args;
+int csts_attn_fwd(const csts_attn_args* a, hipStream_t stream);
+size_t csts_attn_bwd_workspace(const csts_attn_args* a);
+int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws_bytes, hipStream_t stream);
+int csts_attn_probs(const csts_attn_args* a, float* probs /* (B,H,Nq,Nk) */, hipStream_t stream);
+
+/* ---- patch embedding: Conv3d k(3,7,7) s(2,4,4) p(1,3,3) + flatten/transpose (stem_helper.py:27-38) as
+ *      im2col + csts_gemm; separable positional embedding (custom_multimodal_builder.py:362-370). */
+typedef struct {
+  int B, Cin, T, H, W;
+  int kernel[3], stride[3], padding[3];
+  int To, Ho, Wo;
+  int Kpad;
+} csts_im2col_geom;
+int csts_im2col(const csts_im2col_geom* g, const void* x, int x_dt, void* col, int col_dt, hipStream_t stream);
+int csts_posembed_build(const float* spatial, const float* temporal, float* pos, int T, int HW, int C, hipStream_t stream);
+
+/* ---- layout / reductions */
+int csts_transpose_batched(const void* in, int in_dt, void* out, int out_dt, int64_t batch, int R, int Cc,
+                           hipStream_t stream);   /* token fold for the (1,8,8) fusion convs */
+size_t csts_colsum_workspace(int64_t batch, int64_t M, int64_t N);
+int csts_colsum(const void* X, int dt, const float* row_weight, float* out, int64_t batch, int64_t M, int64_t N,
+                void* workspace, size_t ws_bytes, hipStream_t stream);   /* bias / pos-embed / classifier grads */
+int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, int64_t n, float alpha, float beta,
+               hipStream_t stream);
+
+int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
+                    int64_t M, int64_t N, hipStream_t stream);   /* drop-path backward (common.py:46-59) */
+
+/* ---- fusion glue (custom_multimodal_builder.py:454-461 re-weighting, :493-494 token mean) */
+int csts_reweight_fwd(const float* x, const float* w, float* y, int64_t BT, int HW, int C, hipStream_t stream);
+int csts_reweight_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int64_t BT, int HW, int C,
+                      hipStream_t stream);
+int csts_token_mean_fwd(const float* x, float* out, int64_t B, int N, int C, hipStream_t stream);
+int csts_token_mean_bwd(const float* dout, float* dx, int64_t B, int N, int C, hipStream_t stream);
+
+/* ---- head + losses: classifier Conv3d(96,1,1) (custom_multimodal_builder.py:301,481), frame_softmax
+ *      (slowfast/utils/utils.py:5-12), KLDiv (slowfast/models/losses.py:59-82), sim_matrix
+ *      (slowfast/utils/utils.py:15-24), EgoNCE (slowfast/models/losses.py:157-170). */
+int csts_rowdot_fwd(const void* x, int x_dt, const float* w, const float* bias, float* out, int64_t M, int C,
+                    hipStream_t stream);
+int csts_rowdot_dx(const float* dout, const float* w, void* dx, int dx_dt, int64_t M, int C, hipStream_t stream);
+int csts_softmax_fwd(const float* x, float* p, int64_t rows, int n, float temperature, hipStream_t stream);
+int csts_softmax_bwd(const float* x, const float* dp, float* dx, int64_t rows, int n, float temperature, hipStream_t stream);
+int csts_kldiv_fwd(const float* p, const float* q, float* loss, float* rowloss_ws, int64_t rows, int n, float scale,
+                   hipStream_t stream);
+int csts_kldiv_bwd(const float* p, const float* q, const float* grad_out, float* dp, int64_t rows, int n, float scale,
+                   hipStream_t stream);
+int csts_rownorm_fwd(const float* a, float* a_normed, float* norms, int64_t rows, int D, float eps, hipStream_t stream);
+int csts_rownorm_bwd(const float* a, const float* norms, const float* d_normed, float* da, int64_t rows, int D, float eps,
+                     hipStream_t stream);
+int csts_egonce_fwd(const float* sim, float* loss, float* lse_row, float* lse_col, int n, float temperature,
+                    hipStream_t stream);
+int csts_egonce_bwd(const float* sim, const float* lse_row, const float* lse_col, const float* grad_out, float* dsim, int n,
+                    float temperature, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSTS_HIP_H */

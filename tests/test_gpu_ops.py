@@ -1,0 +1,341 @@
+"""GPU parity tests, op level: every HIP kernel (through the C ABI, via csts_amd.ops) against a plain PyTorch fp32
+reference of the same op on the same seeded inputs.  Tolerances: fp32 mode (exact-fp32 MFMA) 2e-5 rel-L2;
+bf16 mode 2e-2 rel-L2 (operands rounded to bf16, fp32 accumulation)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():  # collected everywhere, run only on the GPU box
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from csts_amd import lib as L          # noqa: E402
+from csts_amd import ops               # noqa: E402
+from oracle import csts_oracle as O    # noqa: E402
+
+DEV = torch.device("cuda:0")
+TOL = {L.F32: 2e-5, L.BF16: 2e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0, dt=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dt)
+
+
+def tdt(c):
+    return torch.float32 if c == L.F32 else torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (1040, 768, 264), (128, 128, 32), (16, 768, 4096), (65, 97, 40)])
+def test_gemm_layouts(compute, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    dt = tdt(compute)
+    Ad = A.to(dt)
+    ref = Ad.float() @ B.t()
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(L.GEMM_NT, Ad, 0, K, B, 0, K, out, N, M, N, K, compute=compute)
+    assert rel_l2(out, ref) < TOL[compute]
+    # NN: A[M,K] @ Bn[K,N]
+    Bn = rnd(K, N, seed=3)
+    ops.gemm(L.GEMM_NN, Ad, 0, K, Bn, 0, N, out, N, M, N, K, compute=compute)
+    assert rel_l2(out, Ad.float() @ Bn) < TOL[compute]
+    # TN: At[K,M]^T @ Bn[K,N], split-k with atomics
+    At = rnd(K, M, seed=4).to(dt)
+    for split in (1, 3):
+        out2 = torch.zeros(M, N, device=DEV)
+        ops.gemm(L.GEMM_TN, At, 0, M, Bn, 0, N, out2, N, M, N, K, compute=compute, split_k=split)
+        assert rel_l2(out2, At.float().t() @ Bn) < TOL[compute]
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+def test_gemm_epilogues(compute):
+    M, N, K = 520, 384, 96
+    dt = tdt(compute)
+    A, W, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    res = rnd(260, N, seed=4)
+    rs = torch.tensor([0.0, 1.25], device=DEV)
+    pre = A.float() @ W.t() + b
+    out = torch.empty(M, N, device=DEV, dtype=dt)
+    aux = torch.empty(M, N, device=DEV, dtype=dt)
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out, N, M, N, K, compute=compute, bias=b, epilogue=L.EPI_GELU, aux=aux)
+    assert rel_l2(aux.float(), pre) < TOL[compute] and rel_l2(out.float(), F.gelu(pre)) < TOL[compute]
+    out32 = torch.empty(M, N, device=DEV)
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out32, N, M, N, K, compute=compute, bias=b, residual=res, ldr=N, res_row_mod=260,
+             row_scale=rs, rows_per_scale=260)
+    ref = pre * rs.repeat_interleave(260)[:, None] + res.repeat(2, 1)
+    assert rel_l2(out32, ref) < TOL[compute]
+    # DGELU: (A @ Wn) * gelu'(h)
+    h = rnd(M, N, seed=7).to(dt)
+    Wn = rnd(K, N, seed=8, scale=0.2)
+    ops.gemm(L.GEMM_NN, A, 0, K, Wn, 0, N, out32, N, M, N, K, compute=compute, epilogue=L.EPI_DGELU, aux=h)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).sum().backward()
+    assert rel_l2(out32, (A.float() @ Wn) * hf.grad) < TOL[compute]
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+def test_linear_and_mlp_autograd(compute):
+    dt = tdt(compute)
+    B, N, Cc, Hd, Co = 2, 130, 96, 384, 192
+    x = rnd(B, N, Cc, seed=1).to(dt).requires_grad_(True)
+    W1, b1 = rnd(Hd, Cc, seed=2, scale=0.1).requires_grad_(True), rnd(Hd, seed=3, scale=0.1).requires_grad_(True)
+    W2, b2 = rnd(Co, Hd, seed=4, scale=0.1).requires_grad_(True), rnd(Co, seed=5, scale=0.1).requires_grad_(True)
+    res = rnd(B, N, Co, seed=6).requires_grad_(True)
+    rs = torch.tensor([1.0 / 0.8, 0.0], device=DEV)
+    y = ops.mlp(x, W1, b1, W2, b2, residual=res, row_scale=rs, rows_per_scale=N, act_dt=compute, out_dt=L.F32, compute=compute)
+    gy = rnd(B, N, Co, seed=9)
+    y.backward(gy)
+    got = [y.detach(), x.grad, W1.grad, b1.grad, W2.grad, b2.grad, res.grad]
+    xr = x.detach().float().requires_grad_(True)
+    P = [t.detach().clone().requires_grad_(True) for t in (W1, b1, W2, b2, res)]
+    yr = F.linear(F.gelu(F.linear(xr, P[0], P[1])), P[2], P[3]) * rs[:, None, None] + P[4]
+    yr.backward(gy)
+    ref = [yr.detach(), xr.grad, P[0].grad, P[1].grad, P[2].grad, P[3].grad, P[4].grad]
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert rel_l2(a.float(), b) < TOL[compute] * 2, i
+    # plain linear with both operands differentiable (sim matrix use)
+    a_, b_ = rnd(5, 256, seed=1).requires_grad_(True), rnd(5, 256, seed=2).requires_grad_(True)
+    s = ops.linear(a_, b_, None, out_dt=L.F32, compute=L.F32)
+    s.backward(torch.ones_like(s))
+    assert rel_l2(s, a_.detach() @ b_.detach().t()) < 1e-5
+    assert rel_l2(a_.grad, torch.ones(5, 5, device=DEV) @ b_.detach()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("Cc", [96, 192, 384, 768])
+@pytest.mark.parametrize("out_dt", [L.F32, L.BF16])
+def test_layernorm(Cc, out_dt):
+    x = rnd(3, 77, Cc, seed=1, scale=2.0).requires_grad_(True)
+    g, b = (1 + 0.1 * rnd(Cc, seed=2)).requires_grad_(True), (0.1 * rnd(Cc, seed=3)).requires_grad_(True)
+    y = ops.layer_norm(x, g, b, 1e-6, out_dt)
+    gy = rnd(3, 77, Cc, seed=4).to(tdt(out_dt))
+    y.backward(gy)
+    xr, gr, br = [t.detach().clone().requires_grad_(True) for t in (x, g, b)]
+    yr = F.layer_norm(xr, (Cc,), gr, br, 1e-6)
+    yr.backward(gy.float())
+    tol = 2e-5 if out_dt == L.F32 else 1e-2
+    assert rel_l2(y.float(), yr) < tol
+    assert rel_l2(x.grad, xr.grad) < 1e-4 and rel_l2(g.grad, gr.grad) < 1e-4 and rel_l2(b.grad, br.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ attention inner
+def _ref_attn_inner(qkv, P, B, N, Cc, H, thw, kind, sq, skv, has_q, has_kv, mask):
+    HD = Cc // H
+    t = qkv.reshape(B, N, 3, H, HD).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    if kind == "dec":
+        q, _ = O.upsample_conv_ln(q, thw, P["wq"], sq, P["gq"], P["bq"])
+    elif has_q:
+        q, _ = O.pool_conv_ln(q, thw, P["wq"], sq, P["gq"], P["bq"])
+    if has_kv:
+        k, _ = O.pool_conv_ln(k, thw, P["wk"], skv, P["gk"], P["bk"])
+        v, _ = O.pool_conv_ln(v, thw, P["wv"], skv, P["gv"], P["bv"])
+    m = O.spatial_mask(thw[0], thw[1] * thw[2], qkv.device) if mask else None
+    o, _ = O.attention_core(q, k, v, HD ** -0.5, m)
+    return o.transpose(1, 2).reshape(B, q.shape[2], Cc)
+
+
+CASES = [
+    # name, B, thw, C, H, kind, sq, skv, has_q, has_kv, mask
+    ("enc_nopoolq", 2, (2, 16, 16), 96, 1, "enc", (1, 1, 1), (1, 8, 8), False, True, False),
+    ("enc_poolq", 2, (2, 16, 16), 192, 2, "enc", (1, 2, 2), (1, 4, 4), True, True, False),
+    ("enc_kv111", 1, (4, 8, 8), 384, 4, "enc", (1, 1, 1), (1, 1, 1), False, True, False),
+    ("enc_odd", 1, (3, 7, 5), 192, 2, "enc", (1, 2, 2), (1, 2, 2), True, True, False),
+    ("dec_122", 2, (2, 8, 8), 192, 2, "dec", (1, 2, 2), (1, 2, 2), True, True, False),
+    ("dec_211", 1, (2, 16, 16), 192, 2, "dec", (2, 1, 1), (1, 16, 16), True, True, False),
+    ("dec_hd192", 1, (2, 8, 8), 384, 2, "dec", (1, 2, 2), (1, 4, 4), True, True, False),
+    ("temporal", 2, (2, 2, 2), 768, 8, "plain", (1, 1, 1), (1, 1, 1), False, False, False),
+]
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_attention_inner(case, compute):
+    name, B, thw, Cc, H, kind, sq, skv, has_q, has_kv, mask = case
+    HD = Cc // H
+    N = thw[0] * thw[1] * thw[2]
+    dt = tdt(compute)
+    qkv = rnd(B, N, 3 * Cc, seed=1).to(dt).requires_grad_(True)
+    P = {}
+    for i, s in enumerate("qkv"):
+        P["w" + s] = rnd(HD, 1, 3, 3, 3, seed=10 + i, scale=0.2).requires_grad_(True)
+        P["g" + s] = (1 + 0.1 * rnd(HD, seed=20 + i)).requires_grad_(True)
+        P["b" + s] = (0.1 * rnd(HD, seed=30 + i)).requires_grad_(True)
+    use_q = has_q or kind == "dec"
+    meta = (B, N, Cc, H, list(thw), kind, sq, skv, use_q, has_kv, L.MASK_NONE, 0, 0, compute)
+    args = [P["wq"], P["gq"], P["bq"]] if use_q else [None, None, None]
+    args += [P["wk"], P["gk"], P["bk"], P["wv"], P["gv"], P["bv"]] if has_kv else [None] * 6
+    o, lse = ops.attention_inner(qkv, *args, meta)
+    go = rnd(*o.shape, seed=5).to(dt)
+    o.backward(go)
+    qr = qkv.detach().float().requires_grad_(True)
+    Pr = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    orf = _ref_attn_inner(qr, Pr, B, N, Cc, H, list(thw), kind, sq, skv, has_q, has_kv, mask)
+    orf.backward(go.float())
+    tol = 3e-5 if compute == L.F32 else 3e-2
+    assert rel_l2(o.float(), orf) < tol, "o"
+    assert rel_l2(qkv.grad.float(), qr.grad) < tol * 2, "dqkv"
+    used = (["q"] if use_q else []) + (["k", "v"] if has_kv else [])
+    for s in used:
+        for pfx in "wgb":
+            assert rel_l2(P[pfx + s].grad, Pr[pfx + s].grad) < tol * 3, pfx + s
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+def test_attention_spatial_mask_and_probs(compute):
+    B, T, Hh, Ww, Cc, H = 2, 2, 4, 4, 768, 8
+    HW = Hh * Ww
+    N = T * HW + T
+    dt = tdt(compute)
+    qkv = rnd(B, N, 3 * Cc, seed=3).to(dt).requires_grad_(True)
+    meta = (B, N, Cc, H, [T, Hh, Ww], "plain", (1, 1, 1), (1, 1, 1), False, False, L.MASK_SPATIAL, T, HW, compute)
+    o, lse = ops.attention_inner(qkv, *([None] * 9), meta)
+    go = rnd(*o.shape, seed=4).to(dt)
+    o.backward(go)
+    qr = qkv.detach().float().requires_grad_(True)
+    t = qr.reshape(B, N, 3, H, Cc // H).permute(2, 0, 3, 1, 4)
+    of, attn = O.attention_core(t[0], t[1], t[2], (Cc // H) ** -0.5, O.spatial_mask(T, HW, DEV))
+    of = of.transpose(1, 2).reshape(B, N, Cc)
+    of.backward(go.float())
+    tol = 3e-5 if compute == L.F32 else 3e-2
+    assert rel_l2(o.float(), of) < tol and rel_l2(qkv.grad.float(), qr.grad) < 2 * tol
+    probs = ops.attention_probs(qkv.detach(), B, N, Cc, H, lse, L.MASK_SPATIAL, T, HW)
+    assert rel_l2(probs, attn) < (1e-4 if compute == L.F32 else 3e-2)
+
+
+def test_attention_long_kv_online_softmax():
+    """N_kv = 1000 (not a multiple of the 64-key tile), large score range: exercises the online-softmax rescale."""
+    B, N, Cc, H = 1, 1000, 96, 1
+    qkv = rnd(B, N, 3 * Cc, seed=11, scale=3.0).requires_grad_(True)
+    meta = (B, N, Cc, H, [10, 10, 10], "plain", (1, 1, 1), (1, 1, 1), False, False, L.MASK_NONE, 0, 0, L.F32)
+    o, _ = ops.attention_inner(qkv, *([None] * 9), meta)
+    o.backward(torch.ones_like(o))
+    qr = qkv.detach().clone().requires_grad_(True)
+    t = qr.reshape(B, N, 3, H, Cc).permute(2, 0, 3, 1, 4)
+    of, _ = O.attention_core(t[0], t[1], t[2], Cc ** -0.5)
+    of = of.transpose(1, 2).reshape(B, N, Cc)
+    of.backward(torch.ones_like(of))
+    assert rel_l2(o, of) < 3e-5 and rel_l2(qkv.grad, qr.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ resampling
+@pytest.mark.parametrize("thw,stride", [((2, 8, 8), (1, 2, 2)), ((3, 7, 5), (1, 2, 2)), ((4, 6, 6), (2, 2, 2))])
+def test_maxpool_skip(thw, stride):
+    x = rnd(2, thw[0] * thw[1] * thw[2], 96, seed=1).requires_grad_(True)
+    y = ops.maxpool_skip(x, thw, stride)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    yr, _ = O.maxpool_skip(xr, list(thw), stride)
+    yr.backward(gy)
+    assert torch.equal(y, yr) and rel_l2(x.grad, xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize("thw,stride", [((2, 8, 8), (1, 2, 2)), ((4, 4, 4), (2, 1, 1)), ((3, 5, 7), (1, 2, 2))])
+def test_trilinear(thw, stride):
+    x = rnd(2, thw[0] * thw[1] * thw[2], 96, seed=1).requires_grad_(True)
+    y = ops.trilinear(x, thw, stride)
+    gy = rnd(*y.shape, seed=2)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    yr, _ = O.trilinear_skip(xr, list(thw), stride)
+    yr.backward(gy)
+    assert rel_l2(y, yr) < 1e-6 and rel_l2(x.grad, xr.grad) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ embed / fusion / head
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+@pytest.mark.parametrize("cin", [3, 1])
+def test_patch_embed(compute, cin):
+    x = rnd(2, cin, 4, 32, 32, seed=1)
+    W = rnd(96, cin, 3, 7, 7, seed=2, scale=0.05).requires_grad_(True)
+    b = rnd(96, seed=3, scale=0.1).requires_grad_(True)
+    ps = rnd(1, 64, 96, seed=4, scale=0.1).requires_grad_(True)
+    pt = rnd(1, 2, 96, seed=5, scale=0.1).requires_grad_(True)
+    y = ops.patch_embed(x, W, b, ps, pt, (3, 7, 7), (2, 4, 4), (1, 3, 3), compute, compute)
+    gy = rnd(*y.shape, seed=6)
+    y.backward(gy)
+    Pr = [t.detach().clone().requires_grad_(True) for t in (W, b, ps, pt)]
+    yr = O.patch_embed(x, Pr[0], Pr[1], (2, 4, 4), (1, 3, 3)) + Pr[2].repeat(1, 2, 1) + torch.repeat_interleave(Pr[3], 64, dim=1)
+    yr.backward(gy)
+    tol = TOL[compute]
+    assert rel_l2(y, yr) < tol
+    for a, r in zip((W, b, ps, pt), Pr):
+        assert rel_l2(a.grad, r.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+def test_fusion_conv(compute):
+    B, T, Cc = 2, 2, 192
+    x = rnd(B, T * 64, Cc, seed=1).requires_grad_(True)
+    W = rnd(Cc, Cc, 1, 8, 8, seed=2, scale=0.01).requires_grad_(True)
+    b = rnd(Cc, seed=3, scale=0.1).requires_grad_(True)
+    y = ops.fusion_conv(x, W, b, T, 64, compute, compute)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    Pr = [t.detach().clone().requires_grad_(True) for t in (x, W, b)]
+    yr = O.fusion_conv(Pr[0], [T, 8, 8], Pr[1], Pr[2])
+    yr.backward(gy)
+    tol = TOL[compute]
+    assert rel_l2(y, yr) < tol
+    for a, r in zip((x, W, b), Pr):
+        assert rel_l2(a.grad, r.grad) < 2 * tol
+
+
+def test_classifier_head_and_glue():
+    B, thw = 2, (2, 8, 8)
+    N = thw[0] * thw[1] * thw[2]
+    feat = rnd(B, 2 * N, 96, seed=1).requires_grad_(True)
+    en = rnd(B, N, 96, seed=2).requires_grad_(True)
+    w = rnd(1, 96, 1, 1, 1, seed=3, scale=0.1).requires_grad_(True)
+    b = rnd(1, seed=4).requires_grad_(True)
+    lg = ops.classifier_head(feat, en, w, b, thw)
+    gl = rnd(*lg.shape, seed=5)
+    lg.backward(gl)
+    Pr = [t.detach().clone().requires_grad_(True) for t in (feat, en, w, b)]
+    f5 = Pr[0].reshape(B, 4, 8, 8, 96).permute(0, 4, 1, 2, 3)
+    e5 = Pr[1].reshape(B, 2, 8, 8, 96).permute(0, 4, 1, 2, 3)
+    lr = F.conv3d(f5 + F.interpolate(e5, size=(4, 8, 8), mode="trilinear"), Pr[2], Pr[3])
+    lr.backward(gl)
+    assert rel_l2(lg, lr) < 1e-5
+    for a, r in zip((feat, en, w, b), Pr):
+        assert rel_l2(a.grad, r.grad) < 1e-4
+    # reweight / token mean / add
+    x = rnd(B, 4 * 64, 96, seed=6).requires_grad_(True)
+    wt = rnd(B, 4, 96, seed=7).requires_grad_(True)
+    y = ops.add(ops.reweight(x, wt, 4, 64), en.detach().repeat(1, 2, 1))
+    m = ops.token_mean(y)
+    m.backward(torch.ones_like(m))
+    xr, wr = x.detach().clone().requires_grad_(True), wt.detach().clone().requires_grad_(True)
+    yr = (xr.reshape(B, 4, 64, 96) * wr[:, :, None, :]).reshape(B, 256, 96) + en.detach().repeat(1, 2, 1)
+    mr = yr.mean(dim=1)
+    mr.backward(torch.ones_like(mr))
+    assert rel_l2(m, mr) < 1e-6 and rel_l2(x.grad, xr.grad) < 1e-6 and rel_l2(wt.grad, wr.grad) < 1e-5
+
+
+def test_losses_against_oracle():
+    logits = (rnd(3, 1, 4, 64, 64, seed=1) * 3).requires_grad_(True)
+    tgt = torch.rand(3, 4, 64, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+    tgt = tgt / tgt.sum(dim=(-1, -2), keepdim=True)
+    v, a = rnd(3, 256, seed=3).requires_grad_(True), rnd(3, 256, seed=4).requires_grad_(True)
+    p = ops.frame_softmax(logits, 2.0)
+    kl = ops.kldiv(p, tgt)
+    nce = ops.egonce(ops.sim_matrix(v, a))
+    (kl + 0.05 * nce).backward()
+    lr, vr, ar = [t.detach().clone().requires_grad_(True) for t in (logits, v, a)]
+    loss_r, kl_r, nce_r = O.csts_loss(lr, vr, ar, tgt, 0.05)
+    loss_r.backward()
+    assert abs(float(kl) - float(kl_r)) < 1e-5 and abs(float(nce) - float(nce_r)) < 1e-4
+    assert rel_l2(p, O.frame_softmax(lr.detach(), 2.0)) < 1e-5
+    assert rel_l2(logits.grad, lr.grad) < 1e-4 and rel_l2(v.grad, vr.grad) < 1e-4 and rel_l2(a.grad, ar.grad) < 1e-4
+    # uniform-prior KLDiv (target None)
+    assert abs(float(ops.kldiv(p.detach(), None)) - float(
+        ((p.detach().reshape(3, 4, -1) * torch.log(p.detach().reshape(3, 4, -1) + 1e-10)).sum(-1) + math.log(4096)).sum(-1).div(
+            4 * math.log(4096)).mean())) < 1e-5
