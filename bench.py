@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- CSTS training throughput on MI355X (BASELINE.json metric: clips/s, training step).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): CSTS_Ego4D_Gaze_Forecast.yaml + MODEL.LOSS_FUNC kldiv+egonce, 16 frames x 256^2
+(the reference itself cannot run 224^2), b = 4 clips per GPU (weak scaling), bf16 MFMA mode with fp32
+residual stream, synthetic clips + 24 kHz STFT resident in HBM before the timed region.  One step = forward +
+KLDiv + 0.05 EgoNCE + backward (+ bucketed RCCL gradient all-reduce when N > 1) + L2 clip + AdamW: nothing of the
+reference iteration (train_avgaze_net.py:65-109) is skipped.  Rank 0 prints ONE JSON line.
+
+Extra objects: "roofline" for the dominant kernel (the bf16 NT GEMM), measured live with HIP events on the
+launch stream over an instrumented pass, and "cpu_baseline" = the CPU oracle (a port, plain PyTorch fp32) timed on
+the host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FWD_GFLOP_PER_CLIP = {8: 208.7, 16: 465.3, 32: 1122.3}      # SURVEY.md 8(d) / BASELINE.md section 2
+BYTES_FWD_GB_PER_CLIP = {8: 1.24, 16: 2.34, 32: 4.53}
+PEAK_BF16_TFLOPS = 2500.0                                     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--frames", type=int, default=16)
+    p.add_argument("--batch-per-gpu", type=int, default=4)
+    p.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+class GemmTimer:
+    """HIP-event timing of every csts_gemm launch (events recorded on the launch stream = torch's current stream)."""
+
+    def __init__(self):
+        self.records = []   # (key, flops, bytes, ev0, ev1)
+
+    def install(self):
+        from csts_amd import ops
+        self._orig = ops.gemm
+        timer = self
+
+        def timed(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            timer._orig(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, **kw)
+            e1.record()
+            byt = M * K * A.element_size() + N * K * B.element_size() + M * N * Cm.element_size()
+            timer.records.append(((layout, kw.get("compute")), 2.0 * M * N * K, byt, e0, e1))
+        ops.gemm = timed
+
+    def remove(self):
+        from csts_amd import ops
+        ops.gemm = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += fl
+            a[2] += by
+            a[3] += e0.elapsed_time(e1) * 1e-3
+        return agg
+
+
+def cpu_baseline(frames):
+    """Oracle (CPU port, fp32 PyTorch ops) fwd + loss + bwd on ONE clip of the same shape; a bounded sample."""
+    from oracle import csts_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    P = {k: v.requires_grad_(True) for k, v in O.seeded_params(frames, 256).items()}
+    batch = O.synthetic_batch(2, frames, 256, seed=1000)    # B=2: EgoNCE is identically 0 at B=1
+    t0 = time.time()
+    logits, v, a = O.csts_forward(P, batch["video"], batch["audio"], frames, 256, return_embed=True)
+    loss, _, _ = O.csts_loss(logits, v, a, batch["labels_hm"], 0.05)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": round(2 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 un-warmed train step (fwd+loss+bwd, no optimizer) of the CPU oracle, B=2, {frames}x256^2, fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    from csts_amd.config import load_yaml
+    from csts_amd.build import build_model
+    from csts_amd import train as T
+    from csts_amd.distributed import GradAllReduce
+
+    b = args.batch_per_gpu
+    cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
+                    ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", b * world, "MODEL.LOSS_FUNC", "kldiv+egonce",
+                     "MODEL.LOSS_ALPHA", 0.05, "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute])
+    torch.manual_seed(cfg.RNG_SEED)
+    model = build_model(cfg)
+    model.train()
+    opt = T.construct_optimizer(model, cfg)
+    batch = T.synthetic_batch(b, args.frames, 256, 1000 + rank, dev)      # resident in HBM before timing
+    lr = T.get_lr_at_epoch(cfg, 0.0)
+
+    def step():
+        return T.train_step(cfg, model, batch, opt, lr)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, kld, nce = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    clips = b * world * args.steps
+    value = clips / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        gt = GemmTimer()
+        gt.install()
+        for _ in range(2):
+            step()
+        gt.remove()
+        agg = gt.summary()
+        from csts_amd import lib as L
+        key = (L.GEMM_NT, L.BF16 if args.compute == "bf16" else L.F32)
+        n, fl, by, sec = agg.get(key, (0, 0.0, 0.0, 1.0))
+        tot_sec = sum(a[3] for a in agg.values())
+        tot_fl = sum(a[1] for a in agg.values())
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<NT, %s> (x W^T: qkv/proj/fc1/fc2/patch-embed/fusion)" % args.compute,
+                "achieved": round(fl / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3,
+                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / (PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3), 4),
+                "traffic": None, "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
+                "algorithmic_flop_per_launch": round(fl / max(n, 1)), "algorithmic_bytes_per_launch": round(by / max(n, 1)),
+                "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2), "all_gemm_ms_per_step": round(tot_sec / 2 * 1e3, 2)}
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        per_gpu = value / world
+        train_gflop = 3 * FWD_GFLOP_PER_CLIP.get(args.frames, 0.0)
+        train_gb = 3 * BYTES_FWD_GB_PER_CLIP.get(args.frames, 0.0)
+        out = {
+            "metric": "clips/sec training (fwd+bwd) CSTS-Ego4D 16x256^2 bf16", "value": round(value, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
+            "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml train step (fwd + KLDiv + 0.05*EgoNCE + bwd"
+                                   f"{' + RCCL grad all-reduce' if world > 1 else ''} + clip + AdamW), "
+                                   f"{args.frames}x256^2 video + 24 kHz STFT audio, b={b}/GPU",
+                       "global_batch": b * world, "frames": args.frames, "crop": 256, "parallelism": f"dp{world}",
+                       "note": "256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)"},
+            "loss": round(float(loss), 5),
+            "end_to_end_roofline": {"mfma_frac": round(per_gpu * train_gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
+                                    "hbm_frac": round(per_gpu * train_gb / PEAK_HBM_GBS, 4),
+                                    "train_gflop_per_clip": train_gflop, "train_gb_per_clip": train_gb},
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.frames)
+            except Exception as e:  # keep the line valid even if the host runs out of memory
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

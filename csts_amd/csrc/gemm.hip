@@ -27,7 +27,7 @@ template <> struct Cmp<true> { typedef float T; };
 
 struct Params {
   const void* A; const void* B; void* C;
-  const float* bias; void* aux; const void* residual; const float* row_scale;
+  const float* bias; void* aux; const void* residual; const float* row_scale; float* ws;
   int64_t lda, ldb, ldc, ldaux, ldr;
   int64_t M, N, K, res_row_mod, rows_per_scale, k_chunk;
   int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
@@ -203,6 +203,10 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
+        if (p.split_k > 1 && p.ws != nullptr) {   // deterministic split-K: raw partial, finished by splitk_finish_kernel
+          p.ws[((int64_t)blockIdx.y * p.M + m) * p.N + n] = acc[mt][nt][r];
+          continue;
+        }
         float v = acc[mt][nt][r] + bias;
         if (p.split_k > 1) {
           atomicAdd(reinterpret_cast<float*>(p.C) + m * p.ldc + n, v);
@@ -225,6 +229,28 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
   }
 }
 
+// C = epilogue(sum_s ws[s]) for the deterministic split-K path
+__global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit) {
+  const int64_t total = p.M * p.N;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / p.N, n = idx - m * p.N;
+    float v = p.bias ? p.bias[n] : 0.f;
+    for (int sidx = 0; sidx < nsplit; ++sidx) v += p.ws[(int64_t)sidx * total + idx];
+    if (p.epilogue == CSTS_EPI_GELU) {
+      if (p.aux != nullptr) st_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
+      v = gelu_f(v);
+    } else if (p.epilogue == CSTS_EPI_DGELU) {
+      v *= dgelu_f(ld_as_f32(p.aux, p.aux_dt, m * p.ldaux + n));
+    }
+    if (p.row_scale != nullptr) v *= p.row_scale[m / p.rows_per_scale];
+    if (p.residual != nullptr) {
+      const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+      v += ld_as_f32(p.residual, p.r_dt, rm * p.ldr + n);
+    }
+    st_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
+  }
+}
+
 template <bool A_KC, bool B_KC>
 void launch(const Params& p, int compute, dim3 grid, hipStream_t s) {
   if (compute == CSTS_F32) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(NT_), 0, s, p);
@@ -240,14 +266,16 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   CSTS_REQUIRE(a->A && a->B && a->C, "null operand");
   CSTS_REQUIRE(a->compute == CSTS_F32 || a->compute == CSTS_BF16, "bad compute dtype");
   const int split = a->split_k > 1 ? a->split_k : 1;
-  if (split > 1) {
+  const bool det = split > 1 && a->workspace != nullptr;   // deterministic: partial slabs + finishing pass
+  if (split > 1 && !det) {
     CSTS_REQUIRE(a->c_dt == CSTS_F32, "split-k accumulates with fp32 atomics: C must be f32 (pre-zeroed)");
-    CSTS_REQUIRE(a->epilogue == CSTS_EPI_NONE && !a->residual && !a->row_scale, "split-k allows bias only");
+    CSTS_REQUIRE(a->epilogue == CSTS_EPI_NONE && !a->residual && !a->row_scale, "atomic split-k allows bias only");
   }
   if (a->epilogue == CSTS_EPI_DGELU) CSTS_REQUIRE(a->aux != nullptr, "DGELU needs aux (pre-activation)");
   Params p;
   p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.residual = a->residual;
   p.row_scale = a->row_scale;
+  p.ws = det ? reinterpret_cast<float*>(a->workspace) : nullptr;
   p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux; p.ldr = a->ldr;
   p.M = a->M; p.N = a->N; p.K = a->K; p.res_row_mod = a->res_row_mod;
   p.rows_per_scale = a->rows_per_scale > 0 ? a->rows_per_scale : 1;
@@ -261,6 +289,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   const int64_t ktiles = cdiv(a->K, BK);
   p.k_chunk = cdiv(ktiles, split) * BK;
   const int64_t nsplit = cdiv(a->K, p.k_chunk);
+  if (det) CSTS_REQUIRE(a->ws_bytes >= (size_t)nsplit * a->M * a->N * sizeof(float), "split-k workspace too small");
   p.ntiles_n = (int)cdiv(a->N, BN);
   const int64_t mtiles = cdiv(a->M, BM);
   CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
@@ -271,5 +300,17 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
     default: launch<false, false>(p, a->compute, grid, stream); break;
   }
   CSTS_LAUNCH_CHECK();
+  if (det) {
+    const int64_t total = a->M * a->N;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p,
+                       (int)nsplit);
+    CSTS_LAUNCH_CHECK();
+  }
   return 0;
+}
+
+extern "C" size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k) {
+  if (split_k <= 1) return 0;
+  const int64_t k_chunk = cdiv(cdiv(K, BK), split_k) * BK;
+  return (size_t)cdiv(K, k_chunk) * M * N * sizeof(float);
 }

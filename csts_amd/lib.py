@@ -31,7 +31,8 @@ class GemmArgs(C.Structure):
                 ("aux", vp), ("aux_dt", C.c_int), ("ldaux", i64),
                 ("residual", vp), ("r_dt", C.c_int), ("ldr", i64), ("res_row_mod", i64),
                 ("row_scale", vp), ("rows_per_scale", i64),
-                ("compute", C.c_int), ("split_k", C.c_int)]
+                ("compute", C.c_int), ("split_k", C.c_int),
+                ("workspace", vp), ("ws_bytes", sz)]
 
 
 class DwconvGeom(C.Structure):
@@ -73,6 +74,7 @@ SYMBOLS = {
     "csts_last_error": (C.c_char_p, []),
     "csts_abi_version": (_I, []),
     "csts_gemm": (_I, [C.POINTER(GemmArgs), vp]),
+    "csts_gemm_splitk_workspace": (sz, [i64, i64, i64, _I]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),

@@ -57,7 +57,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------------- raw wrappers
 def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
-         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1):
+         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True):
     a = L.GemmArgs()
     a.layout = layout
     a.A, a.a_dt, a.lda = _p(A, a_off), _dt(A), lda
@@ -71,6 +71,12 @@ def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bia
     a.res_row_mod = res_row_mod
     a.row_scale, a.rows_per_scale = _p(row_scale), rows_per_scale
     a.compute, a.split_k = compute, split_k
+    ws = None
+    if split_k > 1 and deterministic:
+        nb = _lib().csts_gemm_splitk_workspace(M, N, K, split_k)
+        if nb <= SPLITK_WS_LIMIT:
+            ws = _ws(nb, Cm.device)
+            a.workspace, a.ws_bytes = _p(ws), ws.numel()
     L.check(_lib().csts_gemm(C.byref(a), _stream()), "csts_gemm")
 
 
@@ -88,6 +94,9 @@ def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, rows_per_scale: int, M:
     L.check(_lib().csts_scale_rows(_p(x), _dt(x), _p(row_scale), rows_per_scale, _p(out), _dt(out), M, N, _stream()),
             "csts_scale_rows")
     return out
+
+
+SPLITK_WS_LIMIT = 256 << 20   # deterministic split-K slabs up to this size, atomics beyond
 
 
 def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
@@ -580,7 +589,7 @@ class FusionConvFn(Function):
         K = Cc * HW
         A = torch.empty(BT, K, dtype=torch_dtype(act_dt), device=x.device)
         L.check(_lib().csts_transpose_batched(_p(x), _dt(x), _p(A), act_dt, BT, HW, Cc, _stream()), "csts_transpose_batched")
-        y = torch.zeros(B, T, Cout, dtype=torch.float32, device=x.device)
+        y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
         Wv = W.reshape(Cout, K)
         split = max(1, min(128, K // 256))
         gemm(L.GEMM_NT, A, 0, K, Wv, 0, K, y, Cout, BT, Cout, K, compute=compute, bias=b, split_k=split)

@@ -56,7 +56,8 @@ def construct_optimizer(model, cfg):
                 decay.append(p)
     groups = [g for g in ({"params": decay, "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
                           {"params": no_decay, "weight_decay": 0.0}) if g["params"]]
-    return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    fused = all(p.is_cuda for g in groups for p in g["params"])     # one multi-tensor kernel per group on the GPU
+    return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY, fused=fused)
 
 
 def compute_loss(cfg, model, video, audio, labels_hm, keep_masks=None):

@@ -40,7 +40,8 @@ int csts_abi_version(void);
  *      NT: C = A[M,K] B[N,K]^T ; NN: C = A[M,K] B[K,N] ; TN: C = A[K,M]^T B[K,N].
  *      epilogue: v = acc + bias[n]; GELU: aux[m,n] = v, v = gelu_erf(v); DGELU: v *= gelu'(aux[m,n]);
  *                v *= row_scale[m / rows_per_scale] (drop-path, common.py:46-59); v += residual[m % res_row_mod, n].
- *      split_k > 1: fp32 atomic accumulation into a pre-zeroed f32 C (bias only). */
+ *      split_k > 1: with a workspace, deterministic partial slabs + finishing pass (full epilogue);
+ *                   without, fp32 atomic accumulation into a pre-zeroed f32 C (bias only). */
 typedef struct {
   int layout;
   const void* A; int a_dt; int64_t lda;
@@ -54,8 +55,10 @@ typedef struct {
   const float* row_scale; int64_t rows_per_scale;
   int compute;   /* CSTS_BF16: v_mfma_f32_32x32x16_bf16 ; CSTS_F32: v_mfma_f32_32x32x2_f32 (exact fp32) */
   int split_k;
+  void* workspace; size_t ws_bytes;   /* optional: makes split_k deterministic (partial slabs + finishing pass) */
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
+size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */

@@ -21,6 +21,6 @@ def golden_dir():
 
 def rel_l2(a, b):
     import torch
-    a = torch.as_tensor(a).double().flatten()
-    b = torch.as_tensor(b).double().flatten()
+    a = torch.as_tensor(a).detach().cpu().double().flatten()
+    b = torch.as_tensor(b).detach().cpu().double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))

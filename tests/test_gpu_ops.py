@@ -185,6 +185,11 @@ def test_attention_inner(case, compute):
     used = (["q"] if use_q else []) + (["k", "v"] if has_kv else [])
     for s in used:
         for pfx in "wgb":
+            if pfx + s == "bk":
+                # d/d(norm_k.bias) is exactly 0 (a constant key shift moves every score of a query equally and
+                # softmax is shift-invariant): both sides are rounding noise, compare against the scale of d(gamma_k)
+                assert float(P["bk"].grad.norm()) < (1e-3 if compute == L.F32 else 0.5) * float(Pr["gk"].grad.norm()) + 1e-6
+                continue
             assert rel_l2(P[pfx + s].grad, Pr[pfx + s].grad) < tol * 3, pfx + s
 
 
