@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
     return p.parse_args()
 
 
@@ -63,7 +64,7 @@ class GemmTimer:
             timer._orig(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, **kw)
             e1.record()
             byt = M * K * A.element_size() + N * K * B.element_size() + M * N * Cm.element_size()
-            timer.records.append(((layout, kw.get("compute")), 2.0 * M * N * K, byt, e0, e1))
+            timer.records.append(((layout, kw.get("compute")), 2.0 * M * N * K, byt, e0, e1, (M, N, K, kw.get("split_k", 1))))
         ops.gemm = timed
 
     def remove(self):
@@ -73,7 +74,7 @@ class GemmTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, fl, by, e0, e1 in self.records:
+        for key, fl, by, e0, e1, _shape in self.records:
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += fl
@@ -81,11 +82,24 @@ class GemmTimer:
             a[3] += e0.elapsed_time(e1) * 1e-3
         return agg
 
+    def dump_shapes(self, path):
+        torch.cuda.synchronize()
+        per = {}
+        for key, fl, by, e0, e1, shape in self.records:
+            a = per.setdefault((key[0],) + shape, [0, 0.0, fl, by])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+        rows = sorted(per.items(), key=lambda kv: -kv[1][1])
+        with open(path, "w") as f:
+            f.write("layout M N K split calls total_ms avg_us TFLOPs GBps\n")
+            for (lay, M, N, K, sp), (n, sec, fl, by) in rows:
+                f.write(f"{'NT NN TN'.split()[lay]} {M} {N} {K} {sp} {n} {sec*1e3:.3f} {sec/n*1e6:.1f} {fl*n/sec/1e12:.1f} {by*n/sec/1e9:.0f}\n")
+
 
 def cpu_baseline(frames):
     """Oracle (CPU port, fp32 PyTorch ops) fwd + loss + bwd on ONE clip of the same shape; a bounded sample."""
     from oracle import csts_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads only add contention for these op sizes
     P = {k: v.requires_grad_(True) for k, v in O.seeded_params(frames, 256).items()}
     batch = O.synthetic_batch(2, frames, 256, seed=1000)    # B=2: EgoNCE is identically 0 at B=1
     t0 = time.time()
@@ -160,6 +174,8 @@ def main():
             step()
         gt.remove()
         agg = gt.summary()
+        if args.dump_gemm:
+            gt.dump_shapes(args.dump_gemm)
         from csts_amd import lib as L
         key = (L.GEMM_NT, L.BF16 if args.compute == "bf16" else L.F32)
         n, fl, by, sec = agg.get(key, (0, 0.0, 0.0, 1.0))

@@ -102,19 +102,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 }
 
 // out[j] = sum_i ws[i][j]   (deterministic second stage of every cross-block reduction in the library)
+// block = 32 columns x RL row-lanes; fixed summation order -> bitwise reproducible
+template <int RL>
 __global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t nrows, int64_t ncols,
                                    float scale) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncols) return;
+  __shared__ float red[RL][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t j = (int64_t)blockIdx.x * 32 + tx;
   float s = 0.f;
-  for (int64_t i = 0; i < nrows; ++i) s += ws[i * ncols + j];
-  out[j] = s * scale;
+  if (j < ncols)
+    for (int64_t i = ty; i < nrows; i += RL) s += ws[i * ncols + j];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < RL; ++r) t += red[r][tx];
+    out[j] = t * scale;
+  }
 }
 
 }  // namespace
 
 int csts_reduce_rows_launch(const float* ws, float* out, int64_t nrows, int64_t ncols, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv(ncols, 256)), dim3(256), 0, s, ws, out, nrows, ncols, scale);
+  const dim3 grid((unsigned)cdiv(ncols, 32));
+  if (nrows > 64) hipLaunchKernelGGL(reduce_rows_kernel<32>, grid, dim3(1024), 0, s, ws, out, nrows, ncols, scale);
+  else if (nrows > 8) hipLaunchKernelGGL(reduce_rows_kernel<8>, grid, dim3(256), 0, s, ws, out, nrows, ncols, scale);
+  else hipLaunchKernelGGL(reduce_rows_kernel<2>, grid, dim3(64), 0, s, ws, out, nrows, ncols, scale);
   return 0;
 }
 

@@ -107,8 +107,9 @@ def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
 def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int) -> torch.Tensor:
     """dW[N,K] = dY[M,N]^T X[M,K] (fp32, split over M with fp32 atomics)."""
     split = _wgrad_split(N, K, M)
-    dW = (torch.zeros if split > 1 else torch.empty)(N, K, dtype=torch.float32, device=dY.device)
-    gemm(L.GEMM_TN, dY, 0, N, X, 0, K, dW, K, N, K, M, compute=compute, split_k=split)
+    det = split > 1 and _lib().csts_gemm_splitk_workspace(N, K, M, split) <= SPLITK_WS_LIMIT
+    dW = (torch.zeros if (split > 1 and not det) else torch.empty)(N, K, dtype=torch.float32, device=dY.device)
+    gemm(L.GEMM_TN, dY, 0, N, X, 0, K, dW, K, N, K, M, compute=compute, split_k=split, deterministic=det)
     return dW
 
 

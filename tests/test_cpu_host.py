@@ -1,0 +1,198 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared symbol, host logic (config, registry,
+state_dict surface, LR schedule, optimizer groups, CLI parsing), loud failure without a GPU, and the N>1 data-parallel
+logic over a 2-process gloo group."""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+YAML = os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml")
+
+
+def test_library_exports_every_declared_symbol():
+    from csts_amd import lib
+    handle = lib.load()                      # raises loudly if the .so is missing / stale
+    assert handle.csts_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "csts_hip.h")).read()
+    declared = set(re.findall(r"\b(csts_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(lib.SYMBOLS), (declared ^ set(lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.csts_last_error() is not None
+
+
+def test_bad_call_is_rejected_with_message_and_no_gpu_needed():
+    """Argument validation happens on the host before any launch: a null problem returns -1 + a message."""
+    from csts_amd import lib
+    h = lib.load()
+    a = lib.GemmArgs()
+    rc = h.csts_gemm(a, None)
+    assert rc != 0 and b"csts_gemm" in h.csts_last_error()
+    assert h.csts_layernorm_bwd_workspace(1024, 96) > 0
+    assert h.csts_colsum_workspace(1, 4096, 96) > 0
+
+
+def test_registry_and_build_boundary():
+    import slowfast.models as sm
+    from csts_amd.config import load_yaml
+    assert sm.MODEL_REGISTRY.get("CSTS").__name__ == "CSTS"
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "MODEL.LOSS_FUNC", "kldiv+egonce"])
+    m = sm.build_model(cfg)
+    ref = json.load(open(os.path.join(GOLDEN, "manifest_T8.json")))
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["entries"]
+    assert sum(p.numel() for p in m.parameters()) == ref["num_params"] == 188182401
+    assert m.no_weight_decay() == {}
+    # reference mutates cfg.MVIT.POOL_KV_STRIDE in __init__ (custom_multimodal_builder.py:136-142); so do we
+    geo = json.load(open(os.path.join(GOLDEN, "geometry_T8.json")))
+    assert cfg.MVIT.POOL_KV_STRIDE == geo["pool_kv_stride"]
+    # init contract: LN weight 1 / bias 0, Linear bias 0, trunc-normal(0.02) Linear weights
+    assert float(m.blocks[0].norm1.weight.min()) == 1.0 and float(m.blocks[3].mlp.fc1.bias.abs().max()) == 0.0
+    assert 0.015 < float(m.blocks[3].mlp.fc1.weight.std()) < 0.022
+    with pytest.raises(KeyError):
+        sm.MODEL_REGISTRY.get("SlowFast")
+
+
+def test_kldiv_only_variant_and_T32_manifest():
+    from csts_amd.config import load_yaml
+    from csts_amd.build import build_model
+    m = build_model(load_yaml(YAML, ["NUM_GPUS", 0]))       # YAML default LOSS_FUNC kldiv: no vision_proj/audio_proj
+    ref = json.load(open(os.path.join(GOLDEN, "manifest_T8_kldiv.json")))
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["entries"]
+    m32 = build_model(load_yaml(YAML, ["NUM_GPUS", 0, "DATA.NUM_FRAMES", 32, "MODEL.LOSS_FUNC", "kldiv+egonce"]))
+    ref32 = json.load(open(os.path.join(GOLDEN, "manifest_T32.json")))
+    assert [[k, list(v.shape)] for k, v in m32.state_dict().items()] == ref32["entries"]
+
+
+def test_forward_fails_loudly_without_gpu():
+    from csts_amd.config import load_yaml
+    from csts_amd.build import build_model
+    from csts_amd.lib import CstsError
+    m = build_model(load_yaml(YAML, ["NUM_GPUS", 0]))
+    with pytest.raises(CstsError):
+        m([torch.zeros(1, 3, 8, 256, 256)], torch.zeros(1, 1, 8, 256, 256))
+    from csts_amd import ops
+    with pytest.raises(CstsError):
+        ops.layer_norm(torch.zeros(4, 96), torch.ones(96), torch.zeros(96), 1e-6, 0)
+
+
+def test_unsupported_configs_raise_like_reference():
+    from csts_amd.config import load_yaml
+    from csts_amd.build import build_model
+    with pytest.raises(NotImplementedError):
+        build_model(load_yaml(YAML, ["NUM_GPUS", 0, "MVIT.NORM", "batchnorm"]))
+    with pytest.raises(AssertionError):
+        build_model(load_yaml(YAML, ["NUM_GPUS", 0, "DATA.TEST_CROP_SIZE", 224]))   # custom_multimodal_builder.py:28
+
+
+def test_lr_schedule_matches_reference_samples():
+    from csts_amd.config import load_yaml
+    from csts_amd.train import get_lr_at_epoch
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0])
+    g = np.load(os.path.join(GOLDEN, "lr_schedule.npz"))
+    for e, lr in zip(g["epochs"], g["lr"]):
+        assert abs(get_lr_at_epoch(cfg, float(e)) - float(lr)) < 1e-12
+
+
+def test_optimizer_param_groups():
+    from csts_amd.config import load_yaml
+    from csts_amd.build import build_model
+    from csts_amd.train import construct_optimizer
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "MODEL.LOSS_FUNC", "kldiv+egonce"])
+    m = build_model(cfg)
+    opt = construct_optimizer(m, cfg)
+    wd = {g["weight_decay"]: sum(p.numel() for p in g["params"]) for g in opt.param_groups}
+    assert set(wd) == {0.05, 0.0}
+    n1d = sum(p.numel() for n, p in m.named_parameters() if p.dim() == 1 or n.endswith(".bias"))
+    assert wd[0.0] == n1d and wd[0.05] + wd[0.0] == 188182401
+    assert opt.defaults["eps"] == 1e-8
+    # pos-embeds (3-D) DO get weight decay with ZERO_DECAY_POS_CLS False
+    assert any(p is m.pos_embed_spatial for g in opt.param_groups if g["weight_decay"] > 0 for p in g["params"])
+
+
+def test_cli_parsing_and_yaml_tuple_strings():
+    from csts_amd.cli import parse_args, load_config
+    args = parse_args(["--cfg", YAML, "--init_method", "tcp://127.0.0.1:9997", "NUM_GPUS", "8", "TRAIN.BATCH_SIZE", "32",
+                       "MODEL.LOSS_FUNC", "kldiv+egonce", "OUTPUT_DIR", "/tmp/csts_test_out"])
+    cfg = load_config(args)
+    assert cfg.NUM_GPUS == 8 and cfg.TRAIN.BATCH_SIZE == 32 and cfg.MODEL.LOSS_FUNC == "kldiv+egonce"
+    assert cfg.MVIT.PATCH_KERNEL == [3, 7, 7] and cfg.SOLVER.COSINE_END_LR == 1e-6
+    for y in ("configs/Aria/CSTS_Aria_Gaze_Forecast.yaml", "configs/Aria/CSTS_Aria_Gaze_Estimation.yaml",
+              "configs/Ego4D/CSTS_Ego4D_Gaze_Estimation.yaml"):
+        c = load_config(parse_args(["--cfg", os.path.join(ROOT, y), "OUTPUT_DIR", "/tmp/csts_test_out"]))
+        assert c.MODEL.MODEL_NAME == "CSTS" and c.DATA.NUM_FRAMES == 8 and c.DATA.TRAIN_CROP_SIZE == 256
+
+
+# ----------------------------------------------------------------------------------------------- 2-rank gloo
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from csts_amd import distributed as du
+        from oracle import csts_oracle as O
+        torch.manual_seed(0)
+        # (1) EgoNCE embedding gather: W-rank gradient == single-process gradient on the concatenated batch
+        full_v = torch.randn(4, 16)
+        full_a = torch.randn(4, 16)
+        v = full_v[2 * rank:2 * rank + 2].clone().requires_grad_(True)
+        a = full_a[2 * rank:2 * rank + 2].clone().requires_grad_(True)
+        gv, ga = du.all_gather_with_grad([v, a])
+        assert torch.equal(gv.detach(), full_v)
+        loss = O.egonce(O.sim_matrix(gv, ga))
+        loss.backward()
+        fv, fa = full_v.clone().requires_grad_(True), full_a.clone().requires_grad_(True)
+        O.egonce(O.sim_matrix(fv, fa)).backward()
+        # data-parallel convention: per-rank grads are averaged over ranks afterwards
+        ok1 = torch.allclose(v.grad / world, fv.grad[2 * rank:2 * rank + 2], atol=1e-6)
+        # (2) bucketed gradient all-reduce == mean of per-rank grads, all buckets flushed, ready-order re-bucketing
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                                  torch.nn.Linear(32, 4))
+        wrapped = du.GradAllReduce(net, bucket_mb=0)      # 0 MB -> one bucket per parameter: exercises ordering
+        ok2 = True
+        for it in range(2):
+            x = torch.randn(3, 8, generator=torch.Generator().manual_seed(100 + rank + 10 * it))
+            for p in net.parameters():
+                p.grad = None
+            wrapped(x).pow(2).sum().backward()
+            local = [p.grad.clone() for p in net.parameters()]
+            wrapped.finish()
+            for p, l in zip(net.parameters(), local):
+                buf = [torch.empty_like(l) for _ in range(world)]
+                dist.all_gather(buf, l)
+                ok2 &= torch.allclose(p.grad, sum(buf) / world, atol=1e-6)
+        # (3) fused scalar all-reduce and metric gather
+        r = du.all_reduce([torch.tensor(float(rank)), torch.tensor(2.0 * rank)])
+        ok3 = abs(float(r[0]) - 0.5) < 1e-6 and abs(float(r[1]) - 1.0) < 1e-6
+        g = du.all_gather([torch.full((2, 3), float(rank))])[0]
+        ok3 &= g.shape == (4, 3) and float(g[0, 0]) == 0.0 and float(g[3, 0]) == 1.0
+        q.put((rank, bool(ok1), bool(ok2), bool(ok3)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel_logic():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert r[1], "all_gather_with_grad backward != single-process gradient"
+        assert r[2], "bucketed gradient all-reduce != mean of per-rank gradients"
+        assert r[3], "scalar all-reduce / gather"
