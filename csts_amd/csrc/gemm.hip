@@ -251,6 +251,255 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit
   }
 }
 
+// =====================================================================================================
+// v2 kernel (bf16 MFMA only): BK = 64, double-buffered LDS (one barrier per k-tile), raw register staging of the
+// next tile (global loads stay in flight across the MFMA phase), source dtypes compile-time, 128- or 64-row
+// tiles (small grids get twice the workgroups), and an epilogue staged through LDS so that every global
+// load/store of C / residual / aux is a coalesced 16-byte access.
+// =====================================================================================================
+constexpr int BK2 = 64;
+constexpr int KC2_LD = BK2 + 8;            // 144 B rows: conflict-free ds_read_b128 over 16 rows
+constexpr int CS_LD = 128 + 4;             // fp32 C staging row stride
+
+template <bool F32S> struct Raw { uint4 v[F32S ? 2 : 1]; };
+
+template <bool F32S>
+__device__ __forceinline__ void raw_load(Raw<F32S>& r, const void* base, int64_t idx, bool valid) {
+  if (valid) {
+    if (F32S) {
+      const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(base) + idx);
+      r.v[0] = q[0];
+      r.v[F32S ? 1 : 0] = q[1];
+    } else {
+      r.v[0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(base) + idx);
+    }
+  } else {
+    r.v[0] = make_uint4(0, 0, 0, 0);
+    if (F32S) r.v[F32S ? 1 : 0] = make_uint4(0, 0, 0, 0);
+  }
+}
+template <bool F32S>
+__device__ __forceinline__ bf16x8 raw_to_bf16(const Raw<F32S>& r) {
+  if (F32S) {
+    const f32x4 a = __builtin_bit_cast(f32x4, r.v[0]), b = __builtin_bit_cast(f32x4, r.v[F32S ? 1 : 0]);
+    bf16x8 o;
+    o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
+    o[4] = (bf16)b[0]; o[5] = (bf16)b[1]; o[6] = (bf16)b[2]; o[7] = (bf16)b[3];
+    return o;
+  } else {
+    return __builtin_bit_cast(bf16x8, r.v[0]);
+  }
+}
+
+// one operand tile: EXT output rows (128 or 64) x 64 k.  KC: LDS [EXT][72] ; OC: LDS [64][EXT+32]
+template <bool KC, bool F32S, int EXT> struct Oper {
+  static constexpr int NCH = EXT / 32;                  // chunks of 8 elements per thread
+  static constexpr int CPR = EXT / 8;                   // OC: chunks per k-row
+  static constexpr int OC_LD = EXT + 32;
+  static constexpr int LDS_ELEMS = KC ? EXT * KC2_LD : BK2 * OC_LD;
+  Raw<F32S> raw[NCH];
+  __device__ __forceinline__ void load(const void* P, int64_t ld, int64_t out0, int64_t out_lim, int64_t k0, int64_t k_lim,
+                                       int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (KC) {
+        const int64_t r = out0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 8;
+        raw_load<F32S>(raw[i], P, r * ld + k, r < out_lim && k < k_lim);
+      } else {
+        const int64_t k = k0 + tid / CPR + (256 / CPR) * i, o = out0 + (tid % CPR) * 8;
+        raw_load<F32S>(raw[i], P, k * ld + o, k < k_lim && o < out_lim);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(bf16* S, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const bf16x8 w = raw_to_bf16<F32S>(raw[i]);
+      if (KC) *reinterpret_cast<bf16x8*>(&S[((tid >> 3) + 32 * i) * KC2_LD + (tid & 7) * 8]) = w;
+      else *reinterpret_cast<bf16x8*>(&S[(tid / CPR + (256 / CPR) * i) * OC_LD + (tid % CPR) * 8]) = w;
+    }
+  }
+  // MFMA 32x32x16 fragment for output rows obase..obase+31, k-substep ks (0..3)
+  static __device__ __forceinline__ bf16x8 frag(const bf16* S, int obase, int ks, int lane) {
+    if (KC) {
+      return *reinterpret_cast<const bf16x8*>(&S[(obase + (lane & 31)) * KC2_LD + ks * 16 + 8 * (lane >> 5)]);
+    } else {
+      const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+      const bf16* a = &S[(ks * 16 + 8 * (g >> 1) + q) * OC_LD + obase + 16 * (g & 1) + 4 * pp];
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+      const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * OC_LD));
+      const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
+      bf16x8 r;
+      r[0] = b0[0]; r[1] = b0[1]; r[2] = b0[2]; r[3] = b0[3];
+      r[4] = b1[0]; r[5] = b1[1]; r[6] = b1[2]; r[7] = b1[3];
+      return r;
+    }
+  }
+};
+
+template <bool A_KC, bool B_KC, bool A_F32, bool B_F32, int MT>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
+  constexpr int BM2 = 64 * MT;
+  typedef Oper<A_KC, A_F32, BM2> OA;
+  typedef Oper<B_KC, B_F32, 128> OB;
+  constexpr int STAGE = OA::LDS_ELEMS + OB::LDS_ELEMS;
+  constexpr int CS_BYTES = BM2 * CS_LD * 4;
+  constexpr int SMEM_BYTES = (2 * STAGE * 2 > CS_BYTES) ? 2 * STAGE * 2 : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];
+  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t tile_n = blockIdx.x % p.ntiles_n, tile_m = blockIdx.x / p.ntiles_n;
+  const int64_t m0 = tile_m * BM2, n0 = tile_n * 128;
+  const int64_t kbeg = (int64_t)blockIdx.y * p.k_chunk;
+  const int64_t kend = min(p.K, kbeg + p.k_chunk);
+  const int nk = (int)((kend - kbeg + BK2 - 1) / BK2);
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  OA oa;
+  OB ob;
+  oa.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
+  ob.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+  oa.store(smem, tid);
+  ob.store(smem + OA::LDS_ELEMS, tid);
+  if (nk > 1) {
+    oa.load(p.A, p.lda, m0, p.M, kbeg + BK2, kend, tid);
+    ob.load(p.B, p.ldb, n0, p.N, kbeg + BK2, kend, tid);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bf16* As = smem + (kt & 1) * STAGE;
+    const bf16* Bs = As + OA::LDS_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      bf16x8 a[MT], b[2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = OA::frag(As, wm * 32 * MT + i * 32, ks, lane);
+      b[0] = OB::frag(Bs, wn * 64, ks, lane);
+      b[1] = OB::frag(Bs, wn * 64 + 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) {   // tile kt+1 sits in registers: park it in the other LDS buffer, then fetch tile kt+2
+      bf16* An = smem + ((kt + 1) & 1) * STAGE;
+      oa.store(An, tid);
+      ob.store(An + OA::LDS_ELEMS, tid);
+      if (kt + 2 < nk) {
+        oa.load(p.A, p.lda, m0, p.M, kbeg + (int64_t)(kt + 2) * BK2, kend, tid);
+        ob.load(p.B, p.ldb, n0, p.N, kbeg + (int64_t)(kt + 2) * BK2, kend, tid);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue through LDS: accumulators -> Cs[BM2][132] fp32 -> 8-wide coalesced rows
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(wm * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS_LD + wn * 64 + nt * 32 + (lane & 31)] =
+            acc[mt][nt][r];
+  __syncthreads();
+  const bool first_split = (blockIdx.y == 0);
+  const int col = (tid & 15) * 8;
+  const int64_t n = n0 + col;
+  if (n >= p.N) return;
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = 0.f;
+  if (p.bias != nullptr && first_split && p.ws == nullptr) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+  }
+#pragma unroll
+  for (int i = 0; i < BM2 / 16; ++i) {
+    const int row = (tid >> 4) + 16 * i;
+    const int64_t m = m0 + row;
+    if (m >= p.M) continue;
+    float v[8];
+    {
+      const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col]);
+      const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col + 4]);
+      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+    }
+    if (p.split_k > 1 && p.ws != nullptr) {   // deterministic split-K: raw partial slab
+      st8_from_f32(p.ws, CSTS_F32, ((int64_t)blockIdx.y * p.M + m) * p.N + n, v);
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bias[j];
+    if (p.split_k > 1) {
+      float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(c + j, v[j]);
+      continue;
+    }
+    if (p.epilogue == CSTS_EPI_GELU) {
+      if (p.aux != nullptr) st8_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+    } else if (p.epilogue == CSTS_EPI_DGELU) {
+      float h[8];
+      ld8_as_f32(p.aux, p.aux_dt, m * p.ldaux + n, h);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(h[j]);
+    }
+    if (p.row_scale != nullptr) {
+      const float sc = p.row_scale[m / p.rows_per_scale];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= sc;
+    }
+    if (p.residual != nullptr) {
+      const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+      float rr[8];
+      ld8_as_f32(p.residual, p.r_dt, rm * p.ldr + n, rr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rr[j];
+    }
+    st8_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
+  }
+}
+
+template <bool A_KC, bool B_KC, bool A_F32, bool B_F32>
+void launch2(const Params& p, int mt, dim3 grid, hipStream_t s) {
+  if (mt == 2) hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 2>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 1>), grid, dim3(256), 0, s, p);
+}
+
+// v2 needs every 8-element chunk to be whole and 16-byte aligned
+bool v2_ok(const csts_gemm_args* a) {
+  if (a->compute != CSTS_BF16) return false;
+  auto al = [](const void* ptr, int dt, int64_t ld) { return aligned16(ptr) && ld % (dt == CSTS_F32 ? 4 : 8) == 0; };
+  if (!al(a->A, a->a_dt, a->lda) || !al(a->B, a->b_dt, a->ldb)) return false;
+  if (a->N % 8 != 0 || a->K % 8 != 0) return false;
+  if (a->layout == CSTS_GEMM_TN && a->M % 8 != 0) return false;
+  if (!al(a->C, a->c_dt, a->ldc)) return false;
+  if (a->aux && !al(a->aux, a->aux_dt, a->ldaux)) return false;
+  if (a->residual && !al(a->residual, a->r_dt, a->ldr)) return false;
+  if (a->bias && !aligned16(a->bias)) return false;
+  // dtype combinations instantiated below
+  if (a->layout == CSTS_GEMM_TN && a->b_dt != CSTS_BF16) return false;
+  if (a->layout != CSTS_GEMM_TN && a->b_dt != CSTS_F32) return false;
+  if (a->layout == CSTS_GEMM_NT && a->a_dt != CSTS_BF16) return false;
+  return true;
+}
+
 template <bool A_KC, bool B_KC>
 void launch(const Params& p, int compute, dim3 grid, hipStream_t s) {
   if (compute == CSTS_F32) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(NT_), 0, s, p);
@@ -286,13 +535,33 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   };
   p.a_vec = vec_ok(a->A, a->a_dt, a->lda);
   p.b_vec = vec_ok(a->B, a->b_dt, a->ldb);
-  const int64_t ktiles = cdiv(a->K, BK);
-  p.k_chunk = cdiv(ktiles, split) * BK;
+  const bool use_v2 = v2_ok(a);
+  const int bk = use_v2 ? BK2 : BK;
+  const int64_t ktiles = cdiv(a->K, bk);
+  p.k_chunk = cdiv(ktiles, split) * bk;
   const int64_t nsplit = cdiv(a->K, p.k_chunk);
   if (det) CSTS_REQUIRE(a->ws_bytes >= (size_t)nsplit * a->M * a->N * sizeof(float), "split-k workspace too small");
   p.ntiles_n = (int)cdiv(a->N, BN);
-  const int64_t mtiles = cdiv(a->M, BM);
+  int64_t mtiles = cdiv(a->M, BM);
   CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
+  if (use_v2) {
+    // 64-row tiles when the 128-row grid cannot give every CU at least two workgroups
+    const int mt = (mtiles * p.ntiles_n * nsplit >= 512) ? 2 : 1;
+    mtiles = cdiv(a->M, 64 * mt);
+    dim3 grid2((unsigned)(mtiles * p.ntiles_n), (unsigned)nsplit, 1);
+    const bool af = a->a_dt == CSTS_F32;
+    if (a->layout == CSTS_GEMM_NT) launch2<true, true, false, true>(p, mt, grid2, stream);
+    else if (a->layout == CSTS_GEMM_NN) { if (af) launch2<true, false, true, true>(p, mt, grid2, stream); else launch2<true, false, false, true>(p, mt, grid2, stream); }
+    else { if (af) launch2<false, false, true, false>(p, mt, grid2, stream); else launch2<false, false, false, false>(p, mt, grid2, stream); }
+    CSTS_LAUNCH_CHECK();
+    if (det) {
+      const int64_t total = a->M * a->N;
+      hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p,
+                         (int)nsplit);
+      CSTS_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   dim3 grid((unsigned)(mtiles * p.ntiles_n), (unsigned)nsplit, 1);
   switch (a->layout) {
     case CSTS_GEMM_NT: launch<true, true>(p, a->compute, grid, stream); break;
@@ -311,6 +580,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
 
 extern "C" size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k) {
   if (split_k <= 1) return 0;
-  const int64_t k_chunk = cdiv(cdiv(K, BK), split_k) * BK;
-  return (size_t)cdiv(K, k_chunk) * M * N * sizeof(float);
+  // upper bound over both kernels' k-chunking (v1: BK 32, v2: BK 64)
+  const int64_t c1 = cdiv(cdiv(K, BK), split_k) * BK, c2 = cdiv(cdiv(K, BK2), split_k) * BK2;
+  return (size_t)std::max(cdiv(K, c1), cdiv(K, c2)) * M * N * sizeof(float);
 }
