@@ -229,26 +229,49 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
   }
 }
 
-// C = epilogue(sum_s ws[s]) for the deterministic split-K path
+// C = epilogue(sum_s ws[s]) for the deterministic split-K path (VEC elements per thread; VEC = 4 needs N % 4 == 0)
+template <int VEC>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit) {
   const int64_t total = p.M * p.N;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = idx / p.N, n = idx - m * p.N;
-    float v = p.bias ? p.bias[n] : 0.f;
-    for (int sidx = 0; sidx < nsplit; ++sidx) v += p.ws[(int64_t)sidx * total + idx];
-    if (p.epilogue == CSTS_EPI_GELU) {
-      if (p.aux != nullptr) st_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
-      v = gelu_f(v);
-    } else if (p.epilogue == CSTS_EPI_DGELU) {
-      v *= dgelu_f(ld_as_f32(p.aux, p.aux_dt, m * p.ldaux + n));
+  for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x * VEC) {
+    const int64_t m = idx / p.N, n0 = idx - m * p.N;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = p.bias ? p.bias[n0 + j] : 0.f;
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p.ws + (int64_t)sidx * total + idx);
+        v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+      } else {
+        v[0] += p.ws[(int64_t)sidx * total + idx];
+      }
     }
-    if (p.row_scale != nullptr) v *= p.row_scale[m / p.rows_per_scale];
-    if (p.residual != nullptr) {
-      const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-      v += ld_as_f32(p.residual, p.r_dt, rm * p.ldr + n);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int64_t n = n0 + j;
+      float x = v[j];
+      if (p.epilogue == CSTS_EPI_GELU) {
+        if (p.aux != nullptr) st_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, x);
+        x = gelu_f(x);
+      } else if (p.epilogue == CSTS_EPI_DGELU) {
+        x *= dgelu_f(ld_as_f32(p.aux, p.aux_dt, m * p.ldaux + n));
+      }
+      if (p.row_scale != nullptr) x *= p.row_scale[m / p.rows_per_scale];
+      if (p.residual != nullptr) {
+        const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+        x += ld_as_f32(p.residual, p.r_dt, rm * p.ldr + n);
+      }
+      st_from_f32(p.C, p.c_dt, m * p.ldc + n, x);
     }
-    st_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
   }
+}
+static void launch_finish(const Params& p, int nsplit, hipStream_t stream) {
+  const int64_t total = p.M * p.N;
+  if (p.N % 4 == 0 && aligned16(p.ws))
+    hipLaunchKernelGGL(splitk_finish_kernel<4>, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 4096)), dim3(256), 0, stream, p, nsplit);
+  else
+    hipLaunchKernelGGL(splitk_finish_kernel<1>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p, nsplit);
 }
 
 // =====================================================================================================
@@ -555,9 +578,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
     else { if (af) launch2<false, false, true, false>(p, mt, grid2, stream); else launch2<false, false, false, false>(p, mt, grid2, stream); }
     CSTS_LAUNCH_CHECK();
     if (det) {
-      const int64_t total = a->M * a->N;
-      hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p,
-                         (int)nsplit);
+      launch_finish(p, (int)nsplit, stream);
       CSTS_LAUNCH_CHECK();
     }
     return 0;
@@ -570,9 +591,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   }
   CSTS_LAUNCH_CHECK();
   if (det) {
-    const int64_t total = a->M * a->N;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p,
-                       (int)nsplit);
+    launch_finish(p, (int)nsplit, stream);
     CSTS_LAUNCH_CHECK();
   }
   return 0;

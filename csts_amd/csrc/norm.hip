@@ -156,7 +156,7 @@ extern "C" int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, c
 }
 
 extern "C" size_t csts_layernorm_bwd_workspace(int64_t rows, int C) {
-  const int64_t nb = std::min<int64_t>(cdiv(rows, 4 * 8), 1024);
+  const int64_t nb = std::min<int64_t>(cdiv(rows, 4 * 2), 2048);
   return (size_t)nb * 2 * C * sizeof(float);
 }
 
@@ -167,7 +167,7 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "null pointer");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
   CSTS_REQUIRE(dbeta == dgamma + C, "dgamma/dbeta must be one contiguous [2*C] buffer");
-  const int64_t nb = std::min<int64_t>(cdiv(rows, 4 * 8), 1024);
+  const int64_t nb = std::min<int64_t>(cdiv(rows, 4 * 2), 2048);
   CSTS_REQUIRE(ws_bytes >= (size_t)nb * 2 * C * sizeof(float), "workspace too small");
   dim3 grid((unsigned)nb), block(256);
   const size_t sh = (size_t)4 * 2 * C * sizeof(float);

@@ -143,24 +143,27 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(Geom g, const vo
   }
 }
 
-// partial dW: block (slab of blockDim.x channels, chunk of coarse tokens) -> ws[part][HD*27]
+// partial dW: block = (slab of blockDim.x channels) x (blockDim.y token lanes), chunk of coarse tokens -> ws[part][HD*27]
+// token lanes and heads of a slab are folded in LDS in a fixed order (bitwise reproducible).
 __global__ void dwconv_wgrad_kernel(Geom g, const void* __restrict__ fine, int f_dt, const void* __restrict__ coarse,
                                     int c_dt, float* __restrict__ ws, int64_t chunk) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.x][27] when heads share a slab
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.x][27]
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c = blockIdx.x * blockDim.x + tx;
   const int64_t ntok = (int64_t)g.Tc * g.Hc * g.Wc;
   const int64_t total = (int64_t)g.B * ntok;
   const int64_t beg = (int64_t)blockIdx.y * chunk, end = min(total, beg + chunk);
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (int64_t bt = beg; bt < end; ++bt) {
+  for (int64_t bt = beg + ty; bt < end; bt += blockDim.y) {
     const int b = (int)(bt / ntok);
     int o = (int)(bt - (int64_t)b * ntok);
     const float cv = ld_as_f32(coarse, c_dt, b * g.c_bs + (int64_t)o * g.c_ts + c);
     const int ow = o % g.Wc; o /= g.Wc;
     const int oh = o % g.Hc;
     const int ot = o / g.Hc;
+    const int64_t fb = b * g.f_bs + c;
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
       const int t = ot * g.st - 1 + kt;
@@ -171,28 +174,31 @@ __global__ void dwconv_wgrad_kernel(Geom g, const void* __restrict__ fine, int f
         for (int kw = 0; kw < 3; ++kw) {
           const int x = ow * g.sw - 1 + kw;
           const bool ok = t >= 0 && t < g.Tf && h >= 0 && h < g.Hf && x >= 0 && x < g.Wf;
-          const float fv = ok ? ld_as_f32(fine, f_dt, b * g.f_bs + ((int64_t)(t * g.Hf + h) * g.Wf + x) * g.f_ts + c) : 0.f;
+          const float fv = ok ? ld_as_f32(fine, f_dt, fb + ((int64_t)(t * g.Hf + h) * g.Wf + x) * g.f_ts) : 0.f;
           acc[kt * 9 + kh * 3 + kw] += fv * cv;
         }
       }
     }
   }
-  const int heads_in_slab = blockDim.x / g.HD;  // 1 or 2
-  float* out = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * g.HD * 27;
-  if (heads_in_slab == 1) {
+  // fold token lanes (fixed order), then heads
+  for (int l = 0; l < (int)blockDim.y; ++l) {
+    if (ty == l) {
 #pragma unroll
-    for (int k = 0; k < 27; ++k) out[threadIdx.x * 27 + k] = acc[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) red[threadIdx.x * 27 + k] = acc[k];
-    __syncthreads();
-    if (threadIdx.x < g.HD) {
       for (int k = 0; k < 27; ++k) {
-        float s = 0.f;
-        for (int hh = 0; hh < heads_in_slab; ++hh) s += red[(threadIdx.x + hh * g.HD) * 27 + k];
-        out[threadIdx.x * 27 + k] = s;
+        if (l == 0) red[tx * 27 + k] = acc[k];
+        else red[tx * 27 + k] += acc[k];
       }
     }
+    __syncthreads();
+  }
+  const int heads_in_slab = blockDim.x / g.HD;
+  float* out = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * g.HD * 27;
+  const int tid = ty * blockDim.x + tx, nthr = blockDim.x * blockDim.y;
+  for (int i = tid; i < g.HD * 27; i += nthr) {
+    const int cc = i / 27, k = i - cc * 27;
+    float s2 = 0.f;
+    for (int hh = 0; hh < heads_in_slab; ++hh) s2 += red[(cc + hh * g.HD) * 27 + k];
+    out[i] = s2;
   }
 }
 
@@ -409,7 +415,7 @@ static void wgrad_plan(const csts_dwconv_geom* a, int& slab, int& nslab, int64_t
   slab = a->HD * k;
   nslab = a->C / slab;
   const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc;
-  nchunk = std::max<int64_t>(1, std::min<int64_t>(1024 / nslab, cdiv(total, 8)));
+  nchunk = std::max<int64_t>(1, std::min<int64_t>(2048 / nslab, cdiv(total, 16)));
   chunk = cdiv(total, nchunk);
   nchunk = cdiv(total, chunk);
 }
@@ -431,7 +437,8 @@ extern "C" int csts_dwconv_wgrad(const csts_dwconv_geom* a, const void* fine, in
   CSTS_REQUIRE(ws_bytes >= (size_t)nchunk * nslab * a->HD * 27 * sizeof(float), "workspace too small");
   Geom g; fill_geom(a, g);
   float* ws = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nslab, (unsigned)nchunk), dim3(slab), (size_t)slab * 27 * 4, stream, g,
+  const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(4, chunk / 4));   // token lanes per channel
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nslab, (unsigned)nchunk), dim3(slab, lanes), (size_t)slab * 27 * 4, stream, g,
                      fine, fine_dt, coarse, coarse_dt, ws, chunk);
   CSTS_LAUNCH_CHECK();
 

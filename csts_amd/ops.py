@@ -101,7 +101,7 @@ SPLITK_WS_LIMIT = 256 << 20   # deterministic split-K slabs up to this size, ato
 
 def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
     tiles = math.ceil(M_out / 128) * math.ceil(N_out / 128)
-    return max(1, min(1024 // max(tiles, 1), math.ceil(Kred / 256)))
+    return max(1, min(512 // max(tiles, 1), math.ceil(Kred / 512)))
 
 
 def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int) -> torch.Tensor:
