@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph (single GPU only)")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
     return p.parse_args()
 
@@ -137,11 +138,18 @@ def main():
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg)
     model.train()
-    opt = T.construct_optimizer(model, cfg)
+    use_graph = world == 1 and not args.no_graph
+    opt = T.construct_optimizer(model, cfg, capturable=use_graph)
     batch = T.synthetic_batch(b, args.frames, 256, 1000 + rank, dev)      # resident in HBM before timing
     lr = T.get_lr_at_epoch(cfg, 0.0)
+    graphed = T.GraphedTrainStep(cfg, model, opt, batch) if use_graph else None
 
     def step():
+        if graphed is not None:
+            return graphed.run(batch, lr)
+        return T.train_step(cfg, model, batch, opt, lr)
+
+    def eager_step():
         return T.train_step(cfg, model, batch, opt, lr)
 
     def sync():
@@ -171,7 +179,7 @@ def main():
         gt = GemmTimer()
         gt.install()
         for _ in range(2):
-            step()
+            eager_step()
         gt.remove()
         agg = gt.summary()
         if args.dump_gemm:
@@ -201,7 +209,7 @@ def main():
             "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml train step (fwd + KLDiv + 0.05*EgoNCE + bwd"
                                    f"{' + RCCL grad all-reduce' if world > 1 else ''} + clip + AdamW), "
                                    f"{args.frames}x256^2 video + 24 kHz STFT audio, b={b}/GPU",
-                       "global_batch": b * world, "frames": args.frames, "crop": 256, "parallelism": f"dp{world}",
+                       "global_batch": b * world, "frames": args.frames, "crop": 256, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "note": "256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)"},
             "loss": round(float(loss), 5),
             "end_to_end_roofline": {"mfma_frac": round(per_gpu * train_gflop / 1e3 / PEAK_BF16_TFLOPS, 4),

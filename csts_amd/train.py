@@ -35,10 +35,13 @@ def get_lr_at_epoch(cfg, cur_epoch: float) -> float:
 
 def set_lr(optimizer, new_lr: float):
     for g in optimizer.param_groups:
-        g["lr"] = new_lr
+        if isinstance(g["lr"], torch.Tensor):
+            g["lr"].fill_(new_lr)        # device-resident lr (graph-capturable optimizer)
+        else:
+            g["lr"] = new_lr
 
 
-def construct_optimizer(model, cfg):
+def construct_optimizer(model, cfg, capturable: bool = False):
     """AdamW(eps 1e-8) with zero weight decay on 1-D parameters and biases
     (slowfast/models/optimizer.py:11-108 for OPTIMIZING_METHOD adamw, ZERO_WD_1D_PARAM)."""
     assert cfg.SOLVER.OPTIMIZING_METHOD == "adamw", "the CSTS YAMLs train with adamw"
@@ -57,6 +60,11 @@ def construct_optimizer(model, cfg):
     groups = [g for g in ({"params": decay, "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
                           {"params": no_decay, "weight_decay": 0.0}) if g["params"]]
     fused = all(p.is_cuda for g in groups for p in g["params"])     # one multi-tensor kernel per group on the GPU
+    kw = {}
+    if fused and capturable:      # lr lives in a device tensor so that a captured step can follow the schedule
+        kw = {"capturable": True}
+        lr0 = torch.tensor(float(cfg.SOLVER.BASE_LR), dtype=torch.float32, device=groups[0]["params"][0].device)
+        return torch.optim.AdamW(groups, lr=lr0, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY, fused=True, **kw)
     return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY, fused=fused)
 
 
@@ -125,3 +133,49 @@ def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device) -> Di
     hm = k / k.sum(dim=(-1, -2), keepdim=True)
     labels = torch.stack([cx / 63, cy / 63, torch.zeros_like(cx)], dim=-1).double()
     return {"video": video, "audio": audio, "labels_hm": hm, "labels": labels}
+
+
+class GraphedTrainStep:
+    """The whole training iteration (forward + loss + backward + clip + AdamW) captured ONCE into a HIP graph and
+    replayed: ~2000 kernel launches per step become one graph launch, so the step is bounded by the kernels, not by
+    Python/ctypes dispatch.  Single-process only (the RCCL bucket all-reduce path stays eager).  Inputs are copied
+    into static buffers; the learning rate lives in a device tensor (set_lr) so the schedule still applies.
+    Drop-path masks are drawn by torch's graph-safe Philox generator on every replay."""
+
+    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2):
+        assert not isinstance(model, GradAllReduce), "graph capture is single-GPU; multi-GPU runs eagerly"
+        self.cfg, self.model, self.opt = cfg, model, optimizer
+        self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._step()
+        torch.cuda.synchronize()
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss, kld, nce, _ = compute_loss(self.cfg, self.model, self.static["video"], self.static["audio"],
+                                         self.static["labels_hm"])
+        loss.backward()
+        if self.cfg.SOLVER.CLIP_GRAD_VAL:
+            torch.nn.utils.clip_grad_value_(self.model.parameters(), self.cfg.SOLVER.CLIP_GRAD_VAL)
+        elif self.cfg.SOLVER.CLIP_GRAD_L2NORM:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg.SOLVER.CLIP_GRAD_L2NORM)
+        self.opt.step()
+        return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
+
+    def run(self, batch=None, lr: Optional[float] = None):
+        if batch is not None:
+            for k in self.static:
+                if batch[k] is not self.static[k]:
+                    self.static[k].copy_(batch[k], non_blocking=True)
+        if lr is not None:
+            set_lr(self.opt, lr)
+        self.graph.replay()
+        return self.out
