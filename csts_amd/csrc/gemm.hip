@@ -28,6 +28,7 @@ template <> struct Cmp<true> { typedef float T; };
 struct Params {
   const void* A; const void* B; void* C;
   const float* bias; void* aux; const void* residual; const float* row_scale; float* ws;
+  float* colsum; float* colsum_ws;   // TN only: colsum[m] = sum_k A[k][m] (bias gradient), fused into the v2 kernel
   int64_t lda, ldb, ldc, ldaux, ldr;
   int64_t M, N, K, res_row_mod, rows_per_scale, k_chunk;
   int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
@@ -266,7 +267,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit
     }
   }
 }
+__global__ void colsum_finish_kernel(Params p, int nsplit) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.M) return;
+  float t = 0.f;
+  for (int sidx = 0; sidx < nsplit; ++sidx) t += p.colsum_ws[(int64_t)sidx * p.M + m];
+  p.colsum[m] = t;
+}
 static void launch_finish(const Params& p, int nsplit, hipStream_t stream) {
+  if (p.colsum != nullptr && p.colsum_ws != nullptr)
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(p.M, 256)), dim3(256), 0, stream, p, nsplit);
   const int64_t total = p.M * p.N;
   if (p.N % 4 == 0 && aligned16(p.ws))
     hipLaunchKernelGGL(splitk_finish_kernel<4>, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 4096)), dim3(256), 0, stream, p, nsplit);
@@ -400,9 +410,23 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
   }
   __syncthreads();
 
+  // fused bias gradient (TN only): threads own a column pair of the A tile and a slice of its 64 k-rows
+  constexpr int CPAIRS = BM2 / 2, TPP = 256 / CPAIRS, KSL = BK2 / TPP;
+  const bool do_colsum = !A_KC && p.colsum != nullptr && tile_n == 0;
+  float cs0 = 0.f, cs1 = 0.f;
+
   for (int kt = 0; kt < nk; ++kt) {
     const bf16* As = smem + (kt & 1) * STAGE;
     const bf16* Bs = As + OA::LDS_ELEMS;
+    if (!A_KC && do_colsum) {
+      const int cp = tid % CPAIRS, k0s = (tid / CPAIRS) * KSL;
+#pragma unroll
+      for (int kk = 0; kk < KSL; ++kk) {
+        const bf16x2 t = *reinterpret_cast<const bf16x2*>(&As[(k0s + kk) * OA::OC_LD + 2 * cp]);
+        cs0 += (float)t[0];
+        cs1 += (float)t[1];
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < BK2 / 16; ++ks) {
       bf16x8 a[MT], b[2];
@@ -428,6 +452,21 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
     __syncthreads();
   }
 
+  if (!A_KC && do_colsum) {   // fold the k-slices of every column pair (fixed order) and emit this block's partial sums
+    float* red = reinterpret_cast<float*>(smem_raw);           // [TPP][BM2]
+    const int cp = tid % CPAIRS, sl = tid / CPAIRS;
+    red[sl * BM2 + 2 * cp] = cs0;
+    red[sl * BM2 + 2 * cp + 1] = cs1;
+    __syncthreads();
+    if (tid < BM2 && m0 + tid < p.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < TPP; ++q) t += red[q * BM2 + tid];
+      if (p.split_k > 1) p.colsum_ws[(int64_t)blockIdx.y * p.M + m0 + tid] = t;
+      else p.colsum[m0 + tid] = t;
+    }
+    __syncthreads();
+  }
   // ---------------- epilogue through LDS: accumulators -> Cs[BM2][132] fp32 -> 8-wide coalesced rows
   float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
@@ -548,6 +587,8 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.residual = a->residual;
   p.row_scale = a->row_scale;
   p.ws = det ? reinterpret_cast<float*>(a->workspace) : nullptr;
+  p.colsum = a->colsum;
+  p.colsum_ws = nullptr;
   p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldaux = a->ldaux; p.ldr = a->ldr;
   p.M = a->M; p.N = a->N; p.K = a->K; p.res_row_mod = a->res_row_mod;
   p.rows_per_scale = a->rows_per_scale > 0 ? a->rows_per_scale : 1;
@@ -564,6 +605,14 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   p.k_chunk = cdiv(ktiles, split) * bk;
   const int64_t nsplit = cdiv(a->K, p.k_chunk);
   if (det) CSTS_REQUIRE(a->ws_bytes >= (size_t)nsplit * a->M * a->N * sizeof(float), "split-k workspace too small");
+  if (a->colsum != nullptr) {
+    CSTS_REQUIRE(use_v2 && a->layout == CSTS_GEMM_TN, "fused colsum needs the TN bf16 v2 kernel (see csts_gemm_v2_eligible)");
+    CSTS_REQUIRE(split == 1 || det, "fused colsum with split-k needs the deterministic workspace");
+    if (split > 1) {
+      CSTS_REQUIRE(a->ws_bytes >= (size_t)nsplit * a->M * (a->N + 1) * sizeof(float), "workspace too small for colsum partials");
+      p.colsum_ws = p.ws + nsplit * a->M * a->N;
+    }
+  }
   p.ntiles_n = (int)cdiv(a->N, BN);
   int64_t mtiles = cdiv(a->M, BM);
   CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
@@ -597,9 +646,11 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   return 0;
 }
 
+extern "C" int csts_gemm_v2_eligible(const csts_gemm_args* a) { return a != nullptr && v2_ok(a) ? 1 : 0; }
+
 extern "C" size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k) {
   if (split_k <= 1) return 0;
   // upper bound over both kernels' k-chunking (v1: BK 32, v2: BK 64)
   const int64_t c1 = cdiv(cdiv(K, BK), split_k) * BK, c2 = cdiv(cdiv(K, BK2), split_k) * BK2;
-  return (size_t)std::max(cdiv(K, c1), cdiv(K, c2)) * M * N * sizeof(float);
+  return (size_t)std::max(cdiv(K, c1), cdiv(K, c2)) * M * (N + 1) * sizeof(float);   // + colsum partials
 }

@@ -238,16 +238,19 @@ __global__ __launch_bounds__(256) void reweight_dw_kernel(const float* __restric
   for (int i = 0; i < HW; ++i) { const int64_t o = (bt * HW + i) * C + c; s += x[o] * dy[o]; }
   dw[idx] = s;
 }
-// out[b,c] = mean_n x[b,n,c]   ;  bwd: dx[b,n,c] = dout[b,c] / N
+// out[b,c] = mean_n x[b,n,c]   ;  bwd: dx[b,n,c] = dout[b,c] / N      (block = 64 channels x 4 token lanes)
 __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t nbc,
                                                          int N, int C) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nbc) return;
-  const int c = (int)(idx % C);
-  const int64_t b = idx / C;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int64_t b = blockIdx.y;
   float s = 0.f;
-  for (int n = 0; n < N; ++n) s += x[(b * N + n) * C + c];
-  out[idx] = s / N;
+  if (c < C)
+    for (int n = ty; n < N; n += 4) s += x[(b * N + n) * C + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) out[b * C + c] = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / N;
 }
 __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
                                                              int64_t total, int N, int C) {
@@ -435,7 +438,7 @@ extern "C" int csts_reweight_bwd(const float* x, const float* w, const float* dy
 }
 extern "C" int csts_token_mean_fwd(const float* x, float* out, int64_t B, int N, int C, hipStream_t stream) {
   CSTS_REQUIRE(x && out && B > 0 && N > 0 && C > 0, "bad args");
-  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)cdiv(B * C, 256)), dim3(256), 0, stream, x, out, B * C, N, C);
+  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)B), dim3(256), 0, stream, x, out, B * C, N, C);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

@@ -211,18 +211,19 @@ struct PoolGeom {
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolGeom g, const void* __restrict__ x, int dt,
                                                           void* __restrict__ y, uint8_t* __restrict__ arg) {
+  const int CQ = g.C / VEC;
   const int64_t ntok = (int64_t)g.To * g.Ho * g.Wo;
-  const int64_t total = (int64_t)g.B * ntok * g.C;
+  const int64_t total = (int64_t)g.B * ntok * CQ;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % g.C);
-    const int64_t bt = idx / g.C;
+    const int c = (int)(idx % CQ) * VEC;
+    const int64_t bt = idx / CQ;
     const int b = (int)(bt / ntok);
     int o = (int)(bt - (int64_t)b * ntok);
     const int ow = o % g.Wo; o /= g.Wo;
     const int oh = o % g.Ho;
     const int ot = o / g.Ho;
-    float best = -INFINITY;
-    int bi = 0;
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
     bool first = true;
     for (int a = 0; a < g.kt; ++a) {
       const int t = ot * g.st - g.pt + a;
@@ -233,32 +234,36 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolGeom g, const void
         for (int f = 0; f < g.kw; ++f) {
           const int w = ow * g.sw - g.pw + f;
           if (w < 0 || w >= g.Wi) continue;
-          const float v = ld_as_f32(x, dt, ((int64_t)b * g.Ti * g.Hi * g.Wi + (int64_t)(t * g.Hi + h) * g.Wi + w) * g.C + c);
-          if (first || v > best || v != v) {  // first max wins; NaN propagates (torch max_pool3d semantics)
-            best = v; bi = (a * g.kh + e) * g.kw + f; first = false;
-          }
+          float v[4];
+          ld4(x, dt, ((int64_t)b * g.Ti * g.Hi * g.Wi + (int64_t)(t * g.Hi + h) * g.Wi + w) * g.C + c, v);
+          const int tap = (a * g.kh + e) * g.kw + f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (first || v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = tap; }  // first max wins; NaN propagates
+          first = false;
         }
       }
     }
-    st_from_f32(y, dt, idx, best);
-    if (arg) arg[idx] = (uint8_t)bi;
+    st4(y, dt, bt * g.C + c, best);
+    if (arg) *reinterpret_cast<uchar4*>(arg + bt * g.C + c) = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
   }
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolGeom g, const void* __restrict__ dy, int dt,
                                                           const uint8_t* __restrict__ arg, void* __restrict__ dx) {
+  const int CQ = g.C / VEC;
   const int64_t ntok = (int64_t)g.Ti * g.Hi * g.Wi;
   const int64_t ntoko = (int64_t)g.To * g.Ho * g.Wo;
-  const int64_t total = (int64_t)g.B * ntok * g.C;
+  const int64_t total = (int64_t)g.B * ntok * CQ;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % g.C);
-    const int64_t bt = idx / g.C;
+    const int c = (int)(idx % CQ) * VEC;
+    const int64_t bt = idx / CQ;
     const int b = (int)(bt / ntok);
     int i = (int)(bt - (int64_t)b * ntok);
     const int w = i % g.Wi; i /= g.Wi;
     const int h = i % g.Hi;
     const int t = i / g.Hi;
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int a = 0; a < g.kt; ++a) {
       const int nt = t + g.pt - a;
       if (nt < 0 || nt % g.st != 0 || nt / g.st >= g.To) continue;
@@ -269,11 +274,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolGeom g, const void
           const int nw = w + g.pw - f;
           if (nw < 0 || nw % g.sw != 0 || nw / g.sw >= g.Wo) continue;
           const int64_t o = ((int64_t)b * ntoko + (int64_t)((nt / g.st) * g.Ho + nh / g.sh) * g.Wo + nw / g.sw) * g.C + c;
-          if (arg[o] == (uint8_t)((a * g.kh + e) * g.kw + f)) s += ld_as_f32(dy, dt, o);
+          const uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
+          const uint8_t tap = (uint8_t)((a * g.kh + e) * g.kw + f);
+          float v[4];
+          ld4(dy, dt, o, v);
+          if (am.x == tap) s[0] += v[0];
+          if (am.y == tap) s[1] += v[1];
+          if (am.z == tap) s[2] += v[2];
+          if (am.w == tap) s[3] += v[3];
         }
       }
     }
-    st_from_f32(dx, dt, idx, s);
+    st4(dx, dt, bt * g.C + c, s);
   }
 }
 
@@ -296,27 +308,46 @@ __device__ __forceinline__ void src_index(int o, int in, int out, int& i0, int& 
 __global__ __launch_bounds__(256) void trilinear_fwd_kernel(UpGeom g, const void* __restrict__ x, int x_dt,
                                                             const void* __restrict__ addend, int a_dt,
                                                             void* __restrict__ y, int y_dt) {
+  const int CQ = g.C / VEC;
   const int64_t ntok = (int64_t)g.To * g.Ho * g.Wo, ntoki = (int64_t)g.Ti * g.Hi * g.Wi;
-  const int64_t total = (int64_t)g.B * ntok * g.C;
+  const int64_t total = (int64_t)g.B * ntok * CQ;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % g.C);
-    const int64_t bt = idx / g.C;
+    const int c = (int)(idx % CQ) * VEC;
+    const int64_t bt = idx / CQ;
     const int b = (int)(bt / ntok);
     int o = (int)(bt - (int64_t)b * ntok);
     const int ow = o % g.Wo; o /= g.Wo;
     const int oh = o % g.Ho;
     const int ot = o / g.Ho;
-    int t0, t1, h0, h1, w0, w1;
-    float a0, a1, b0, b1, c0, c1;
-    src_index(ot, g.Ti, g.To, t0, t1, a0, a1);
-    src_index(oh, g.Hi, g.Ho, h0, h1, b0, b1);
-    src_index(ow, g.Wi, g.Wo, w0, w1, c0, c1);
+    int ti[2], hi[2], wi[2];
+    float tl[2], hl[2], wl[2];
+    src_index(ot, g.Ti, g.To, ti[0], ti[1], tl[0], tl[1]);
+    src_index(oh, g.Hi, g.Ho, hi[0], hi[1], hl[0], hl[1]);
+    src_index(ow, g.Wi, g.Wo, wi[0], wi[1], wl[0], wl[1]);
     const int64_t base = (int64_t)b * ntoki;
-    auto at = [&](int t, int h, int w) { return ld_as_f32(x, x_dt, (base + (int64_t)(t * g.Hi + h) * g.Wi + w) * g.C + c); };
-    float v = a0 * (b0 * (c0 * at(t0, h0, w0) + c1 * at(t0, h0, w1)) + b1 * (c0 * at(t0, h1, w0) + c1 * at(t0, h1, w1))) +
-              a1 * (b0 * (c0 * at(t1, h0, w0) + c1 * at(t1, h0, w1)) + b1 * (c0 * at(t1, h1, w0) + c1 * at(t1, h1, w1)));
-    if (addend) v += ld_as_f32(addend, a_dt, idx);
-    st_from_f32(y, y_dt, idx, v);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      if (tl[a] == 0.f) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (hl[e] == 0.f) continue;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (wl[f] == 0.f) continue;
+          const float wgt = tl[a] * hl[e] * wl[f];
+          float v[4];
+          ld4(x, x_dt, (base + (int64_t)(ti[a] * g.Hi + hi[e]) * g.Wi + wi[f]) * g.C + c, v);
+          acc[0] += wgt * v[0]; acc[1] += wgt * v[1]; acc[2] += wgt * v[2]; acc[3] += wgt * v[3];
+        }
+      }
+    }
+    if (addend) {
+      float v[4];
+      ld4(addend, a_dt, bt * g.C + c, v);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    st4(y, y_dt, bt * g.C + c, acc);
   }
 }
 
@@ -329,18 +360,19 @@ __device__ __forceinline__ float adj_w(int o, int i, int in, int out) {
 
 __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void* __restrict__ dy, int dy_dt,
                                                             void* __restrict__ dx, int dx_dt) {
+  const int CQ = g.C / VEC;
   const int64_t ntok = (int64_t)g.Ti * g.Hi * g.Wi, ntoko = (int64_t)g.To * g.Ho * g.Wo;
-  const int64_t total = (int64_t)g.B * ntok * g.C;
+  const int64_t total = (int64_t)g.B * ntok * CQ;
   const int rt = g.To / g.Ti, rh = g.Ho / g.Hi, rw = g.Wo / g.Wi;  // integer up-factors
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % g.C);
-    const int64_t bt = idx / g.C;
+    const int c = (int)(idx % CQ) * VEC;
+    const int64_t bt = idx / CQ;
     const int b = (int)(bt / ntok);
     int i = (int)(bt - (int64_t)b * ntok);
     const int w = i % g.Wi; i /= g.Wi;
     const int h = i % g.Hi;
     const int t = i / g.Hi;
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (int ot = max(0, rt * t - rt); ot <= min(g.To - 1, rt * t + 2 * rt - 1); ++ot) {
       const float wt = adj_w(ot, t, g.Ti, g.To);
       if (wt == 0.f) continue;
@@ -350,11 +382,14 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void
         for (int ow = max(0, rw * w - rw); ow <= min(g.Wo - 1, rw * w + 2 * rw - 1); ++ow) {
           const float ww = adj_w(ow, w, g.Wi, g.Wo);
           if (ww == 0.f) continue;
-          s += wt * wh * ww * ld_as_f32(dy, dy_dt, ((int64_t)b * ntoko + (int64_t)(ot * g.Ho + oh) * g.Wo + ow) * g.C + c);
+          const float wgt = wt * wh * ww;
+          float v[4];
+          ld4(dy, dy_dt, ((int64_t)b * ntoko + (int64_t)(ot * g.Ho + oh) * g.Wo + ow) * g.C + c, v);
+          s[0] += wgt * v[0]; s[1] += wgt * v[1]; s[2] += wgt * v[2]; s[3] += wgt * v[3];
         }
       }
     }
-    st_from_f32(dx, dx_dt, idx, s);
+    st4(dx, dx_dt, bt * g.C + c, s);
   }
 }
 
@@ -461,10 +496,10 @@ static int fill_pool(const csts_pool_geom* a, PoolGeom& g) {
 extern "C" int csts_maxpool_fwd(const csts_pool_geom* a, const void* x, int dt, void* y, uint8_t* argmax,
                                 hipStream_t stream) {
   CSTS_REQUIRE(a && x && y, "null pointer");
-  CSTS_REQUIRE(a->B > 0 && a->C > 0 && a->st >= 1 && a->sh >= 1 && a->sw >= 1, "bad geometry");
+  CSTS_REQUIRE(a->B > 0 && a->C > 0 && a->C % 4 == 0 && a->st >= 1 && a->sh >= 1 && a->sw >= 1, "bad geometry (C % 4)");
   PoolGeom g; fill_pool(a, g);
   CSTS_REQUIRE(g.To == a->To && g.Ho == a->Ho && g.Wo == a->Wo, "output grid mismatch");
-  const int64_t total = (int64_t)g.B * g.To * g.Ho * g.Wo * g.C;
+  const int64_t total = (int64_t)g.B * g.To * g.Ho * g.Wo * (g.C / VEC);
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, x, dt, y, argmax);
   CSTS_LAUNCH_CHECK();
   return 0;
@@ -475,7 +510,7 @@ extern "C" int csts_maxpool_bwd(const csts_pool_geom* a, const void* dy, int dt,
   CSTS_REQUIRE(a && dy && argmax && dx, "null pointer");
   PoolGeom g; fill_pool(a, g);
   CSTS_REQUIRE(g.To == a->To && g.Ho == a->Ho && g.Wo == a->Wo, "output grid mismatch");
-  const int64_t total = (int64_t)g.B * g.Ti * g.Hi * g.Wi * g.C;
+  const int64_t total = (int64_t)g.B * g.Ti * g.Hi * g.Wi * (g.C / VEC);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, dy, dt, argmax, dx);
   CSTS_LAUNCH_CHECK();
   return 0;
@@ -484,9 +519,10 @@ extern "C" int csts_maxpool_bwd(const csts_pool_geom* a, const void* dy, int dt,
 extern "C" int csts_trilinear_fwd(const csts_pool_geom* a, const void* x, int x_dt, const void* addend, int addend_dt,
                                   void* y, int y_dt, hipStream_t stream) {
   CSTS_REQUIRE(a && x && y, "null pointer");
+  CSTS_REQUIRE(a->C % 4 == 0, "C % 4");
   CSTS_REQUIRE(a->To == a->Ti * a->st && a->Ho == a->Hi * a->sh && a->Wo == a->Wi * a->sw, "output grid must be input*scale");
   UpGeom g{a->B, a->C, a->Ti, a->Hi, a->Wi, a->To, a->Ho, a->Wo};
-  const int64_t total = (int64_t)g.B * g.To * g.Ho * g.Wo * g.C;
+  const int64_t total = (int64_t)g.B * g.To * g.Ho * g.Wo * (g.C / VEC);
   hipLaunchKernelGGL(trilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, x, x_dt, addend, addend_dt, y, y_dt);
   CSTS_LAUNCH_CHECK();
   return 0;
@@ -497,7 +533,7 @@ extern "C" int csts_trilinear_bwd(const csts_pool_geom* a, const void* dy, int d
   CSTS_REQUIRE(a && dy && dx, "null pointer");
   CSTS_REQUIRE(a->To == a->Ti * a->st && a->Ho == a->Hi * a->sh && a->Wo == a->Wi * a->sw, "output grid must be input*scale");
   UpGeom g{a->B, a->C, a->Ti, a->Hi, a->Wi, a->To, a->Ho, a->Wo};
-  const int64_t total = (int64_t)g.B * g.Ti * g.Hi * g.Wi * g.C;
+  const int64_t total = (int64_t)g.B * g.Ti * g.Hi * g.Wi * (g.C / VEC);
   hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, dy, dy_dt, dx, dx_dt);
   CSTS_LAUNCH_CHECK();
   return 0;

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("residual", vp), ("r_dt", C.c_int), ("ldr", i64), ("res_row_mod", i64),
                 ("row_scale", vp), ("rows_per_scale", i64),
                 ("compute", C.c_int), ("split_k", C.c_int),
-                ("workspace", vp), ("ws_bytes", sz)]
+                ("workspace", vp), ("ws_bytes", sz), ("colsum", vp)]
 
 
 class DwconvGeom(C.Structure):
@@ -75,6 +75,7 @@ SYMBOLS = {
     "csts_abi_version": (_I, []),
     "csts_gemm": (_I, [C.POINTER(GemmArgs), vp]),
     "csts_gemm_splitk_workspace": (sz, [i64, i64, i64, _I]),
+    "csts_gemm_v2_eligible": (_I, [C.POINTER(GemmArgs)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),

@@ -57,7 +57,8 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------------- raw wrappers
 def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
-         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True):
+         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True,
+         want_colsum=False):
     a = L.GemmArgs()
     a.layout = layout
     a.A, a.a_dt, a.lda = _p(A, a_off), _dt(A), lda
@@ -77,7 +78,12 @@ def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bia
         if nb <= SPLITK_WS_LIMIT:
             ws = _ws(nb, Cm.device)
             a.workspace, a.ws_bytes = _p(ws), ws.numel()
+    fused = None
+    if want_colsum and (split_k == 1 or ws is not None) and _lib().csts_gemm_v2_eligible(C.byref(a)):
+        fused = torch.empty(M, dtype=torch.float32, device=Cm.device)
+        a.colsum = _p(fused)
     L.check(_lib().csts_gemm(C.byref(a), _stream()), "csts_gemm")
+    return fused
 
 
 def colsum(X: torch.Tensor, batch: int, M: int, N: int, row_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -104,12 +110,16 @@ def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
     return max(1, min(512 // max(tiles, 1), math.ceil(Kred / 512)))
 
 
-def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int) -> torch.Tensor:
-    """dW[N,K] = dY[M,N]^T X[M,K] (fp32, split over M with fp32 atomics)."""
+def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int, want_bias: bool = False):
+    """dW[N,K] = dY[M,N]^T X[M,K] (fp32, split over M); with want_bias also db[N] = colsum(dY), fused into the same
+    kernel when the bf16 v2 GEMM applies."""
     split = _wgrad_split(N, K, M)
     det = split > 1 and _lib().csts_gemm_splitk_workspace(N, K, M, split) <= SPLITK_WS_LIMIT
     dW = (torch.zeros if (split > 1 and not det) else torch.empty)(N, K, dtype=torch.float32, device=dY.device)
-    gemm(L.GEMM_TN, dY, 0, N, X, 0, K, dW, K, N, K, M, compute=compute, split_k=split, deterministic=det)
+    db = gemm(L.GEMM_TN, dY, 0, N, X, 0, K, dW, K, N, K, M, compute=compute, split_k=split, deterministic=det,
+              want_colsum=want_bias)
+    if want_bias:
+        return dW, (db if db is not None else colsum(dY, 1, M, N))
     return dW
 
 
@@ -184,8 +194,12 @@ class LinearFn(Function):
             dx = torch.empty_like(x)
             gemm(L.GEMM_NN, dys, 0, N, W, 0, K, dx, K, M, K, N, compute=compute)
         if ctx.needs_input_grad[1]:
-            dW = _wgrad(dys, x, M, N, K, compute).to(W.dtype)
-        if has_b and ctx.needs_input_grad[2]:
+            if has_b and ctx.needs_input_grad[2]:
+                dW, db = _wgrad(dys, x, M, N, K, compute, want_bias=True)
+            else:
+                dW = _wgrad(dys, x, M, N, K, compute)
+            dW = dW.to(W.dtype)
+        elif has_b and ctx.needs_input_grad[2]:
             db = colsum(dys, 1, M, N)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == res_dtype else dy.to(res_dtype)
@@ -226,12 +240,10 @@ class MlpFn(Function):
         M, K, Hd, N, rps, compute, has_res = ctx.meta
         dy = dy.contiguous()
         dys = scale_rows(dy, row_scale, rps, M, N) if row_scale is not None else dy
-        dW2 = _wgrad(dys, g, M, N, Hd, compute)
-        db2 = colsum(dys, 1, M, N)
+        dW2, db2 = _wgrad(dys, g, M, N, Hd, compute, want_bias=True)
         dh = torch.empty_like(h)
         gemm(L.GEMM_NN, dys, 0, N, W2, 0, Hd, dh, Hd, M, Hd, N, compute=compute, epilogue=L.EPI_DGELU, aux=h)
-        dW1 = _wgrad(dh, x, M, Hd, K, compute)
-        db1 = colsum(dh, 1, M, Hd)
+        dW1, db1 = _wgrad(dh, x, M, Hd, K, compute, want_bias=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)

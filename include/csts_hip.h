@@ -56,9 +56,11 @@ typedef struct {
   int compute;   /* CSTS_BF16: v_mfma_f32_32x32x16_bf16 ; CSTS_F32: v_mfma_f32_32x32x2_f32 (exact fp32) */
   int split_k;
   void* workspace; size_t ws_bytes;   /* optional: makes split_k deterministic (partial slabs + finishing pass) */
+  float* colsum;   /* optional, TN + bf16 v2 kernel only: colsum[m] = sum_k A[k,m] (the bias gradient of a Linear) */
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
 size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);
+int csts_gemm_v2_eligible(const csts_gemm_args* args);   /* 1 when the fast bf16 kernel (and fused colsum) applies */
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */
