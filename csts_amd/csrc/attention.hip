@@ -172,6 +172,74 @@ template <int HD, bool F32> struct Cfg {
   static constexpr int LD_TR = F32 ? HD + 4 : (HD == 96 ? 96 : 224);  // tiles only read transposed
 };
 
+// raw register copy of this thread's share of one ROWS x HD bf16 tile (16-byte chunks)
+template <int HD, int ROWS> struct TileStage {
+  static constexpr int CPR = HD / 8, NCH = ROWS * CPR / 256;
+  uint4 r[NCH];
+  __device__ __forceinline__ void gload(const void* src, int64_t base, int64_t ts, int row0, int lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, col = (c - row * CPR) * 8;
+      r[i] = (row0 + row < lim)
+                 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(src) + base + (int64_t)(row0 + row) * ts + col)
+                 : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void lstore(bf16* S, int LD, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, col = (c - row * CPR) * 8;
+      *reinterpret_cast<uint4*>(S + row * LD + col) = r[i];
+    }
+  }
+};
+
+// Iterate over ROWS-row tiles [row_beg, row_end) of two tensors X, Y staged in LDS and call body(Xs, Ys, row0).
+// bf16: the next tile is prefetched into registers while the current one is consumed, LDS is double-buffered
+// (one barrier per tile, the HBM round trip hides under the MFMAs).  f32 (parity mode): synchronous, single buffer.
+template <int HD, int ROWS, int LDX, int LDY, bool F32, typename Body>
+__device__ __forceinline__ void tile_loop(typename El<F32>::T* smem, const void* X, int64_t xbase, int64_t xts,
+                                          const void* Y, int64_t ybase, int64_t yts, int row_beg, int row_end, int tid,
+                                          Body&& body) {
+  typedef typename El<F32>::T T;
+  if constexpr (F32) {
+    for (int row0 = row_beg; row0 < row_end; row0 += ROWS) {
+      __syncthreads();
+      load_tile<HD, ROWS, LDX, true>(smem, X, xbase, xts, row0, row_end, tid);
+      load_tile<HD, ROWS, LDY, true>(smem + ROWS * LDX, Y, ybase, yts, row0, row_end, tid);
+      __syncthreads();
+      body(smem, smem + ROWS * LDX, row0);
+    }
+  } else {
+    constexpr int TILE = ROWS * (LDX + LDY);
+    TileStage<HD, ROWS> sx, sy;
+    sx.gload(X, xbase, xts, row_beg, row_end, tid);
+    sy.gload(Y, ybase, yts, row_beg, row_end, tid);
+    sx.lstore(smem, LDX, tid);
+    sy.lstore(smem + ROWS * LDX, LDY, tid);
+    if (row_beg + ROWS < row_end) {
+      sx.gload(X, xbase, xts, row_beg + ROWS, row_end, tid);
+      sy.gload(Y, ybase, yts, row_beg + ROWS, row_end, tid);
+    }
+    __syncthreads();
+    int it = 0;
+    for (int row0 = row_beg; row0 < row_end; row0 += ROWS, ++it) {
+      T* cur = smem + (it & 1) * TILE;
+      T* nxt = smem + ((it + 1) & 1) * TILE;
+      body(cur, cur + ROWS * LDX, row0);
+      if (row0 + ROWS < row_end) {
+        sx.lstore(nxt, LDX, tid);
+        sy.lstore(nxt + ROWS * LDX, LDY, tid);
+        if (row0 + 2 * ROWS < row_end) {
+          sx.gload(X, xbase, xts, row0 + 2 * ROWS, row_end, tid);
+          sy.gload(Y, ybase, yts, row0 + 2 * ROWS, row_end, tid);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- forward
 template <int HD, bool F32>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
@@ -179,8 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   typedef Cfg<HD, F32> C;
   constexpr int KT = C::KVBLK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* Ks = reinterpret_cast<T*>(smem_raw);
-  T* Vs = Ks + C::KVBLK * C::LD_ROW;
+  T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
@@ -198,11 +265,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
   const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
 
-  for (int k0 = 0; k0 < p.Nk; k0 += C::KVBLK) {
-    __syncthreads();
-    load_tile<HD, C::KVBLK, C::LD_ROW, F32>(Ks, p.K, kbase, p.k_ts, k0, p.Nk, tid);
-    load_tile<HD, C::KVBLK, C::LD_TR, F32>(Vs, p.V, vbase, p.v_ts, k0, p.Nk, tid);
-    __syncthreads();
+  tile_loop<HD, C::KVBLK, C::LD_ROW, C::LD_TR, F32>(smem, p.K, kbase, p.k_ts, p.V, vbase, p.v_ts, 0, p.Nk, tid,
+                                                    [&](const T* Ks, const T* Vs, int k0) {
     f32x16 S[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -240,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) pv<HD, C::LD_TR, F32>(O, Vs + kt * 32 * C::LD_TR, S[kt], lane);
-  }
+  });
   lsum += __shfl_xor(lsum, 32, 64);
   if (qvalid) {
     store_rows<HD>(p.O, p.dt, (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)head * p.o_hs, O, 1.f / lsum, h);
@@ -255,8 +319,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   typedef Cfg<HD, F32> C;
   constexpr int KT = C::KVBLK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* Ks = reinterpret_cast<T*>(smem_raw);
-  T* Vs = Ks + C::KVBLK * C::LD_ROW;
+  T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int b = blockIdx.z, head = blockIdx.y;
   const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
@@ -276,11 +339,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
   const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
 
-  for (int k0 = 0; k0 < p.Nk; k0 += C::KVBLK) {
-    __syncthreads();
-    load_tile<HD, C::KVBLK, C::LD_ROW, F32>(Ks, p.K, kbase, p.k_ts, k0, p.Nk, tid);
-    load_tile<HD, C::KVBLK, C::LD_ROW, F32>(Vs, p.V, vbase, p.v_ts, k0, p.Nk, tid);
-    __syncthreads();
+  tile_loop<HD, C::KVBLK, C::LD_ROW, C::LD_ROW, F32>(smem, p.K, kbase, p.k_ts, p.V, vbase, p.v_ts, 0, p.Nk, tid,
+                                                     [&](const T* Ks, const T* Vs, int k0) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       f32x16 S, dP;
@@ -297,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
       }
       pv<HD, C::LD_ROW, F32>(acc, Ks + kt * 32 * C::LD_ROW, S, lane);
     }
-  }
+  });
   if (qvalid)
     store_rows<HD>(p.dQ, p.dt, (int64_t)b * p.dq_bs + (int64_t)qi * p.dq_ts + (int64_t)head * p.dq_hs, acc, p.scale, h);
 }
@@ -309,10 +369,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   typedef Cfg<HD, F32> C;
   constexpr int QBLK = C::KVBLK, QT = QBLK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* Qs = reinterpret_cast<T*>(smem_raw);
-  T* dOs = Qs + QBLK * C::LD_ROW;
-  float* Ls = reinterpret_cast<float*>(dOs + QBLK * C::LD_ROW);
-  float* Ds = Ls + QBLK;
+  T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int b = blockIdx.z / p.H, head = blockIdx.z % p.H;
   const int split = blockIdx.y;
@@ -331,18 +388,11 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   const int64_t qbase = (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
   const int64_t dobase = (int64_t)b * p.do_bs + (int64_t)head * p.do_hs;
   const int qbeg = split * p.q_chunk, qend = min(p.Nq, qbeg + p.q_chunk);
-  const int64_t statbase = ((int64_t)b * p.H + head) * p.Nq;
+  const float* Lrow = p.LSE + ((int64_t)b * p.H + head) * p.Nq;     // per-query statistics: wave-uniform (broadcast) loads
+  const float* Drow = p.delta + ((int64_t)b * p.H + head) * p.Nq;
 
-  for (int q0 = qbeg; q0 < qend; q0 += QBLK) {
-    __syncthreads();
-    load_tile<HD, QBLK, C::LD_ROW, F32>(Qs, p.Q, qbase, p.q_ts, q0, qend, tid);
-    load_tile<HD, QBLK, C::LD_ROW, F32>(dOs, p.dO, dobase, p.do_ts, q0, qend, tid);
-    if (tid < QBLK) {
-      const bool ok = q0 + tid < qend;
-      Ls[tid] = ok ? p.LSE[statbase + q0 + tid] : 0.f;
-      Ds[tid] = ok ? p.delta[statbase + q0 + tid] : 0.f;
-    }
-    __syncthreads();
+  tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
+                                                 [&](const T* Qs, const T* dOs, int q0) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       f32x16 S, dP;
@@ -352,17 +402,17 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       score<HD, C::LD_ROW, F32>(dP, dOs + qt * 32 * C::LD_ROW, vf, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ql = qt * 32 + rowoff(r, h);
-        const int q = q0 + ql;
+        const int q = q0 + qt * 32 + rowoff(r, h);
         const bool dead = q >= qend || !kvalid || is_masked(p, q, ki);
-        const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * p.scale_log2 - Ls[ql]);
+        const int qc = q < qend ? q : qend - 1;
+        const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * p.scale_log2 - Lrow[qc]);
         S[r] = pr;
-        dP[r] = pr * (dP[r] - Ds[ql]);
+        dP[r] = pr * (dP[r] - Drow[qc]);
       }
       pv<HD, C::LD_ROW, F32>(dV, dOs + qt * 32 * C::LD_ROW, S, lane);
       pv<HD, C::LD_ROW, F32>(dK, Qs + qt * 32 * C::LD_ROW, dP, lane);
     }
-  }
+  });
   if (!kvalid) return;
   if (p.nsplit == 1) {
     store_rows<HD>(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)ki * p.dk_ts + (int64_t)head * p.dk_hs, dK, p.scale, h);
@@ -434,11 +484,11 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnP p, int HD, float*
 
 template <int HD, bool F32> size_t smem_fwd() {
   typedef Cfg<HD, F32> C;
-  return (size_t)C::KVBLK * (C::LD_ROW + C::LD_TR) * (F32 ? 4 : 2);
+  return (size_t)C::KVBLK * (C::LD_ROW + C::LD_TR) * (F32 ? 4 : 2 * 2);   // bf16: double-buffered
 }
 template <int HD, bool F32> size_t smem_bwd() {
   typedef Cfg<HD, F32> C;
-  return (size_t)C::KVBLK * 2 * C::LD_ROW * (F32 ? 4 : 2) + 2 * C::KVBLK * sizeof(float);
+  return (size_t)C::KVBLK * 2 * C::LD_ROW * (F32 ? 4 : 2 * 2);
 }
 
 int fill(const csts_attn_args* a, AttnP& p) {
