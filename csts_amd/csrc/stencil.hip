@@ -44,154 +44,307 @@ __device__ __forceinline__ void st4(void* p, int dt, int64_t i, const float (&o)
   }
 }
 
+// 8 consecutive channels (16-byte bf16 / 2 x 16-byte f32 accesses); offsets are 32-bit inside one batch element
+__device__ __forceinline__ void ld8v(const void* p, int dt, int i, float (&o)[8]) {
+  if (dt == CSTS_F32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+    const float4 a = q[0], b = q[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p) + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+  }
+}
+__device__ __forceinline__ const void* batch_ptr(const void* p, int dt, int64_t off) {
+  return dt == CSTS_F32 ? (const void*)(reinterpret_cast<const float*>(p) + off) : (const void*)(reinterpret_cast<const bf16*>(p) + off);
+}
+__device__ __forceinline__ void* batch_ptr(void* p, int dt, int64_t off) {
+  return dt == CSTS_F32 ? (void*)(reinterpret_cast<float*>(p) + off) : (void*)(reinterpret_cast<bf16*>(p) + off);
+}
+
 // weights staged as wl[tap][HD] (fp32) so that lanes read consecutive channels
 __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* wl, int HD) {
-  for (int i = threadIdx.x; i < HD * 27; i += blockDim.x) {
-    const int c = i / 27, k = i - c * 27;
-    wl[k * HD + c] = w[i];
+  const int nthr = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = tid; i < HD * 27; i += nthr) {   // consecutive LDS addresses (conflict-free), strided L2-cached reads
+    const int k = i / HD, c = i - k * HD;
+    wl[i] = w[c * 27 + k];
   }
   __syncthreads();
 }
 
-// coarse[b,o,c] = sum_k fine[b, o*s-1+k, c] * w[c%HD][k]
-__global__ __launch_bounds__(256) void dwconv_strided_kernel(Geom g, const void* __restrict__ fine, int f_dt,
-                                                             const float* __restrict__ w, void* __restrict__ coarse,
-                                                             int c_dt) {
+// The depthwise kernels keep their tap loads free of control flow AND of dtype conversion: a batch of raw loads
+// (clamped, always in-range addresses) is issued back to back so that the memory latencies overlap, and only then
+// converted and accumulated.  Out-of-range taps read a ZERO weight row (strided / transposed) or are masked on the
+// raw bits (wgrad).  Measured with rocprofv3 PMC on MI355X: the earlier "load, convert, continue" form spent 79 %
+// of its wave cycles in s_waitcnt (one HBM/L2 round trip per tap).  Strides are powers of two (mask / shift).
+struct RowGeom {
+  Geom g;
+  int lt, lh, lw;        // log2 strides
+};
+
+// 32-bit decomposition of a flat token index (host guarantees B*ntok*C < 2^31)
+__device__ __forceinline__ void decomp(int bt, int ntok, int H, int W, int& b, int& t, int& h, int& w) {
+  b = bt / ntok;
+  int o = bt - b * ntok;
+  w = o % W; o /= W;
+  h = o % H;
+  t = o / H;
+}
+
+template <bool F32> struct Raw4;                       // 4 consecutive channels, unconverted
+template <> struct Raw4<true> { float4 v; };
+template <> struct Raw4<false> { uint2 v; };
+template <bool F32> __device__ __forceinline__ Raw4<F32> raw4_load(const void* base, int i) {
+  Raw4<F32> r;
+  if constexpr (F32) r.v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i);
+  else r.v = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(base) + i);
+  return r;
+}
+template <bool F32> __device__ __forceinline__ void raw4_cvt(const Raw4<F32>& r, float (&o)[4]) {
+  if constexpr (F32) { o[0] = r.v.x; o[1] = r.v.y; o[2] = r.v.z; o[3] = r.v.w; }
+  else {
+    o[0] = __uint_as_float(r.v.x << 16); o[1] = __uint_as_float(r.v.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.v.y << 16); o[3] = __uint_as_float(r.v.y & 0xffff0000u);
+  }
+}
+template <bool F32> __device__ __forceinline__ void st4t(void* base, int i, const float (&o)[4]) {
+  if constexpr (F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + i) = make_float4(o[0], o[1], o[2], o[3]);
+  else {
+    bf16x4 a;
+    a[0] = (bf16)o[0]; a[1] = (bf16)o[1]; a[2] = (bf16)o[2]; a[3] = (bf16)o[3];
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(base) + i) = a;
+  }
+}
+template <bool F32> __device__ __forceinline__ const void* bptr(const void* p, int64_t off) {
+  if constexpr (F32) return reinterpret_cast<const float*>(p) + off;
+  else return reinterpret_cast<const bf16*>(p) + off;
+}
+template <bool F32> __device__ __forceinline__ void* bptr(void* p, int64_t off) {
+  if constexpr (F32) return reinterpret_cast<float*>(p) + off;
+  else return reinterpret_cast<bf16*>(p) + off;
+}
+
+// weights staged as wl[28][HD] fp32: 27 taps + one all-zero row (index 27) that invalid taps point to
+__device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, float* wl, int HD) {
+  const int nthr = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = tid; i < HD * 27; i += nthr) {   // coalesced global reads; the (conflicting) transposition is paid in LDS
+    const int c = i / 27, k = i - c * 27;
+    wl[k * HD + c] = w[i];
+  }
+  for (int i = tid; i < HD; i += nthr) wl[27 * HD + i] = 0.f;
+  __syncthreads();
+}
+
+// coarse[b,o,c] = sum_k fine[b, o*s-1+k, c] * w[c%HD][k]          (4 channels per thread)
+template <bool FF32, bool CF32>
+__global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const void* __restrict__ fine,
+                                                             const float* __restrict__ w, void* __restrict__ coarse) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
-  stage_weights(w, wl, g.HD);
+  const Geom& g = rg.g;
+  stage_weights_z(w, wl, g.HD);
   const int CQ = g.C / VEC;
-  const int64_t ntok = (int64_t)g.Tc * g.Hc * g.Wc;
-  const int64_t total = (int64_t)g.B * ntok * CQ;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cq = (int)(idx % CQ);
-    const int64_t bt = idx / CQ;
-    const int b = (int)(bt / ntok);
-    int o = (int)(bt - (int64_t)b * ntok);
-    const int ow = o % g.Wc; o /= g.Wc;
-    const int oh = o % g.Hc;
-    const int ot = o / g.Hc;
-    const int c = cq * VEC, cw = c % g.HD;
+  const int ntok = g.Tc * g.Hc * g.Wc;
+  const int total = g.B * ntok * CQ;
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int bt = idx / CQ;
+    const int c = (idx - bt * CQ) * VEC, cw = c % g.HD;
+    int b, ot, oh, ow;
+    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+    int tof[3], hof[3], xof[3];
+    bool tv[3], hv[3], xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
+      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
+    }
+    const void* fb = bptr<FF32>(fine, (int64_t)b * g.f_bs);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
-      const int t = ot * g.st - 1 + kt;
-      if (t < 0 || t >= g.Tf) continue;
+      Raw4<FF32> raw[9];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int h = oh * g.sh - 1 + kh;
-        if (h < 0 || h >= g.Hf) continue;
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw4_load<FF32>(fb, tof[kt] + hof[kh] + xof[kw]);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int x = ow * g.sw - 1 + kw;
-          if (x < 0 || x >= g.Wf) continue;
+          const int tap = (tv[kt] && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
+          const float4 ww = *reinterpret_cast<const float4*>(&wl[tap * g.HD + cw]);
           float v[4];
-          ld4(fine, f_dt, b * g.f_bs + ((int64_t)(t * g.Hf + h) * g.Wf + x) * g.f_ts + c, v);
-          const float4 ww = *reinterpret_cast<const float4*>(&wl[(kt * 9 + kh * 3 + kw) * g.HD + cw]);
+          raw4_cvt<FF32>(raw[kh * 3 + kw], v);
           acc[0] += v[0] * ww.x; acc[1] += v[1] * ww.y; acc[2] += v[2] * ww.z; acc[3] += v[3] * ww.w;
         }
-      }
     }
-    st4(coarse, c_dt, b * g.c_bs + (bt - (int64_t)b * ntok) * g.c_ts + c, acc);
+    st4t<CF32>(bptr<CF32>(coarse, (int64_t)b * g.c_bs), (bt - b * ntok) * cts + c, acc);
   }
 }
 
-// fine[b,f,c] = sum_{k : (f+1-k) % s == 0} coarse[b, (f+1-k)/s, c] * w[c%HD][k]
-__global__ __launch_bounds__(256) void dwconv_transposed_kernel(Geom g, const void* __restrict__ coarse, int c_dt,
-                                                                const float* __restrict__ w, void* __restrict__ fine,
-                                                                int f_dt) {
+// candidate taps of one axis of the transposed form: k with (f + 1 - k) % s == 0, o = (f + 1 - k) / s.
+// stride 1: three candidates, stride 2: two (parity), stride >= 4: at most one.
+template <int N>
+__device__ __forceinline__ void axis_cand(int f, int s, int ls, int nc, int (&k)[N], int (&o)[N], bool (&ok)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    int kk, n;
+    if (N == 3) { kk = i; n = f + 1 - i; }
+    else if (N == 2) { kk = ((f + 1) & 1) + 2 * i; n = f + 1 - kk; }
+    else { kk = (f + 1) & (s - 1); n = f + 1 - kk; }
+    const int oo = n >> ls;
+    ok[i] = kk <= 2 && n >= 0 && oo < nc;
+    k[i] = min(kk, 2);
+    o[i] = min(max(oo, 0), nc - 1);
+  }
+}
+
+// fine[b,f,c] = sum_{k : (f+1-k) % s == 0} coarse[b, (f+1-k)/s, c] * w[c%HD][k]      (4 channels per thread)
+template <int NT, int NH, int NW, bool CF32, bool FF32>
+__global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, const void* __restrict__ coarse,
+                                                                const float* __restrict__ w, void* __restrict__ fine) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
-  stage_weights(w, wl, g.HD);
+  const Geom& g = rg.g;
+  stage_weights_z(w, wl, g.HD);
   const int CQ = g.C / VEC;
-  const int64_t ntok = (int64_t)g.Tf * g.Hf * g.Wf;
-  const int64_t total = (int64_t)g.B * ntok * CQ;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int cq = (int)(idx % CQ);
-    const int64_t bt = idx / CQ;
-    const int b = (int)(bt / ntok);
-    int f = (int)(bt - (int64_t)b * ntok);
-    const int fw = f % g.Wf; f /= g.Wf;
-    const int fh = f % g.Hf;
-    const int ft = f / g.Hf;
-    const int c = cq * VEC, cw = c % g.HD;
+  const int ntok = g.Tf * g.Hf * g.Wf;
+  const int total = g.B * ntok * CQ;
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int bt = idx / CQ;
+    const int c = (idx - bt * CQ) * VEC, cw = c % g.HD;
+    int b, ft, fh, fw;
+    decomp(bt, ntok, g.Hf, g.Wf, b, ft, fh, fw);
+    int kt[NT], ot[NT], kh[NH], oh[NH], kw[NW], ow[NW];
+    bool vt[NT], vh[NH], vw[NW];
+    axis_cand<NT>(ft, g.st, rg.lt, g.Tc, kt, ot, vt);
+    axis_cand<NH>(fh, g.sh, rg.lh, g.Hc, kh, oh, vh);
+    axis_cand<NW>(fw, g.sw, rg.lw, g.Wc, kw, ow, vw);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ot[i] *= g.Hc * g.Wc * cts;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) oh[i] *= g.Wc * cts;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) ow[i] = ow[i] * cts + c;
+    const void* cb = bptr<CF32>(coarse, (int64_t)b * g.c_bs);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const int nt = ft + 1 - kt;
-      if (nt < 0 || nt % g.st != 0) continue;
-      const int ot = nt / g.st;
-      if (ot >= g.Tc) continue;
+    for (int a = 0; a < NT; ++a) {
+      Raw4<CF32> raw[NH * NW];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int nh = fh + 1 - kh;
-        if (nh < 0 || nh % g.sh != 0) continue;
-        const int oh = nh / g.sh;
-        if (oh >= g.Hc) continue;
+      for (int e = 0; e < NH; ++e)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int nw = fw + 1 - kw;
-          if (nw < 0 || nw % g.sw != 0) continue;
-          const int ow = nw / g.sw;
-          if (ow >= g.Wc) continue;
+        for (int f = 0; f < NW; ++f) raw[e * NW + f] = raw4_load<CF32>(cb, ot[a] + oh[e] + ow[f]);
+#pragma unroll
+      for (int e = 0; e < NH; ++e)
+#pragma unroll
+        for (int f = 0; f < NW; ++f) {
+          const int tap = (vt[a] && vh[e] && vw[f]) ? kt[a] * 9 + kh[e] * 3 + kw[f] : 27;
+          const float4 ww = *reinterpret_cast<const float4*>(&wl[tap * g.HD + cw]);
           float v[4];
-          ld4(coarse, c_dt, b * g.c_bs + ((int64_t)(ot * g.Hc + oh) * g.Wc + ow) * g.c_ts + c, v);
-          const float4 ww = *reinterpret_cast<const float4*>(&wl[(kt * 9 + kh * 3 + kw) * g.HD + cw]);
+          raw4_cvt<CF32>(raw[e * NW + f], v);
           acc[0] += v[0] * ww.x; acc[1] += v[1] * ww.y; acc[2] += v[2] * ww.z; acc[3] += v[3] * ww.w;
         }
-      }
     }
-    st4(fine, f_dt, b * g.f_bs + (bt - (int64_t)b * ntok) * g.f_ts + c, acc);
+    st4t<FF32>(bptr<FF32>(fine, (int64_t)b * g.f_bs), (bt - b * ntok) * fts + c, acc);
   }
 }
 
-// partial dW: block = (slab of blockDim.x channels) x (blockDim.y token lanes), chunk of coarse tokens -> ws[part][HD*27]
+// partial dW: block = (slab/2 channel pairs) x (token lanes), chunk of coarse tokens -> ws[part][HD*27]
 // token lanes and heads of a slab are folded in LDS in a fixed order (bitwise reproducible).
-__global__ void dwconv_wgrad_kernel(Geom g, const void* __restrict__ fine, int f_dt, const void* __restrict__ coarse,
-                                    int c_dt, float* __restrict__ ws, int64_t chunk) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [blockDim.x][27]
+template <bool FF32, bool CF32>
+__global__ void dwconv_wgrad_kernel(RowGeom rg, const void* __restrict__ fine, const void* __restrict__ coarse,
+                                    float* __restrict__ ws, int slab, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [slab][27]
+  const Geom& g = rg.g;
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int c = blockIdx.x * blockDim.x + tx;
-  const int64_t ntok = (int64_t)g.Tc * g.Hc * g.Wc;
-  const int64_t total = (int64_t)g.B * ntok;
-  const int64_t beg = (int64_t)blockIdx.y * chunk, end = min(total, beg + chunk);
-  float acc[27];
+  const int cl = 2 * tx;
+  const int c = blockIdx.x * slab + cl;
+  const int ntok = g.Tc * g.Hc * g.Wc;
+  const int total = g.B * ntok;
+  const int beg = blockIdx.y * chunk, end = min(total, beg + chunk);
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  float a0[27], a1[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (int64_t bt = beg + ty; bt < end; bt += blockDim.y) {
-    const int b = (int)(bt / ntok);
-    int o = (int)(bt - (int64_t)b * ntok);
-    const float cv = ld_as_f32(coarse, c_dt, b * g.c_bs + (int64_t)o * g.c_ts + c);
-    const int ow = o % g.Wc; o /= g.Wc;
-    const int oh = o % g.Hc;
-    const int ot = o / g.Hc;
-    const int64_t fb = b * g.f_bs + c;
+  for (int k = 0; k < 27; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+  for (int bt = beg + ty; bt < end; bt += blockDim.y) {
+    int b, ot, oh, ow;
+    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+    int tof[3], hof[3], xof[3];
+    bool tv[3], hv[3], xv[3];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const int t = ot * g.st - 1 + kt;
+    for (int k = 0; k < 3; ++k) {
+      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
+      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
+    }
+    const void* fb = bptr<FF32>(fine, (int64_t)b * g.f_bs);
+    const void* cb = bptr<CF32>(coarse, (int64_t)b * g.c_bs);
+    float c0, c1;
+    if constexpr (CF32) {
+      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(cb) + (bt - b * ntok) * cts + c);
+      c0 = v.x; c1 = v.y;
+    } else {
+      const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16*>(cb) + (bt - b * ntok) * cts + c);
+      c0 = __uint_as_float(v << 16); c1 = __uint_as_float(v & 0xffff0000u);
+    }
+    if constexpr (FF32) {
+      float2 raw[27];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int h = oh * g.sh - 1 + kh;
+      for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int x = ow * g.sw - 1 + kw;
-          const bool ok = t >= 0 && t < g.Tf && h >= 0 && h < g.Hf && x >= 0 && x < g.Wf;
-          const float fv = ok ? ld_as_f32(fine, f_dt, fb + ((int64_t)(t * g.Hf + h) * g.Wf + x) * g.f_ts) : 0.f;
-          acc[kt * 9 + kh * 3 + kw] += fv * cv;
-        }
-      }
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            raw[kt * 9 + kh * 3 + kw] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(fb) + tof[kt] + hof[kh] + xof[kw]);
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kt * 9 + kh * 3 + kw;
+            const bool ok = tv[kt] && hv[kh] && xv[kw];
+            a0[tap] += (ok ? raw[tap].x : 0.f) * c0;
+            a1[tap] += (ok ? raw[tap].y : 0.f) * c1;
+          }
+    } else {
+      unsigned raw[27];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            raw[kt * 9 + kh * 3 + kw] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16*>(fb) + tof[kt] + hof[kh] + xof[kw]);
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kt * 9 + kh * 3 + kw;
+            const unsigned r = (tv[kt] && hv[kh] && xv[kw]) ? raw[tap] : 0u;
+            a0[tap] += __uint_as_float(r << 16) * c0;
+            a1[tap] += __uint_as_float(r & 0xffff0000u) * c1;
+          }
     }
   }
-  // fold token lanes (fixed order), then heads
-  for (int l = 0; l < (int)blockDim.y; ++l) {
+  for (int l = 0; l < (int)blockDim.y; ++l) {   // fold the token lanes in a fixed order
     if (ty == l) {
 #pragma unroll
       for (int k = 0; k < 27; ++k) {
-        if (l == 0) red[tx * 27 + k] = acc[k];
-        else red[tx * 27 + k] += acc[k];
+        if (l == 0) { red[cl * 27 + k] = a0[k]; red[(cl + 1) * 27 + k] = a1[k]; }
+        else { red[cl * 27 + k] += a0[k]; red[(cl + 1) * 27 + k] += a1[k]; }
       }
     }
     __syncthreads();
   }
-  const int heads_in_slab = blockDim.x / g.HD;
+  const int heads_in_slab = slab / g.HD;
   float* out = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * g.HD * 27;
   const int tid = ty * blockDim.x + tx, nthr = blockDim.x * blockDim.y;
   for (int i = tid; i < g.HD * 27; i += nthr) {
@@ -393,14 +546,19 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void
   }
 }
 
-int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 16); }
+int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 8); }
 
-int fill_geom(const csts_dwconv_geom* a, Geom& g) {
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int fill_geom(const csts_dwconv_geom* a, RowGeom& rg) {
+  Geom& g = rg.g;
   g.B = a->B; g.C = a->C; g.HD = a->HD;
   g.Tf = a->Tf; g.Hf = a->Hf; g.Wf = a->Wf; g.Tc = a->Tc; g.Hc = a->Hc; g.Wc = a->Wc;
   g.st = a->st; g.sh = a->sh; g.sw = a->sw;
   g.f_bs = a->fine_batch_stride; g.f_ts = a->fine_token_stride;
   g.c_bs = a->coarse_batch_stride; g.c_ts = a->coarse_token_stride;
+  rg.lt = ilog2(a->st); rg.lh = ilog2(a->sh); rg.lw = ilog2(a->sw);
   return 0;
 }
 
@@ -408,25 +566,34 @@ int fill_geom(const csts_dwconv_geom* a, Geom& g) {
 
 #define CHECK_GEOM(a)                                                                                         \
   CSTS_REQUIRE((a) != nullptr, "null geometry");                                                              \
-  CSTS_REQUIRE((a)->B > 0 && (a)->C > 0 && (a)->HD > 0 && (a)->C % (a)->HD == 0 && (a)->HD % 4 == 0, "bad channels"); \
-  CSTS_REQUIRE((a)->HD <= 192, "head_dim > 192 unsupported");                                                \
-  CSTS_REQUIRE((a)->st >= 1 && (a)->sh >= 1 && (a)->sw >= 1, "bad stride");                                 \
+  CSTS_REQUIRE((a)->B > 0 && (a)->C > 0 && (a)->HD > 0 && (a)->C % (a)->HD == 0 && (a)->HD % 8 == 0, "bad channels (head_dim % 8)"); \
+  CSTS_REQUIRE((a)->HD <= 192 && (a)->C <= 1024, "head_dim > 192 / C > 1024 unsupported");                   \
+  CSTS_REQUIRE(pow2((a)->st) && pow2((a)->sh) && pow2((a)->sw), "strides must be powers of two");           \
   CSTS_REQUIRE((a)->Tc == ((a)->Tf - 1) / (a)->st + 1 && (a)->Hc == ((a)->Hf - 1) / (a)->sh + 1 &&          \
                    (a)->Wc == ((a)->Wf - 1) / (a)->sw + 1,                                                   \
                "coarse grid must equal floor((fine-1)/stride)+1");                                           \
-  CSTS_REQUIRE((a)->fine_token_stride % 4 == 0 && (a)->coarse_token_stride % 4 == 0 &&                       \
-                   (a)->fine_batch_stride % 4 == 0 && (a)->coarse_batch_stride % 4 == 0,                     \
-               "strides must be multiples of 4 elements")
+  CSTS_REQUIRE((a)->fine_token_stride % 8 == 0 && (a)->coarse_token_stride % 8 == 0 &&                       \
+                   (a)->fine_batch_stride % 8 == 0 && (a)->coarse_batch_stride % 8 == 0,                     \
+               "strides must be multiples of 8 elements");                                                   \
+  CSTS_REQUIRE((int64_t)(a)->Tf * (a)->Hf * (a)->Wf * (a)->fine_token_stride < ((int64_t)1 << 31) &&          \
+                   (int64_t)(a)->Tc * (a)->Hc * (a)->Wc * (a)->coarse_token_stride < ((int64_t)1 << 31),      \
+               "one batch element must span < 2^31 elements");                                               \
+  CSTS_REQUIRE((int64_t)(a)->B * (a)->Tf * (a)->Hf * (a)->Wf * (a)->C < ((int64_t)1 << 31), "B*N*C must be < 2^31")
 
 extern "C" int csts_dwconv_strided(const csts_dwconv_geom* a, const void* fine, int fine_dt, const float* weight,
                                    void* coarse, int coarse_dt, hipStream_t stream) {
   CHECK_GEOM(a);
   CSTS_REQUIRE(fine && weight && coarse, "null pointer");
-  CSTS_REQUIRE(((uintptr_t)fine & 7) == 0 && ((uintptr_t)coarse & 7) == 0, "tensors must be 8-byte aligned");
-  Geom g; fill_geom(a, g);
-  const int64_t total = (int64_t)g.B * g.Tc * g.Hc * g.Wc * (g.C / VEC);
-  hipLaunchKernelGGL(dwconv_strided_kernel, dim3(grid_for(total)), dim3(256), (size_t)g.HD * 27 * 4, stream, g, fine,
-                     fine_dt, weight, coarse, coarse_dt);
+  CSTS_REQUIRE(((uintptr_t)fine & 15) == 0 && ((uintptr_t)coarse & 15) == 0, "tensors must be 16-byte aligned");
+  RowGeom rg; fill_geom(a, rg);
+  const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc * (a->C / VEC);
+  const dim3 grid(grid_for(total)), block(256);
+  const size_t sm = (size_t)a->HD * 28 * 4;
+  const bool ff = fine_dt == CSTS_F32, cf = coarse_dt == CSTS_F32;
+  if (ff && cf) hipLaunchKernelGGL((dwconv_strided_kernel<true, true>), grid, block, sm, stream, rg, fine, weight, coarse);
+  else if (!ff && !cf) hipLaunchKernelGGL((dwconv_strided_kernel<false, false>), grid, block, sm, stream, rg, fine, weight, coarse);
+  else if (ff) hipLaunchKernelGGL((dwconv_strided_kernel<true, false>), grid, block, sm, stream, rg, fine, weight, coarse);
+  else hipLaunchKernelGGL((dwconv_strided_kernel<false, true>), grid, block, sm, stream, rg, fine, weight, coarse);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
@@ -435,17 +602,35 @@ extern "C" int csts_dwconv_transposed(const csts_dwconv_geom* a, const void* coa
                                       void* fine, int fine_dt, hipStream_t stream) {
   CHECK_GEOM(a);
   CSTS_REQUIRE(fine && weight && coarse, "null pointer");
-  CSTS_REQUIRE(((uintptr_t)fine & 7) == 0 && ((uintptr_t)coarse & 7) == 0, "tensors must be 8-byte aligned");
-  Geom g; fill_geom(a, g);
-  const int64_t total = (int64_t)g.B * g.Tf * g.Hf * g.Wf * (g.C / VEC);
-  hipLaunchKernelGGL(dwconv_transposed_kernel, dim3(grid_for(total)), dim3(256), (size_t)g.HD * 27 * 4, stream, g, coarse,
-                     coarse_dt, weight, fine, fine_dt);
+  CSTS_REQUIRE(((uintptr_t)fine & 15) == 0 && ((uintptr_t)coarse & 15) == 0, "tensors must be 16-byte aligned");
+  RowGeom rg; fill_geom(a, rg);
+  const int64_t total = (int64_t)a->B * a->Tf * a->Hf * a->Wf * (a->C / VEC);
+  const dim3 grid(grid_for(total)), block(256);
+  const size_t sm = (size_t)a->HD * 28 * 4;
+  CSTS_REQUIRE(coarse_dt == fine_dt, "transposed stencil: both tensors must have the same dtype");
+  const bool f32 = fine_dt == CSTS_F32;
+  auto nc = [](int st) { return st == 1 ? 3 : (st == 2 ? 2 : 1); };
+  const int key = nc(a->st) * 100 + nc(a->sh) * 10 + nc(a->sw);
+#define TR_CASE(NT, NH, NW)                                                                                          \
+  case NT * 100 + NH * 10 + NW:                                                                                      \
+    if (f32) hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, true, true>), grid, block, sm, stream, rg, coarse, weight, fine); \
+    else hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, false, false>), grid, block, sm, stream, rg, coarse, weight, fine); \
+    break;
+  switch (key) {
+    TR_CASE(3, 3, 3) TR_CASE(3, 3, 2) TR_CASE(3, 3, 1) TR_CASE(3, 2, 3) TR_CASE(3, 2, 2) TR_CASE(3, 2, 1)
+    TR_CASE(3, 1, 3) TR_CASE(3, 1, 2) TR_CASE(3, 1, 1) TR_CASE(2, 3, 3) TR_CASE(2, 3, 2) TR_CASE(2, 3, 1)
+    TR_CASE(2, 2, 3) TR_CASE(2, 2, 2) TR_CASE(2, 2, 1) TR_CASE(2, 1, 3) TR_CASE(2, 1, 2) TR_CASE(2, 1, 1)
+    TR_CASE(1, 3, 3) TR_CASE(1, 3, 2) TR_CASE(1, 3, 1) TR_CASE(1, 2, 3) TR_CASE(1, 2, 2) TR_CASE(1, 2, 1)
+    TR_CASE(1, 1, 3) TR_CASE(1, 1, 2) TR_CASE(1, 1, 1)
+    default: CSTS_FAIL("unsupported stride combination");
+  }
+#undef TR_CASE
   CSTS_LAUNCH_CHECK();
   return 0;
 }
 
 static void wgrad_plan(const csts_dwconv_geom* a, int& slab, int& nslab, int64_t& chunk, int64_t& nchunk) {
-  int k = std::max(1, 192 / a->HD);    // a slab (= thread block) holds k whole heads, <= 192 channels
+  int k = std::max(1, 192 / a->HD);    // a slab holds k whole heads, <= 192 channels
   while (k > 1 && a->C % (a->HD * k) != 0) --k;
   slab = a->HD * k;
   nslab = a->C / slab;
@@ -456,7 +641,7 @@ static void wgrad_plan(const csts_dwconv_geom* a, int& slab, int& nslab, int64_t
 }
 
 extern "C" size_t csts_dwconv_wgrad_workspace(const csts_dwconv_geom* a) {
-  if (!a || a->C <= 0) return 0;
+  if (!a || a->C <= 0 || a->HD <= 0) return 0;
   int slab, nslab; int64_t chunk, nchunk;
   wgrad_plan(a, slab, nslab, chunk, nchunk);
   return (size_t)nchunk * nslab * a->HD * 27 * sizeof(float);
@@ -468,15 +653,16 @@ extern "C" int csts_dwconv_wgrad(const csts_dwconv_geom* a, const void* fine, in
   CSTS_REQUIRE(fine && coarse && dweight && workspace, "null pointer");
   int slab, nslab; int64_t chunk, nchunk;
   wgrad_plan(a, slab, nslab, chunk, nchunk);
-  CSTS_REQUIRE(a->C % slab == 0 && slab % a->HD == 0, "channel slab must hold whole heads");
+  CSTS_REQUIRE(a->C % slab == 0 && slab % a->HD == 0 && slab % 2 == 0, "channel slab must hold whole heads");
   CSTS_REQUIRE(ws_bytes >= (size_t)nchunk * nslab * a->HD * 27 * sizeof(float), "workspace too small");
-  Geom g; fill_geom(a, g);
+  RowGeom rg; fill_geom(a, rg);
   float* ws = reinterpret_cast<float*>(workspace);
-  const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(4, chunk / 4));   // token lanes per channel
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nslab, (unsigned)nchunk), dim3(slab, lanes), (size_t)slab * 27 * 4, stream, g,
-                     fine, fine_dt, coarse, coarse_dt, ws, chunk);
+  const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 512 / (slab / 2)), chunk / 2));
+  CSTS_REQUIRE(coarse_dt == fine_dt, "stencil wgrad: both tensors must have the same dtype");
+  const dim3 wg(nslab, (unsigned)nchunk), wb(slab / 2, lanes);
+  if (fine_dt == CSTS_F32) hipLaunchKernelGGL((dwconv_wgrad_kernel<true, true>), wg, wb, (size_t)slab * 27 * 4, stream, rg, fine, coarse, ws, slab, (int)chunk);
+  else hipLaunchKernelGGL((dwconv_wgrad_kernel<false, false>), wg, wb, (size_t)slab * 27 * 4, stream, rg, fine, coarse, ws, slab, (int)chunk);
   CSTS_LAUNCH_CHECK();
-
   csts_reduce_rows_launch(ws, dweight, nchunk * nslab, (int64_t)a->HD * 27, 1.f, stream);
   CSTS_LAUNCH_CHECK();
   return 0;
