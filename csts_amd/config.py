@@ -110,6 +110,7 @@ def get_cfg() -> CfgNode:
                        SYNTHETIC_DATA=True,          # the data pipeline is out of scope: synthetic clips
                        STEPS_PER_EPOCH=50,
                        GRAD_BUCKET_MB=64,
+                       TWO_STREAMS=True,             # audio trunk on a second HIP stream, concurrent with the video trunk
                        FUSION_KERNEL_FROM_GRID=False)  # True: (1,S/32,S/32) fusion kernels -> 224^2 works (parity unpinned)
     return c
 

@@ -191,6 +191,7 @@ class CSTS(nn.Module):
                                       "token, separable pos-embed, 3-D patches, conv pooling, no dropout, no stem norm")
         amd = getattr(cfg, "CSTS_AMD", None)
         self.rt = Runtime(amd.COMPUTE if amd is not None else "bf16")
+        self.two_streams = bool(getattr(amd, "TWO_STREAMS", True)) if amd is not None else True
         rt = self.rt
         S, T = cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.NUM_FRAMES
         self.patch_stride = list(cfg.MVIT.PATCH_STRIDE)
@@ -285,6 +286,11 @@ class CSTS(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def _audio_stream(self):
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
+
     @torch.jit.ignore
     def no_weight_decay(self):
         """custom_multimodal_builder.py:327-341."""
@@ -316,11 +322,25 @@ class CSTS(nn.Module):
         vb, ab = self.blocks, self.blocks_audio
         vn = [f"blocks.{i}" for i in range(len(vb))]
         an = [f"blocks_audio.{i}" for i in range(len(ab))]
-        # video / audio stages interleaved as in the reference (:387-411); the two trunks are independent until fusion
-        xt, thw = run(xt, thw, vb[:1], vn[:1]); inter.append((xt, thw)); yt, thw_a = run(yt, thw_a, ab[:1], an[:1])
-        xt, thw = run(xt, thw, vb[1:3], vn[1:3]); inter.append((xt, thw)); yt, thw_a = run(yt, thw_a, ab[1:2], an[1:2])
-        xt, thw = run(xt, thw, vb[3:14], vn[3:14]); inter.append((xt, thw)); yt, thw_a = run(yt, thw_a, ab[2:3], an[2:3])
-        xt, thw = run(xt, thw, vb[14:], vn[14:]); yt, thw_a = run(yt, thw_a, ab[3:], an[3:])
+        # The reference interleaves video / audio stages (:387-411) but the two trunks are data-independent until the
+        # fusion: the audio trunk runs on its own HIP stream (autograd replays its backward on that stream too), so
+        # its latency-bound kernels fill CUs the video trunk leaves idle.
+        main = torch.cuda.current_stream()
+        side = self._audio_stream() if self.two_streams else None
+        if side is not None:
+            side.wait_stream(main)
+            yt.record_stream(side)      # allocated on `main`, read on `side`: keep the allocator from recycling it early
+            with torch.cuda.stream(side):
+                yt, thw_a = run(yt, thw_a, ab, an)
+        xt, thw = run(xt, thw, vb[:1], vn[:1]); inter.append((xt, thw))
+        xt, thw = run(xt, thw, vb[1:3], vn[1:3]); inter.append((xt, thw))
+        xt, thw = run(xt, thw, vb[3:14], vn[3:14]); inter.append((xt, thw))
+        xt, thw = run(xt, thw, vb[14:], vn[14:])
+        if side is not None:
+            main.wait_stream(side)
+            yt.record_stream(main)
+        else:
+            yt, thw_a = run(yt, thw_a, ab, an)
 
         # ---- spatial fusion (:415-432)
         B, Nv, Cc = xt.shape

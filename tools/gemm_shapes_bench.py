@@ -25,9 +25,12 @@ for lo, M, N, K, sp, calls, *_ in rows:
     for _ in range(5): f()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 5 * 1e3
-    out.append((us * calls, lo, M, N, K, sp, calls, us, 2.0 * M * N * K / us / 1e6))
+    byt = A.numel() * A.element_size() + B.numel() * B.element_size() + Cm.numel() * Cm.element_size()
+    ideal = max(2.0 * M * N * K / 1.5e15, byt / 5e12) * 1e6
+    out.append((us * calls, lo, M, N, K, sp, calls, us, 2.0 * M * N * K / us / 1e6, ideal, byt / us / 1e3))
 out.sort(reverse=True)
 tot = sum(o[0] for o in out)
 print(f"total GEMM ms/step {tot/1e3:.2f}")
-for t, lo, M, N, K, sp, calls, us, tf in out[:40]:
-    print(f"{lo} {M:7d} {N:6d} {K:7d} split {sp:3d} calls {calls:3d} {us:8.1f} us {tf:7.1f} TF/s  -> {t/1e3:6.2f} ms/step")
+print(f"ideal (1.5 PF/s, 5 TB/s) total ms/step {sum(o[9]*o[6] for o in out)/1e3:.2f}")
+for t, lo, M, N, K, sp, calls, us, tf, ideal, gbs in out[:60]:
+    print(f"{lo} {M:7d} {N:6d} {K:7d} split {sp:3d} calls {calls:3d} {us:8.1f} us {tf:7.1f} TF/s {gbs:6.0f} GB/s ideal {ideal:6.1f} us x{us/ideal:4.1f} -> {t/1e3:6.2f} ms/step (gap {(us-ideal)*calls/1e3:5.2f})")
