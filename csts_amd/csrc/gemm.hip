@@ -234,6 +234,13 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit) {
   const int64_t total = p.M * p.N;
+  if (p.colsum != nullptr && p.colsum_ws != nullptr) {   // fused bias-gradient partials: colsum[m] = sum_s colsum_ws[s][m]
+    for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (int64_t)gridDim.x * blockDim.x) {
+      float t = 0.f;
+      for (int sidx = 0; sidx < nsplit; ++sidx) t += p.colsum_ws[(int64_t)sidx * p.M + m];
+      p.colsum[m] = t;
+    }
+  }
   for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x * VEC) {
     const int64_t m = idx / p.N, n0 = idx - m * p.N;
@@ -267,16 +274,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit
     }
   }
 }
-__global__ void colsum_finish_kernel(Params p, int nsplit) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= p.M) return;
-  float t = 0.f;
-  for (int sidx = 0; sidx < nsplit; ++sidx) t += p.colsum_ws[(int64_t)sidx * p.M + m];
-  p.colsum[m] = t;
-}
 static void launch_finish(const Params& p, int nsplit, hipStream_t stream) {
-  if (p.colsum != nullptr && p.colsum_ws != nullptr)
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)cdiv(p.M, 256)), dim3(256), 0, stream, p, nsplit);
   const int64_t total = p.M * p.N;
   if (p.N % 4 == 0 && aligned16(p.ws))
     hipLaunchKernelGGL(splitk_finish_kernel<4>, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 4096)), dim3(256), 0, stream, p, nsplit);
@@ -557,7 +555,6 @@ bool v2_ok(const csts_gemm_args* a) {
   if (a->bias && !aligned16(a->bias)) return false;
   // dtype combinations instantiated below
   if (a->layout == CSTS_GEMM_TN && a->b_dt != CSTS_BF16) return false;
-  if (a->layout != CSTS_GEMM_TN && a->b_dt != CSTS_F32) return false;
   if (a->layout == CSTS_GEMM_NT && a->a_dt != CSTS_BF16) return false;
   return true;
 }
@@ -621,10 +618,19 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
     const int mt = (mtiles * p.ntiles_n * nsplit >= 512) ? 2 : 1;
     mtiles = cdiv(a->M, 64 * mt);
     dim3 grid2((unsigned)(mtiles * p.ntiles_n), (unsigned)nsplit, 1);
-    const bool af = a->a_dt == CSTS_F32;
-    if (a->layout == CSTS_GEMM_NT) launch2<true, true, false, true>(p, mt, grid2, stream);
-    else if (a->layout == CSTS_GEMM_NN) { if (af) launch2<true, false, true, true>(p, mt, grid2, stream); else launch2<true, false, false, true>(p, mt, grid2, stream); }
-    else { if (af) launch2<false, false, true, false>(p, mt, grid2, stream); else launch2<false, false, false, false>(p, mt, grid2, stream); }
+    const bool af = a->a_dt == CSTS_F32, bf = a->b_dt == CSTS_F32;
+    if (a->layout == CSTS_GEMM_NT) {
+      if (bf) launch2<true, true, false, true>(p, mt, grid2, stream);
+      else launch2<true, true, false, false>(p, mt, grid2, stream);            // bf16 shadow weights
+    } else if (a->layout == CSTS_GEMM_NN) {
+      if (af && bf) launch2<true, false, true, true>(p, mt, grid2, stream);
+      else if (!af && bf) launch2<true, false, false, true>(p, mt, grid2, stream);
+      else if (af) launch2<true, false, true, false>(p, mt, grid2, stream);
+      else launch2<true, false, false, false>(p, mt, grid2, stream);
+    } else {
+      if (af) launch2<false, false, true, false>(p, mt, grid2, stream);
+      else launch2<false, false, false, false>(p, mt, grid2, stream);
+    }
     CSTS_LAUNCH_CHECK();
     if (det) {
       launch_finish(p, (int)nsplit, stream);

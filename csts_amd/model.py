@@ -118,7 +118,8 @@ class Block(nn.Module):
         H = self.heads
         thw = list(thw)
         xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt)
-        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute)
+        w16 = lambda lin: getattr(lin, "_w16", None)      # bf16 shadow maintained by CSTS._refresh_w16 (bf16 mode)
+        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv))
         mask_mode, mT, mHW = L.MASK_NONE, 0, 0
         if self.kind == "spatial":
             mask_mode, mT, mHW = L.MASK_SPATIAL, thw[0], thw[1] * thw[2]
@@ -147,13 +148,14 @@ class Block(nn.Module):
         Nq = o.shape[1]
         s_attn, s_mlp = self._drop_scales(B, x.device, keep_masks)
         x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x_res, row_scale=s_attn, rows_per_scale=Nq, out_dt=L.F32,
-                        compute=rt.compute)
+                        compute=rt.compute, w16=w16(a.proj))
         xn2 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt)
         base = x1
         if self.dim != self.dim_out:
-            base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute)
+            base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj))
         out = ops.mlp(xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=base,
-                      row_scale=s_mlp, rows_per_scale=Nq, act_dt=rt.act_dt, out_dt=L.F32, compute=rt.compute)
+                      row_scale=s_mlp, rows_per_scale=Nq, act_dt=rt.act_dt, out_dt=L.F32, compute=rt.compute,
+                      w16_1=w16(self.mlp.fc1), w16_2=w16(self.mlp.fc2))
         extra = None
         if want_attn or spatial_audio_attn:
             with torch.no_grad():
@@ -286,6 +288,26 @@ class CSTS(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def _refresh_w16(self):
+        """bf16 shadows of every block Linear weight (fp32 masters stay the nn.Parameters): one multi-tensor cast per
+        forward in training mode (weights change every step; also what a captured HIP graph replays), on demand in eval."""
+        if self.rt.compute != L.BF16:
+            return
+        lins = getattr(self, "_w16_lins", None)
+        if lins is None:
+            lins = [m for blk in self.modules() if isinstance(blk, Block)
+                    for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2, getattr(blk, "proj", None)) if m is not None]
+            self._w16_lins = lins
+        stale = [l for l in lins if getattr(l, "_w16", None) is None or l._w16.device != l.weight.device]
+        for l in stale:
+            l._w16 = torch.empty(l.weight.shape, dtype=torch.bfloat16, device=l.weight.device)
+            l._w16_ver = -1
+        if self.training or any(l._w16_ver != l.weight._version for l in lins):
+            with torch.no_grad():
+                torch._foreach_copy_([l._w16 for l in lins], [l.weight.detach() for l in lins])
+            for l in lins:
+                l._w16_ver = l.weight._version
+
     def _audio_stream(self):
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream()
@@ -305,6 +327,7 @@ class CSTS(nn.Module):
         if not inpt.is_cuda:
             raise L.CstsError("CSTS (csts_amd) runs on MI355X only: inputs must be GPU tensors; there is no CPU fallback")
         km = keep_masks or {}
+        self._refresh_w16()
         pe, pa = self.patch_embed, self.patch_embed_audio
         xt = ops.patch_embed(inpt.float(), pe.proj.weight, pe.proj.bias, self.pos_embed_spatial, self.pos_embed_temporal,
                              pe.kernel, pe.stride, pe.padding, rt.act_dt, rt.compute)

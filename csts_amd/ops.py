@@ -166,7 +166,7 @@ class LinearFn(Function):
     of attention.py:242,247 folded into the epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int):
+    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int, w16):
         _need_gpu(x, W)
         x = x.contiguous()
         W = W.contiguous()
@@ -176,9 +176,11 @@ class LinearFn(Function):
         y = torch.empty(*x.shape[:-1], N, dtype=torch_dtype(out_dt), device=x.device)
         if residual is not None:
             residual = residual.contiguous()
-        gemm(L.GEMM_NT, x, 0, K, W, 0, K, y, N, M, N, K, compute=compute, bias=b, residual=residual, ldr=N,
+        Wop = w16 if (w16 is not None and compute == BF16) else W     # bf16 shadow of the fp32 master weight
+        gemm(L.GEMM_NT, x, 0, K, Wop, 0, K, y, N, M, N, K, compute=compute, bias=b, residual=residual, ldr=N,
              row_scale=row_scale, rows_per_scale=rows_per_scale)
-        ctx.save_for_backward(x, W, row_scale)
+        ctx.save_for_backward(x, Wop, row_scale)
+        ctx.wdtype = W.dtype
         ctx.meta = (M, N, K, rows_per_scale, compute, b is not None, residual is not None,
                     residual.dtype if residual is not None else None)
         return y
@@ -198,16 +200,16 @@ class LinearFn(Function):
                 dW, db = _wgrad(dys, x, M, N, K, compute, want_bias=True)
             else:
                 dW = _wgrad(dys, x, M, N, K, compute)
-            dW = dW.to(W.dtype)
+            dW = dW.to(ctx.wdtype)
         elif has_b and ctx.needs_input_grad[2]:
             db = colsum(dys, 1, M, N)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == res_dtype else dy.to(res_dtype)
-        return dx, dW, db, dres, None, None, None, None
+        return dx, dW, db, dres, None, None, None, None, None
 
 
-def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32):
-    return LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute)
+def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32, w16=None):
+    return LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16)
 
 
 class MlpFn(Function):
@@ -215,8 +217,11 @@ class MlpFn(Function):
     GELU lives in fc1's epilogue, GELU' in the epilogue of fc2's data-gradient GEMM."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, residual, row_scale, rows_per_scale: int, act_dt: int, out_dt: int, compute: int):
+    def forward(ctx, x, W1, b1, W2, b2, residual, row_scale, rows_per_scale: int, act_dt: int, out_dt: int, compute: int,
+                w16_1, w16_2):
         _need_gpu(x, W1, W2)
+        if compute == BF16 and w16_1 is not None and w16_2 is not None:   # bf16 shadows of the fp32 master weights
+            W1, W2 = w16_1, w16_2
         x = x.contiguous()
         K = x.shape[-1]
         Hd = W1.shape[0]
@@ -248,11 +253,12 @@ class MlpFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(L.GEMM_NN, dh, 0, Hd, W1, 0, K, dx, K, M, K, Hd, compute=compute)
-        return dx, dW1, db1, dW2, db2, (dy if has_res else None), None, None, None, None, None
+        return dx, dW1, db1, dW2, db2, (dy if has_res else None), None, None, None, None, None, None, None
 
 
-def mlp(x, W1, b1, W2, b2, *, residual=None, row_scale=None, rows_per_scale=1, act_dt=F32, out_dt=F32, compute=F32):
-    return MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute)
+def mlp(x, W1, b1, W2, b2, *, residual=None, row_scale=None, rows_per_scale=1, act_dt=F32, out_dt=F32, compute=F32,
+        w16_1=None, w16_2=None):
+    return MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute, w16_1, w16_2)
 
 
 # ----------------------------------------------------------------------------------------- attention inner
@@ -360,6 +366,7 @@ class AttnInnerFn(Function):
         ctx.descr = (qd, kd, vd, Nq, Nk)
         ctx.save_for_backward(qkv, o, lse, wq, gq, wk, gk, wv, gv)
         ctx.mark_non_differentiable(lse)
+        ctx.set_materialize_grads(False)     # no zero-filled d(lse) tensor per backward
         return o, lse
 
     @staticmethod
