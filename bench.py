@@ -178,8 +178,12 @@ def main():
     if not args.no_roofline and rank == 0:
         gt = GemmTimer()
         gt.install()
+        core = model.module if hasattr(model, "module") else model
+        two = core.two_streams
+        core.two_streams = False        # one stream: an event pair then brackets exactly one kernel (plus its launch gap)
         for _ in range(2):
             eager_step()
+        core.two_streams = two
         gt.remove()
         agg = gt.summary()
         if args.dump_gemm:

@@ -323,9 +323,11 @@ __device__ __forceinline__ bf16x8 raw_to_bf16(const Raw<F32S>& r) {
 }
 
 // one operand tile: EXT output rows (128 or 64) x 64 k.  KC: LDS [EXT][72] ; OC: LDS [64][EXT+32]
-template <bool KC, bool F32S, int EXT> struct Oper {
-  static constexpr int NCH = EXT / 32;                  // chunks of 8 elements per thread
+template <bool KC, bool F32S, int EXT, int NTHR> struct Oper {
+  static constexpr int NCH = EXT * 8 / NTHR;            // chunks of 8 elements per thread (tile = EXT x 64)
   static constexpr int CPR = EXT / 8;                   // OC: chunks per k-row
+  static constexpr int KCR = NTHR / 8;                  // KC: rows covered per pass
+  static constexpr int OCR = NTHR / CPR;                // OC: k-rows covered per pass
   static constexpr int OC_LD = EXT + 32;
   static constexpr int LDS_ELEMS = KC ? EXT * KC2_LD : BK2 * OC_LD;
   Raw<F32S> raw[NCH];
@@ -334,10 +336,10 @@ template <bool KC, bool F32S, int EXT> struct Oper {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       if (KC) {
-        const int64_t r = out0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 8;
+        const int64_t r = out0 + (tid >> 3) + KCR * i, k = k0 + (tid & 7) * 8;
         raw_load<F32S>(raw[i], P, r * ld + k, r < out_lim && k < k_lim);
       } else {
-        const int64_t k = k0 + tid / CPR + (256 / CPR) * i, o = out0 + (tid % CPR) * 8;
+        const int64_t k = k0 + tid / CPR + OCR * i, o = out0 + (tid % CPR) * 8;
         raw_load<F32S>(raw[i], P, k * ld + o, k < k_lim && o < out_lim);
       }
     }
@@ -346,8 +348,8 @@ template <bool KC, bool F32S, int EXT> struct Oper {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const bf16x8 w = raw_to_bf16<F32S>(raw[i]);
-      if (KC) *reinterpret_cast<bf16x8*>(&S[((tid >> 3) + 32 * i) * KC2_LD + (tid & 7) * 8]) = w;
-      else *reinterpret_cast<bf16x8*>(&S[(tid / CPR + (256 / CPR) * i) * OC_LD + (tid % CPR) * 8]) = w;
+      if (KC) *reinterpret_cast<bf16x8*>(&S[((tid >> 3) + KCR * i) * KC2_LD + (tid & 7) * 8]) = w;
+      else *reinterpret_cast<bf16x8*>(&S[(tid / CPR + OCR * i) * OC_LD + (tid % CPR) * 8]) = w;
     }
   }
   // MFMA 32x32x16 fragment for output rows obase..obase+31, k-substep ks (0..3)
@@ -369,20 +371,35 @@ template <bool KC, bool F32S, int EXT> struct Oper {
   }
 };
 
-template <bool A_KC, bool B_KC, bool A_F32, bool B_F32, int MT>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
-  constexpr int BM2 = 64 * MT;
-  typedef Oper<A_KC, A_F32, BM2> OA;
-  typedef Oper<B_KC, B_F32, 128> OB;
-  constexpr int STAGE = OA::LDS_ELEMS + OB::LDS_ELEMS;
-  constexpr int CS_BYTES = BM2 * CS_LD * 4;
-  constexpr int SMEM_BYTES = (2 * STAGE * 2 > CS_BYTES) ? 2 * STAGE * 2 : CS_BYTES;
+// LDS-lean schedule: ONE LDS stage (A+B <= 40 KiB) + the next k-tile prefetched in registers, and the epilogue staged
+// 64 rows at a time (33 KiB) -> 4 workgroups per CU.  Counters on MI355X (rocprofv3 PMC, NT 8192x1536x384): with the
+// previous double-buffered 74 KiB layout only 2 workgroups fit per CU and waves sat 47 % in s_waitcnt / barriers with
+// the MFMA pipe 12 % busy; residency, not per-workgroup pipelining, is what hides the L2/HBM round trips here.
+// Wave grid WM x 2, each wave (32*MT) x 64: tiles 64x128 (MT 1), 128x128 (MT 2), 256x128 (MT 4: 128x64 per wave, 2 wg/CU).
+// The operand stream through the vector memory path sustains only ~15 B/clk/CU here (measured: ~1 us per 64-deep
+// k-tile of a 64x128 tile), so FLOPs per loaded byte -- the tile size -- is what sets the MFMA rate.
+template <bool A_KC, bool B_KC, bool A_F32, bool B_F32, int MT, int WM>
+__global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void gemm2_kernel(Params p) {
+  constexpr int BM2 = 32 * MT * WM, NTHR = 128 * WM;
+  typedef Oper<A_KC, A_F32, BM2, NTHR> OA;
+  typedef Oper<B_KC, B_F32, 128, NTHR> OB;
+  constexpr int STAGE_BYTES = (OA::LDS_ELEMS + OB::LDS_ELEMS) * 2;
+  constexpr int CS_BYTES = 64 * CS_LD * 4;                     // half-tile (64 rows) fp32 staging
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
   __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];
-  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  bf16* As = reinterpret_cast<bf16*>(smem_raw);
+  bf16* Bs = As + OA::LDS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t tile_n = blockIdx.x % p.ntiles_n, tile_m = blockIdx.x / p.ntiles_n;
+  const int wm = wave >> 1, wn = wave & 1;      // wm in [0, WM)
+  // XCD-aware remap (speed only): workgroups are dealt round-robin over the 8 XCDs, so give each XCD a CONTIGUOUS
+  // range of tiles -- tiles that share an A panel (same tile_m) then hit the same L2.  Bijective for any grid size.
+  int64_t bid = blockIdx.x;
+  {
+    const int64_t nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int64_t tile_n = bid % p.ntiles_n, tile_m = bid / p.ntiles_n;
   const int64_t m0 = tile_m * BM2, n0 = tile_n * 128;
   const int64_t kbeg = (int64_t)blockIdx.y * p.k_chunk;
   const int64_t kend = min(p.K, kbeg + p.k_chunk);
@@ -396,26 +413,25 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // fused bias gradient (TN only): threads own a column pair of the A tile and a slice of its 64 k-rows
+  constexpr int CPAIRS = BM2 / 2, TPP = NTHR / CPAIRS, KSL = BK2 / TPP;
+  const bool do_colsum = !A_KC && p.colsum != nullptr && tile_n == 0;
+  float cs0 = 0.f, cs1 = 0.f;
+
   OA oa;
   OB ob;
   oa.load(p.A, p.lda, m0, p.M, kbeg, kend, tid);
   ob.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-  oa.store(smem, tid);
-  ob.store(smem + OA::LDS_ELEMS, tid);
-  if (nk > 1) {
-    oa.load(p.A, p.lda, m0, p.M, kbeg + BK2, kend, tid);
-    ob.load(p.B, p.ldb, n0, p.N, kbeg + BK2, kend, tid);
-  }
-  __syncthreads();
-
-  // fused bias gradient (TN only): threads own a column pair of the A tile and a slice of its 64 k-rows
-  constexpr int CPAIRS = BM2 / 2, TPP = 256 / CPAIRS, KSL = BK2 / TPP;
-  const bool do_colsum = !A_KC && p.colsum != nullptr && tile_n == 0;
-  float cs0 = 0.f, cs1 = 0.f;
 
   for (int kt = 0; kt < nk; ++kt) {
-    const bf16* As = smem + (kt & 1) * STAGE;
-    const bf16* Bs = As + OA::LDS_ELEMS;
+    __syncthreads();                       // previous tile fully consumed
+    oa.store(As, tid);
+    ob.store(Bs, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {                     // next tile's global loads fly under the MFMAs below
+      oa.load(p.A, p.lda, m0, p.M, kbeg + (int64_t)(kt + 1) * BK2, kend, tid);
+      ob.load(p.B, p.ldb, n0, p.N, kbeg + (int64_t)(kt + 1) * BK2, kend, tid);
+    }
     if (!A_KC && do_colsum) {
       const int cp = tid % CPAIRS, k0s = (tid / CPAIRS) * KSL;
 #pragma unroll
@@ -438,17 +454,8 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
         acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) {   // tile kt+1 sits in registers: park it in the other LDS buffer, then fetch tile kt+2
-      bf16* An = smem + ((kt + 1) & 1) * STAGE;
-      oa.store(An, tid);
-      ob.store(An + OA::LDS_ELEMS, tid);
-      if (kt + 2 < nk) {
-        oa.load(p.A, p.lda, m0, p.M, kbeg + (int64_t)(kt + 2) * BK2, kend, tid);
-        ob.load(p.B, p.ldb, n0, p.N, kbeg + (int64_t)(kt + 2) * BK2, kend, tid);
-      }
-    }
-    __syncthreads();
   }
+  __syncthreads();
 
   if (!A_KC && do_colsum) {   // fold the k-slices of every column pair (fixed order) and emit this block's partial sums
     float* red = reinterpret_cast<float*>(smem_raw);           // [TPP][BM2]
@@ -465,81 +472,90 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(Params p) {
     }
     __syncthreads();
   }
-  // ---------------- epilogue through LDS: accumulators -> Cs[BM2][132] fp32 -> 8-wide coalesced rows
+
+  // ---------------- epilogue through LDS, 64 rows (one 32-row MFMA tile of each wave row) at a time
   float* Cs = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Cs[(wm * 32 * MT + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS_LD + wn * 64 + nt * 32 + (lane & 31)] =
-            acc[mt][nt][r];
-  __syncthreads();
   const bool first_split = (blockIdx.y == 0);
   const int col = (tid & 15) * 8;
   const int64_t n = n0 + col;
-  if (n >= p.N) return;
   float bias[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias[j] = 0.f;
-  if (p.bias != nullptr && first_split && p.ws == nullptr) {
+  if (n < p.N && p.bias != nullptr && first_split && p.ws == nullptr) {
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
     bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
   }
+  constexpr int NGRP = BM2 / 64;                 // 64-row groups staged one at a time
 #pragma unroll
-  for (int i = 0; i < BM2 / 16; ++i) {
-    const int row = (tid >> 4) + 16 * i;
-    const int64_t m = m0 + row;
-    if (m >= p.M) continue;
-    float v[8];
-    {
-      const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col]);
-      const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col + 4]);
-      v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+  for (int g = 0; g < NGRP; ++g) {
+    if (g > 0) __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int unit = wm * MT + mt;              // 32-row unit of the tile owned by this wave
+      if ((unit >> 1) != g) continue;             // wave-uniform
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[((unit & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS_LD + wn * 64 + nt * 32 + (lane & 31)] = acc[mt][nt][r];
     }
-    if (p.split_k > 1 && p.ws != nullptr) {   // deterministic split-K: raw partial slab
-      st8_from_f32(p.ws, CSTS_F32, ((int64_t)blockIdx.y * p.M + m) * p.N + n, v);
-      continue;
+    __syncthreads();
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 1024 / NTHR; ++i) {
+      const int row = (tid >> 4) + (NTHR / 16) * i;                         // 0..63 inside the group
+      const int64_t m = m0 + g * 64 + row;
+      if (m >= p.M) continue;
+      float v[8];
+      {
+        const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col + 4]);
+        v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+      }
+      if (p.split_k > 1 && p.ws != nullptr) {   // deterministic split-K: raw partial slab
+        st8_from_f32(p.ws, CSTS_F32, ((int64_t)blockIdx.y * p.M + m) * p.N + n, v);
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bias[j];
+      if (p.split_k > 1) {
+        float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(c + j, v[j]);
+        continue;
+      }
+      if (p.epilogue == CSTS_EPI_GELU) {
+        if (p.aux != nullptr) st8_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+      } else if (p.epilogue == CSTS_EPI_DGELU) {
+        float h[8];
+        ld8_as_f32(p.aux, p.aux_dt, m * p.ldaux + n, h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(h[j]);
+      }
+      if (p.row_scale != nullptr) {
+        const float sc = p.row_scale[m / p.rows_per_scale];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+      }
+      if (p.residual != nullptr) {
+        const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+        float rr[8];
+        ld8_as_f32(p.residual, p.r_dt, rm * p.ldr + n, rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+      }
+      st8_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += bias[j];
-    if (p.split_k > 1) {
-      float* c = reinterpret_cast<float*>(p.C) + m * p.ldc + n;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(c + j, v[j]);
-      continue;
-    }
-    if (p.epilogue == CSTS_EPI_GELU) {
-      if (p.aux != nullptr) st8_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-    } else if (p.epilogue == CSTS_EPI_DGELU) {
-      float h[8];
-      ld8_as_f32(p.aux, p.aux_dt, m * p.ldaux + n, h);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(h[j]);
-    }
-    if (p.row_scale != nullptr) {
-      const float sc = p.row_scale[m / p.rows_per_scale];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] *= sc;
-    }
-    if (p.residual != nullptr) {
-      const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-      float rr[8];
-      ld8_as_f32(p.residual, p.r_dt, rm * p.ldr + n, rr);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += rr[j];
-    }
-    st8_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
   }
 }
 
 template <bool A_KC, bool B_KC, bool A_F32, bool B_F32>
-void launch2(const Params& p, int mt, dim3 grid, hipStream_t s) {
-  if (mt == 2) hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 2>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 1>), grid, dim3(256), 0, s, p);
+void launch2(const Params& p, int bm, dim3 grid, hipStream_t s) {
+  if (bm == 256) hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 4, 2>), grid, dim3(256), 0, s, p);
+  else if (bm == 128) hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 2, 2>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 1, 2>), grid, dim3(256), 0, s, p);
 }
 
 // v2 needs every 8-element chunk to be whole and 16-byte aligned
@@ -614,9 +630,11 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   int64_t mtiles = cdiv(a->M, BM);
   CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
   if (use_v2) {
-    // 64-row tiles when the 128-row grid cannot give every CU at least two workgroups
-    const int mt = (mtiles * p.ntiles_n * nsplit >= 512) ? 2 : 1;
-    mtiles = cdiv(a->M, 64 * mt);
+    // largest row tile (256 / 128 / 64) that still gives every CU a workgroup
+    const int64_t per = (int64_t)p.ntiles_n * nsplit;
+    int mt = (cdiv(a->M, 256) * per >= 256) ? 256 : ((cdiv(a->M, 128) * per >= 256) ? 128 : 64);
+    if (mt == 256 && a->a_dt == CSTS_F32) mt = 128;   // fp32 A staging registers do not fit beside a 128x64 accumulator
+    mtiles = cdiv(a->M, mt);
     dim3 grid2((unsigned)(mtiles * p.ntiles_n), (unsigned)nsplit, 1);
     const bool af = a->a_dt == CSTS_F32, bf = a->b_dt == CSTS_F32;
     if (a->layout == CSTS_GEMM_NT) {

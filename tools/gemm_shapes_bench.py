@@ -10,9 +10,9 @@ out = []
 for lo, M, N, K, sp, calls, *_ in rows:
     M, N, K, sp, calls = int(M), int(N), int(K), int(sp), int(calls) // 2
     if lo == "NT":
-        A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(N, K, device=dev); lda, ldb = K, K
+        A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(N, K, device=dev).bfloat16(); lda, ldb = K, K
     elif lo == "NN":
-        A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(K, N, device=dev); lda, ldb = K, N
+        A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(K, N, device=dev).bfloat16(); lda, ldb = K, N
     else:
         A = torch.randn(K, M, device=dev).bfloat16(); B = torch.randn(K, N, device=dev).bfloat16(); lda, ldb = M, N
         sp = ops._wgrad_split(M, N, K)
