@@ -9,52 +9,86 @@ namespace {
 
 constexpr int MAXV = 12;  // C <= 768
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, void* __restrict__ y, int y_dt,
+// compile-time dtypes: no branch sits between a load and the next one, so a wave keeps R rows x NV loads in flight
+template <bool F32> __device__ __forceinline__ float ldt(const void* p, int64_t i) {
+  if constexpr (F32) return reinterpret_cast<const float*>(p)[i];
+  else return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+}
+template <bool F32> __device__ __forceinline__ void stt(void* p, int64_t i, float v) {
+  if constexpr (F32) reinterpret_cast<float*>(p)[i] = v;
+  else reinterpret_cast<bf16*>(p)[i] = (bf16)v;
+}
+
+// one wave handles R rows per iteration (R*NV independent loads), two-pass statistics in registers
+template <int NV, int R, bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, void* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
                                                      int C, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t row = wave; row < rows; row += nwaves) {
-    float v[NV];
-    float s = 0.f;
+  float gm[NV], bt[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = lane + 64 * j;
-      v[j] = c < C ? ld_as_f32(x, x_dt, row * C + c) : 0.f;
-      s += v[j];
-    }
-    const float mu = wave_sum(s) / C;
-    float q = 0.f;
+  for (int j = 0; j < NV; ++j) {
+    const int c = lane + 64 * j;
+    gm[j] = c < C ? gamma[c] : 0.f;
+    bt[j] = c < C ? beta[c] : 0.f;
+  }
+  const float invC = 1.f / C;
+  for (int64_t row0 = wave * R; row0 < rows; row0 += nwaves * R) {
+    float v[R][NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = lane + 64 * j;
-      const float d = c < C ? v[j] - mu : 0.f;
-      q += d * d;
-    }
-    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = min(row0 + r, rows - 1);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) st_from_f32(y, y_dt, row * C + c, (v[j] - mu) * rs * gamma[c] + beta[c]);
+      for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        v[r][j] = ldt<XF32>(x, row * C + min(c, C - 1));
+      }
     }
-    if (lane == 0) {
-      if (mean) mean[row] = mu;
-      if (rstd) rstd[row] = rs;
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) s += (lane + 64 * j < C) ? v[r][j] : 0.f;
+      mu[r] = wave_sum(s) * invC;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const float d = (lane + 64 * j < C) ? v[r][j] - mu[r] : 0.f;
+        q += d * d;
+      }
+      rs[r] = rsqrtf(wave_sum(q) * invC + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = row0 + r;
+      if (row >= rows) break;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < C) stt<YF32>(y, row * C + c, (v[r][j] - mu[r]) * rs[r] * gm[j] + bt[j]);
+      }
+      if (lane == 0) {
+        if (mean) mean[row] = mu[r];
+        if (rstd) rstd[row] = rs[r];
+      }
     }
   }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // per-wave partial dgamma/dbeta are summed through LDS and written to ws[block][2*C]
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int dy_dt, const void* __restrict__ x,
-                                                     int x_dt, const float* __restrict__ gamma,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     void* __restrict__ dx, int dx_dt, float* __restrict__ ws,
-                                                     int64_t rows, int C) {
+template <int NV, int R, bool DYF32, bool XF32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, void* __restrict__ dx,
+                                                     float* __restrict__ ws, int64_t rows, int C) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2*C]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;
@@ -66,29 +100,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const int c = lane + 64 * j;
     gm[j] = c < C ? gamma[c] : 0.f;
   }
-  for (int64_t row = wave; row < rows; row += nwaves) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NV], g[NV];
-    float s1 = 0.f, s2 = 0.f;
+  const float invC = 1.f / C;
+  for (int64_t row0 = wave * R; row0 < rows; row0 += nwaves * R) {
+    float d[R][NV], xv[R][NV], mu[R], rs[R];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) {
-        const float d = ld_as_f32(dy, dy_dt, row * C + c);
-        xh[j] = (ld_as_f32(x, x_dt, row * C + c) - mu) * rs;
-        g[j] = d * gm[j];
-        dg[j] += d * xh[j];
-        db[j] += d;
-      } else { xh[j] = 0.f; g[j] = 0.f; }
-      s1 += g[j];
-      s2 += g[j] * xh[j];
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = min(row0 + r, rows - 1);
+      mu[r] = mean[row];
+      rs[r] = rstd[row];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int64_t i = row * C + min(lane + 64 * j, C - 1);
+        d[r][j] = ldt<DYF32>(dy, i);
+        xv[r][j] = ldt<XF32>(x, i);
+      }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = lane + 64 * j;
-      if (c < C) st_from_f32(dx, dx_dt, row * C + c, rs * (g[j] - s1 - xh[j] * s2));
+    for (int r = 0; r < R; ++r) {
+      const bool live = row0 + r < rows;
+      float s1 = 0.f, s2 = 0.f, xh[NV], g[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const bool ok = live && (lane + 64 * j < C);
+        const float dd = ok ? d[r][j] : 0.f;
+        xh[j] = ok ? (xv[r][j] - mu[r]) * rs[r] : 0.f;
+        g[j] = dd * gm[j];
+        dg[j] += dd * xh[j];
+        db[j] += dd;
+        s1 += g[j];
+        s2 += g[j] * xh[j];
+      }
+      s1 = wave_sum(s1) * invC;
+      s2 = wave_sum(s2) * invC;
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int c = lane + 64 * j;
+          if (c < C) stt<XF32>(dx, (row0 + r) * C + c, rs[r] * (g[j] - s1 - xh[j] * s2));
+        }
+      }
     }
   }
 #pragma unroll
@@ -140,24 +190,42 @@ extern "C" int csts_reduce_rows(const float* ws, float* out, int64_t nrows, int6
   return 0;
 }
 
-static int ln_grid(int64_t rows) { return (int)std::min<int64_t>(cdiv(rows, 4), 4096); }
+template <int NV, int R>
+static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const void* x, const float* g, const float* b, void* y,
+                          float* mean, float* rstd, int64_t rows, int C, float eps) {
+  if (xf && yf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, true, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+  else if (xf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, true, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+  else if (yf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, false, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+  else hipLaunchKernelGGL((ln_fwd_kernel<NV, R, false, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+}
+template <int NV, int R>
+static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
+                          const float* mean, const float* rstd, void* dx, float* ws, int64_t rows, int C) {
+  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+}
+static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
+static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
+static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 1024); }
 
 extern "C" int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt,
                                   float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t stream) {
   CSTS_REQUIRE(x && gamma && beta && y, "null pointer");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
-  dim3 grid(ln_grid(rows)), block(256);
-  if (C <= 128) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, stream, x, x_dt, gamma, beta, y, y_dt, mean, rstd, rows, C, eps);
-  else if (C <= 192) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, stream, x, x_dt, gamma, beta, y, y_dt, mean, rstd, rows, C, eps);
-  else if (C <= 384) hipLaunchKernelGGL(ln_fwd_kernel<6>, grid, block, 0, stream, x, x_dt, gamma, beta, y, y_dt, mean, rstd, rows, C, eps);
-  else hipLaunchKernelGGL(ln_fwd_kernel<12>, grid, block, 0, stream, x, x_dt, gamma, beta, y, y_dt, mean, rstd, rows, C, eps);
+  const dim3 grid((unsigned)ln_fwd_blocks(rows, C));
+  const bool xf = x_dt == CSTS_F32, yf = y_dt == CSTS_F32;
+  if (C <= 128) ln_fwd_launch<2, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  else if (C <= 192) ln_fwd_launch<3, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  else if (C <= 384) ln_fwd_launch<6, 2>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  else ln_fwd_launch<12, 1>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" size_t csts_layernorm_bwd_workspace(int64_t rows, int C) {
-  const int64_t nb = std::min<int64_t>(cdiv(rows, 4 * 2), 2048);
-  return (size_t)nb * 2 * C * sizeof(float);
+  return (size_t)ln_bwd_blocks(rows, C) * 2 * C * sizeof(float);
 }
 
 extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma,
@@ -167,15 +235,17 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "null pointer");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
   CSTS_REQUIRE(dbeta == dgamma + C, "dgamma/dbeta must be one contiguous [2*C] buffer");
-  const int64_t nb = std::min<int64_t>(cdiv(rows, 4 * 2), 2048);
+  CSTS_REQUIRE(dx_dt == x_dt, "dx must have the dtype of x");
+  const int64_t nb = ln_bwd_blocks(rows, C);
   CSTS_REQUIRE(ws_bytes >= (size_t)nb * 2 * C * sizeof(float), "workspace too small");
-  dim3 grid((unsigned)nb), block(256);
+  const dim3 grid((unsigned)nb);
   const size_t sh = (size_t)4 * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
-  if (C <= 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, sh, stream, dy, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, ws, rows, C);
-  else if (C <= 192) hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, sh, stream, dy, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, ws, rows, C);
-  else if (C <= 384) hipLaunchKernelGGL(ln_bwd_kernel<6>, grid, block, sh, stream, dy, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, ws, rows, C);
-  else hipLaunchKernelGGL(ln_bwd_kernel<12>, grid, block, sh, stream, dy, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, ws, rows, C);
+  const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
+  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
+  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
+  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
+  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
   CSTS_LAUNCH_CHECK();
   csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
   CSTS_LAUNCH_CHECK();
