@@ -25,17 +25,21 @@ struct AttnP {
   int64_t do_bs, do_ts, do_hs, dq_bs, dq_ts, dq_hs, dk_bs, dk_ts, dk_hs, dv_bs, dv_ts, dv_hs;
   float scale, scale_log2;
   int mask_mode, mask_T, mask_HW;
+  float mask_inv_hw;
   int q_chunk, nsplit;
 };
 
 __device__ __forceinline__ int rowoff(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__device__ __forceinline__ bool is_masked(const AttnP& p, int q, int k) {
-  if (p.mask_mode == 0) return false;
+// frame index of a token of the spatial-fusion sequence [T*HW visual tokens, T audio tokens] (av_attention.py:337-346).
+// Branch-free on purpose; the quotient comes from a float multiply, exact while T*HW < 2^20 (checked on the host).
+__device__ __forceinline__ int frame_of(const AttnP& p, int x) {
   const int thw = p.mask_T * p.mask_HW;
-  const int fq = q < thw ? q / p.mask_HW : q - thw;
-  const int fk = k < thw ? k / p.mask_HW : k - thw;
-  return fq != fk;   // av_attention.py:337-346: -1e8 outside the same-frame blocks
+  const int f = (int)(((float)x + 0.5f) * p.mask_inv_hw);
+  return x < thw ? f : x - thw;
+}
+__device__ __forceinline__ bool is_masked(const AttnP& p, int q, int k) {
+  return (p.mask_mode != 0) & (frame_of(p, q) != frame_of(p, k));   // -1e8 outside the same-frame blocks
 }
 
 template <int HD, bool F32> struct RowFrag;   // B-operand fragments of one [HD]-row per lane (lane&31 = row)
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
   float m = -1e30f, lsum = 0.f;
+  const int fq = frame_of(p, qi);
   const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
   const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
 
@@ -274,31 +279,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       for (int r = 0; r < 16; ++r) S[kt][r] = 0.f;
       score<HD, C::LD_ROW, F32>(S[kt], Ks + kt * 32 * C::LD_ROW, qf, lane);
     }
-    float mx = -1e30f;
+    // tiles that need no masking (all but the ragged last one, and every tile of unmasked attention) skip the
+    // per-element key tests; the softmax scale rides on the exp2 argument's fma (S stays unscaled)
+    if ((k0 + C::KVBLK > p.Nk) || p.mask_mode != 0) {
+      // dead keys sit at -2^16 in the exp2 domain: far below any live score, yet small enough that the fma's
+      // rounding error (2^16 * 2^-24) cannot blow up exp2 while a row has seen dead keys only (that state is
+      // wiped by alpha = 0 at the row's first live key)
+      const float dead_raw = -65536.f / p.scale_log2;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kt * 32 + rowoff(r, h);
+          const bool dead = (key >= p.Nk) | ((p.mask_mode != 0) & (frame_of(p, key) != fq));
+          S[kt][r] = dead ? dead_raw : S[kt][r];
+        }
+    }
+    float mx = S[0][0];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kt * 32 + rowoff(r, h);
-        float v = S[kt][r] * p.scale_log2;
-        if (key >= p.Nk || is_masked(p, qi, key)) v = -1e30f;
-        S[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    m = mn;
-    lsum *= alpha;
+    const float ms = mx * p.scale_log2;
+    // lazy running max: rescale only when some row's max grew by more than 2^8 (p <= 256 keeps full fp32/bf16
+    // precision and the final 1/lsum normalisation makes the result independent of the reference point)
+    const bool grow = ms > m + 8.f;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float mn = grow ? ms : m;
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      m = mn;
+      lsum *= alpha;
 #pragma unroll
-    for (int d = 0; d < HD / 32; ++d)
+      for (int d = 0; d < HD / 32; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+        for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+    }
+    const float negm = -m;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(S[kt][r] - m);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], p.scale_log2, negm));
         S[kt][r] = e;
         lsum += e;
       }
@@ -331,6 +353,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   dof.load(p.dO, (int64_t)b * p.do_bs + (int64_t)qi * p.do_ts + (int64_t)head * p.do_hs, h);
   const float L = p.LSE[((int64_t)b * p.H + head) * p.Nq + qi];
   const float dl = p.delta[((int64_t)b * p.H + head) * p.Nq + qi];
+  const float negL = -L;
+  const int fq = frame_of(p, qi);
   f32x16 acc[HD / 32];
 #pragma unroll
   for (int d = 0; d < HD / 32; ++d)
@@ -341,6 +365,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 
   tile_loop<HD, C::KVBLK, C::LD_ROW, C::LD_ROW, F32>(smem, p.K, kbase, p.k_ts, p.V, vbase, p.v_ts, 0, p.Nk, tid,
                                                      [&](const T* Ks, const T* Vs, int k0) {
+    const bool slow = (k0 + C::KVBLK > p.Nk) || p.mask_mode != 0;   // wave-uniform
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       f32x16 S, dP;
@@ -348,12 +373,18 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
       for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
       score<HD, C::LD_ROW, F32>(S, Ks + kt * 32 * C::LD_ROW, qf, lane);
       score<HD, C::LD_ROW, F32>(dP, Vs + kt * 32 * C::LD_ROW, dof, lane);
+      if (slow) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + kt * 32 + rowoff(r, h);
-        const bool dead = key >= p.Nk || is_masked(p, qi, key);
-        const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * p.scale_log2 - L);
-        S[r] = pr * (dP[r] - dl);
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kt * 32 + rowoff(r, h);
+          const bool dead = (key >= p.Nk) | ((p.mask_mode != 0) & (frame_of(p, key) != fq));
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], p.scale_log2, negL));
+          const float pr = dead ? 0.f : e;
+          S[r] = pr * (dP[r] - dl);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], p.scale_log2, negL)) * (dP[r] - dl);
       }
       pv<HD, C::LD_ROW, F32>(acc, Ks + kt * 32 * C::LD_ROW, S, lane);
     }
@@ -390,9 +421,12 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   const int qbeg = split * p.q_chunk, qend = min(p.Nq, qbeg + p.q_chunk);
   const float* Lrow = p.LSE + ((int64_t)b * p.H + head) * p.Nq;     // per-query statistics: wave-uniform (broadcast) loads
   const float* Drow = p.delta + ((int64_t)b * p.H + head) * p.Nq;
+  const int fk = frame_of(p, ki);
+  const bool stats_vec = (((uintptr_t)Lrow | (uintptr_t)Drow) & 15) == 0 && (qbeg & 3) == 0;
 
   tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
                                                  [&](const T* Qs, const T* dOs, int q0) {
+    const bool slow = (q0 + QBLK > qend) || p.mask_mode != 0;   // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       f32x16 S, dP;
@@ -400,14 +434,37 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
       score<HD, C::LD_ROW, F32>(S, Qs + qt * 32 * C::LD_ROW, kf, lane);
       score<HD, C::LD_ROW, F32>(dP, dOs + qt * 32 * C::LD_ROW, vf, lane);
+      if (slow || !stats_vec) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = q0 + qt * 32 + rowoff(r, h);
-        const bool dead = q >= qend || !kvalid || is_masked(p, q, ki);
-        const int qc = q < qend ? q : qend - 1;
-        const float pr = dead ? 0.f : __builtin_amdgcn_exp2f(S[r] * p.scale_log2 - Lrow[qc]);
-        S[r] = pr;
-        dP[r] = pr * (dP[r] - Drow[qc]);
+        for (int r = 0; r < 16; ++r) {
+          const int q = q0 + qt * 32 + rowoff(r, h);
+          // clamped (invalid) key lanes are never stored, so they need no masking
+          const bool dead = (q >= qend) | ((p.mask_mode != 0) & (frame_of(p, q) != fk));
+          const int qc = q < qend ? q : qend - 1;
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], p.scale_log2, -Lrow[qc]));
+          const float pr = dead ? 0.f : e;
+          S[r] = pr;
+          dP[r] = pr * (dP[r] - Drow[qc]);
+        }
+      } else {
+        // the 4 registers of a quad are 4 consecutive queries: one 16-byte load of LSE / delta each
+        float4 L4[4], D4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = q0 + qt * 32 + 8 * j + 4 * h;
+          L4[j] = *reinterpret_cast<const float4*>(Lrow + q);
+          D4[j] = *reinterpret_cast<const float4*>(Drow + q);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float l[4] = {L4[j].x, L4[j].y, L4[j].z, L4[j].w}, dd[4] = {D4[j].x, D4[j].y, D4[j].z, D4[j].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * j + i], p.scale_log2, -l[i]));
+            S[4 * j + i] = pr;
+            dP[4 * j + i] = pr * (dP[4 * j + i] - dd[i]);
+          }
+        }
       }
       pv<HD, C::LD_ROW, F32>(dV, dOs + qt * 32 * C::LD_ROW, S, lane);
       pv<HD, C::LD_ROW, F32>(dK, Qs + qt * 32 * C::LD_ROW, dP, lane);
@@ -506,6 +563,7 @@ int fill(const csts_attn_args* a, AttnP& p) {
   p.scale = a->scale;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.mask_mode = a->mask_mode; p.mask_T = a->mask_T; p.mask_HW = a->mask_HW;
+  p.mask_inv_hw = (a->mask_mode != 0 && a->mask_HW > 0) ? 1.f / (float)a->mask_HW : 0.f;
   p.q_chunk = 0; p.nsplit = 1;
   return 0;
 }
@@ -538,7 +596,7 @@ void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
                    strides_ok((a)->v_strides, (a)->dtype),                                             \
                "strides must keep 16-byte row alignment");                                              \
   if ((a)->mask_mode == CSTS_MASK_SPATIAL)                                                              \
-  CSTS_REQUIRE((a)->Nq == (a)->mask_T * (a)->mask_HW + (a)->mask_T && (a)->Nk == (a)->Nq, "spatial mask needs Nq == Nk == T*HW + T")
+  CSTS_REQUIRE((a)->mask_HW > 0 && (a)->Nq < (1 << 20) && (a)->Nq == (a)->mask_T * (a)->mask_HW + (a)->mask_T && (a)->Nk == (a)->Nq, "spatial mask needs Nq == Nk == T*HW + T < 2^20")
 
 enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
 template <int HD, bool F32>

@@ -230,9 +230,13 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
   }
 }
 
-// C = epilogue(sum_s ws[s]) for the deterministic split-K path (VEC elements per thread; VEC = 4 needs N % 4 == 0)
-template <int VEC>
+// C = epilogue(sum_s ws[s]) for the deterministic split-K path (VEC elements per thread; VEC = 4 needs N % 4 == 0).
+// SL slab-lanes share one output vector (small outputs with many slabs would otherwise be one long serial chain per
+// thread); lane l sums slabs l, l+SL, ... in order, lanes are combined in order through LDS -> reproducible.
+template <int VEC, int SL>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit) {
+  constexpr int EV = 256 / SL;   // output vectors per block
+  __shared__ float red[SL > 1 ? SL : 1][EV][VEC];
   const int64_t total = p.M * p.N;
   if (p.colsum != nullptr && p.colsum_ws != nullptr) {   // fused bias-gradient partials: colsum[m] = sum_s colsum_ws[s][m]
     for (int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += (int64_t)gridDim.x * blockDim.x) {
@@ -241,24 +245,50 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit
       p.colsum[m] = t;
     }
   }
-  for (int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x * VEC) {
-    const int64_t m = idx / p.N, n0 = idx - m * p.N;
+  const int e = threadIdx.x % EV, sl = threadIdx.x / EV;
+  const int64_t nvec = (total + VEC - 1) / VEC;
+  for (int64_t v0 = (int64_t)blockIdx.x * EV; v0 < nvec; v0 += (int64_t)gridDim.x * EV) {
+    const int64_t idx = (v0 + e) * VEC;
+    const bool live = v0 + e < nvec;
     float v[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) v[j] = p.bias ? p.bias[n0 + j] : 0.f;
-    for (int sidx = 0; sidx < nsplit; ++sidx) {
+    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+    if (live) {
+      int sidx = sl;
       if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p.ws + (int64_t)sidx * total + idx);
-        v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+        for (; sidx + 3 * SL < nsplit; sidx += 4 * SL) {
+          float4 t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(p.ws + (int64_t)(sidx + u * SL) * total + idx);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { v[0] += t[u].x; v[1 % VEC] += t[u].y; v[2 % VEC] += t[u].z; v[3 % VEC] += t[u].w; }
+        }
+        for (; sidx < nsplit; sidx += SL) {
+          const float4 t = *reinterpret_cast<const float4*>(p.ws + (int64_t)sidx * total + idx);
+          v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+        }
       } else {
-        v[0] += p.ws[(int64_t)sidx * total + idx];
+        for (; sidx < nsplit; sidx += SL) v[0] += p.ws[(int64_t)sidx * total + idx];
       }
     }
+    if (SL > 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[sl][e][j] = v[j];
+      __syncthreads();
+      if (sl == 0) {
+#pragma unroll
+        for (int l = 1; l < SL; ++l)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] += red[l][e][j];
+      }
+      __syncthreads();
+    }
+    if (sl != 0 || !live) continue;
+    const int64_t m = idx / p.N, n0 = idx - m * p.N;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int64_t n = n0 + j;
-      float x = v[j];
+      float x = v[j] + (p.bias ? p.bias[n] : 0.f);
       if (p.epilogue == CSTS_EPI_GELU) {
         if (p.aux != nullptr) st_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, x);
         x = gelu_f(x);
@@ -274,12 +304,19 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(Params p, int nsplit
     }
   }
 }
+template <int VEC>
+static void launch_finish_v(const Params& p, int nsplit, hipStream_t stream) {
+  const int64_t nvec = cdiv(p.M * p.N, VEC);
+  // slab-lanes only where the output alone cannot fill the chip (a function of the shape only -> reproducible)
+  const int sl = (nsplit >= 16 && nvec < 16384) ? 16 : ((nsplit >= 4 && nvec < 131072) ? 4 : 1);
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv(nvec, 256 / sl), 8192));
+  if (sl == 16) hipLaunchKernelGGL((splitk_finish_kernel<VEC, 16>), grid, dim3(256), 0, stream, p, nsplit);
+  else if (sl == 4) hipLaunchKernelGGL((splitk_finish_kernel<VEC, 4>), grid, dim3(256), 0, stream, p, nsplit);
+  else hipLaunchKernelGGL((splitk_finish_kernel<VEC, 1>), grid, dim3(256), 0, stream, p, nsplit);
+}
 static void launch_finish(const Params& p, int nsplit, hipStream_t stream) {
-  const int64_t total = p.M * p.N;
-  if (p.N % 4 == 0 && aligned16(p.ws))
-    hipLaunchKernelGGL(splitk_finish_kernel<4>, dim3((unsigned)std::min<int64_t>(cdiv(total, 1024), 4096)), dim3(256), 0, stream, p, nsplit);
-  else
-    hipLaunchKernelGGL(splitk_finish_kernel<1>, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0, stream, p, nsplit);
+  if (p.N % 4 == 0 && aligned16(p.ws)) launch_finish_v<4>(p, nsplit, stream);
+  else launch_finish_v<1>(p, nsplit, stream);
 }
 
 // =====================================================================================================

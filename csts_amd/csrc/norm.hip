@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int MAXV = 12;  // C <= 768
+constexpr int LN_BWD_WAVES = 8;  // 512-thread blocks: few, fat partial rows for the second-stage reduction
 
 // compile-time dtypes: no branch sits between a load and the next one, so a wave keeps R rows x NV loads in flight
 template <bool F32> __device__ __forceinline__ float ldt(const void* p, int64_t i) {
@@ -85,14 +86,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // per-wave partial dgamma/dbeta are summed through LDS and written to ws[block][2*C]
 template <int NV, int R, bool DYF32, bool XF32>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      float* __restrict__ ws, int64_t rows, int C) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2*C]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [LN_BWD_WAVES][2*C]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave = (int64_t)blockIdx.x * LN_BWD_WAVES + w;
+  const int64_t nwaves = (int64_t)gridDim.x * LN_BWD_WAVES;
   float dg[NV], db[NV], gm[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -147,8 +148,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     if (c < C) { red[w * 2 * C + c] = dg[j]; red[w * 2 * C + C + c] = db[j]; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x)
-    ws[(int64_t)blockIdx.x * 2 * C + i] = red[i] + red[2 * C + i] + red[4 * C + i] + red[6 * C + i];
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_BWD_WAVES; ++k) t += red[k * 2 * C + i];
+    ws[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
 }
 
 // out[j] = sum_i ws[i][j]   (deterministic second stage of every cross-block reduction in the library)
@@ -160,8 +165,15 @@ __global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restri
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int64_t j = (int64_t)blockIdx.x * 32 + tx;
   float s = 0.f;
-  if (j < ncols)
-    for (int64_t i = ty; i < nrows; i += RL) s += ws[i * ncols + j];
+  if (j < ncols) {
+    int64_t i = ty;
+    for (; i + 3 * RL < nrows; i += 4 * RL) {
+      const float a = ws[i * ncols + j], b = ws[(i + RL) * ncols + j], c = ws[(i + 2 * RL) * ncols + j],
+                  d = ws[(i + 3 * RL) * ncols + j];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; i < nrows; i += RL) s += ws[i * ncols + j];
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && j < ncols) {
@@ -201,14 +213,14 @@ static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const voi
 template <int NV, int R>
 static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
                           const float* mean, const float* rstd, void* dx, float* ws, int64_t rows, int C) {
-  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
-  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
-  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(256), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
 }
 static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
 static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
-static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 1024); }
+static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, LN_BWD_WAVES * rows_per_wave(C)), 512); }
 
 extern "C" int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt,
                                   float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t stream) {
@@ -239,7 +251,7 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   const int64_t nb = ln_bwd_blocks(rows, C);
   CSTS_REQUIRE(ws_bytes >= (size_t)nb * 2 * C * sizeof(float), "workspace too small");
   const dim3 grid((unsigned)nb);
-  const size_t sh = (size_t)4 * 2 * C * sizeof(float);
+  const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
   if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);

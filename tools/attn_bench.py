@@ -33,8 +33,10 @@ def run(B, H, Nq, Nk, hd, bwd):
     for _ in range(10): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 10 * 1e3
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 print(f"{'shape':12s} {'fwd us':>8s} {'TF/s':>7s} {'bwd us':>8s} {'TF/s':>7s}")
 for name, B, H, Nq, Nk, hd in SH:
+    if only and name != only: continue
     fl = 4.0 * B * H * Nq * Nk * hd
     tf = run(B, H, Nq, Nk, hd, False); tb = run(B, H, Nq, Nk, hd, True)
     print(f"{name:12s} {tf:8.1f} {fl/tf/1e6:7.1f} {tb:8.1f} {2.5*fl/tb/1e6:7.1f}")
