@@ -612,6 +612,26 @@ bool v2_ok(const csts_gemm_args* a) {
   return true;
 }
 
+// Row tile of the v2 kernel.  Mid-size problems here are latency-bound, not MFMA-bound (K is short: 96..3072), so the
+// tile is chosen for resident workgroups per CU rather than for arithmetic intensity; table fitted to sweeps of the
+// CSTS shapes on MI355X (tools/gemm_tile_sweep.py, profiles/r1_gemm_tile_sweep.txt).
+int pick_tile_rows(const csts_gemm_args* a, int64_t per) {
+  const bool a_f32 = a->a_dt == CSTS_F32;
+  if (a->tile_rows == 64 || a->tile_rows == 128 || (a->tile_rows == 256 && !a_f32)) return a->tile_rows;
+  int mt;
+  if (a->layout == CSTS_GEMM_TN) {
+    // weight gradients (split-K fills the chip): 128 rows, 256 only where it pads M no further and still leaves
+    // one workgroup per CU
+    const int64_t pad128 = cdiv(a->M, 128) * 128, pad256 = cdiv(a->M, 256) * 256;
+    mt = (!a_f32 && pad256 == pad128 && cdiv(a->M, 256) * per >= 256) ? 256 : 128;
+  } else {
+    // activations x weights, K = 96..3072: 128 rows once that gives >= 2.5 workgroups per CU, else 64
+    mt = (cdiv(a->M, 128) * per >= 640) ? 128 : 64;
+  }
+  while (mt > 64 && a->M <= mt / 2) mt /= 2;   // never tile wider than the problem
+  return mt;
+}
+
 template <bool A_KC, bool B_KC>
 void launch(const Params& p, int compute, dim3 grid, hipStream_t s) {
   if (compute == CSTS_F32) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(NT_), 0, s, p);
@@ -667,10 +687,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   int64_t mtiles = cdiv(a->M, BM);
   CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
   if (use_v2) {
-    // largest row tile (256 / 128 / 64) that still gives every CU a workgroup
-    const int64_t per = (int64_t)p.ntiles_n * nsplit;
-    int mt = (cdiv(a->M, 256) * per >= 256) ? 256 : ((cdiv(a->M, 128) * per >= 256) ? 128 : 64);
-    if (mt == 256 && a->a_dt == CSTS_F32) mt = 128;   // fp32 A staging registers do not fit beside a 128x64 accumulator
+    int mt = pick_tile_rows(a, p.ntiles_n * nsplit);
     mtiles = cdiv(a->M, mt);
     dim3 grid2((unsigned)(mtiles * p.ntiles_n), (unsigned)nsplit, 1);
     const bool af = a->a_dt == CSTS_F32, bf = a->b_dt == CSTS_F32;

@@ -57,7 +57,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------------- raw wrappers
 def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
-         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True,
+         residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True, tile_rows=0,
          want_colsum=False):
     a = L.GemmArgs()
     a.layout = layout
@@ -72,6 +72,7 @@ def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bia
     a.res_row_mod = res_row_mod
     a.row_scale, a.rows_per_scale = _p(row_scale), rows_per_scale
     a.compute, a.split_k = compute, split_k
+    a.tile_rows = tile_rows
     ws = None
     if split_k > 1 and deterministic:
         nb = _lib().csts_gemm_splitk_workspace(M, N, K, split_k)
