@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph (single GPU only)")
+    p.add_argument("--op-breakdown", default=None, help="write per-C-ABI-entry device time of one eager step to this file")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
     return p.parse_args()
 
@@ -95,6 +96,51 @@ class GemmTimer:
             f.write("layout M N K split calls total_ms avg_us TFLOPs GBps\n")
             for (lay, M, N, K, sp), (n, sec, fl, by) in rows:
                 f.write(f"{'NT NN TN'.split()[lay]} {M} {N} {K} {sp} {n} {sec*1e3:.3f} {sec/n*1e6:.1f} {fl*n/sec/1e12:.1f} {by*n/sec/1e9:.0f}\n")
+
+
+class OpTimer:
+    """HIP-event timing of EVERY C-ABI entry point (per-family device time of one eager single-stream step)."""
+
+    class _Proxy:
+        def __init__(self, lib, rec):
+            self._lib, self._rec = lib, rec
+
+        def __getattr__(self, name):
+            fn = getattr(self._lib, name)
+            if not name.startswith("csts_") or name.endswith("_workspace") or name in (
+                    "csts_last_error", "csts_abi_version", "csts_gemm_v2_eligible"):
+                return fn
+            rec = self._rec
+
+            def timed(*a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*a)
+                e1.record()
+                rec.append((name, e0, e1))
+                return rc
+            return timed
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        from csts_amd import lib as L
+        self._orig = L.load()
+        L._lib = OpTimer._Proxy(self._orig, self.rec)
+
+    def remove(self):
+        from csts_amd import lib as L
+        L._lib = self._orig
+
+    def summary(self, steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1 in self.rec:
+            a = agg.setdefault(name[5:], [0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+        return {k: {"calls": v[0] // steps, "ms": round(v[1] / steps, 3)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 
 
 def cpu_baseline(frames):
@@ -189,8 +235,27 @@ def main():
         for _ in range(2):
             torch.cuda._sleep(spin)
             eager_step()
-        core.two_streams = two
         gt.remove()
+        if args.op_breakdown:
+            ot = OpTimer()
+            ot.install()
+            torch.cuda._sleep(spin)
+            eager_step()
+            t_ev0, t_ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ot.rec.clear()
+            torch.cuda._sleep(spin)
+            t_ev0.record()
+            eager_step()
+            t_ev1.record()
+            ot.remove()
+            ops_ms = ot.summary(1)
+            tot = t_ev0.elapsed_time(t_ev1)
+            with open(args.op_breakdown, "w") as f:
+                f.write(f"single-stream eager step {tot:.2f} ms; C-ABI kernels {sum(v['ms'] for v in ops_ms.values()):.2f} ms; "
+                        f"torch-native remainder (optimizer, clip, autograd adds, casts, fills) {tot - sum(v['ms'] for v in ops_ms.values()):.2f} ms\n")
+                for k, v in ops_ms.items():
+                    f.write(f"{k:28s} {v['calls']:5d} calls {v['ms']:8.3f} ms\n")
+        core.two_streams = two
         agg = gt.summary()
         if args.dump_gemm:
             gt.dump_shapes(args.dump_gemm)

@@ -68,6 +68,17 @@ class Im2colGeom(C.Structure):
                 ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Kpad", C.c_int)]
 
 
+class OptTensor(C.Structure):
+    _fields_ = [("p", vp), ("m", vp), ("v", vp), ("w16", vp), ("n", i64), ("weight_decay", C.c_float), ("pad_", C.c_int)]
+
+
+class OptArgs(C.Structure):
+    _fields_ = [("chunk_tensor", vp), ("chunk_off", vp), ("nchunks", C.c_int), ("chunk_elems", C.c_int),
+                ("tensors", vp), ("grads", vp), ("ntensors", C.c_int),
+                ("partial", vp), ("state", vp), ("lr", vp),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_grad_norm", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/csts_hip.h declares
 _I, _F = C.c_int, C.c_float
 SYMBOLS = {
@@ -113,6 +124,7 @@ SYMBOLS = {
     "csts_rownorm_bwd": (_I, [vp, vp, vp, vp, i64, _I, _F, vp]),
     "csts_egonce_fwd": (_I, [vp, vp, vp, vp, _I, _F, vp]),
     "csts_egonce_bwd": (_I, [vp, vp, vp, vp, vp, _I, _F, vp]),
+    "csts_adamw_step": (_I, [C.POINTER(OptArgs), vp]),
 }
 
 _lib = None

@@ -99,10 +99,14 @@ class Block(nn.Module):
             self.proj = nn.Linear(dim, dim_out)
 
     def _drop_scales(self, B, device, keep_masks):
-        """Two independent per-sample scales (attention branch, MLP branch), drop_path of common.py:46-59."""
+        """Two independent per-sample scales (attention branch, MLP branch), drop_path of common.py:46-59.
+        keep_masks: (m1, m2) 0/1 masks (tests replay the reference's draws) or ("scales", s1, s2) drawn by
+        CSTS.forward for all blocks at once."""
         if self.drop_prob == 0.0 or not (self.training or keep_masks is not None):
             return None, None
         keep = 1.0 - self.drop_prob
+        if keep_masks is not None and len(keep_masks) == 3:
+            return keep_masks[1], keep_masks[2]
         if keep_masks is not None:
             m1, m2 = keep_masks
             m1, m2 = m1.to(device=device, dtype=torch.float32), m2.to(device=device, dtype=torch.float32)
@@ -302,11 +306,30 @@ class CSTS(nn.Module):
         for l in stale:
             l._w16 = torch.empty(l.weight.shape, dtype=torch.bfloat16, device=l.weight.device)
             l._w16_ver = -1
-        if self.training or any(l._w16_ver != l.weight._version for l in lins):
+        # With csts_amd.optim.FusedAdamW the optimizer kernel itself rewrites the shadows (w16_external): only an
+        # out-of-band weight change (load_state_dict, manual edit: bumps _version) needs a refresh here.
+        if (self.training and not getattr(self, "w16_external", False)) or any(l._w16_ver != l.weight._version for l in lins):
             with torch.no_grad():
                 torch._foreach_copy_([l._w16 for l in lins], [l.weight.detach() for l in lins])
             for l in lins:
                 l._w16_ver = l.weight._version
+
+    def _draw_drop_paths(self, B, device):
+        """All stochastic-depth scales of one forward in ONE draw (4 small kernels instead of 4 per block branch):
+        row 2i / 2i+1 = attention / MLP branch of the i-th block with a non-zero rate (common.py:46-59:
+        floor(keep + U[0,1)) / keep per sample).  Uses torch's Philox generator (graph-safe)."""
+        named = [(f"blocks.{i}", b) for i, b in enumerate(self.blocks)] + \
+                [(f"blocks_audio.{i}", b) for i, b in enumerate(self.blocks_audio)]
+        named = [(n, b) for n, b in named if b.drop_prob > 0.0]
+        if not named:
+            return {}
+        keep = getattr(self, "_dp_keep", None)
+        if keep is None or keep.device != device:
+            keep = torch.tensor([1.0 - b.drop_prob for _, b in named for _ in (0, 1)], dtype=torch.float32,
+                                device=device).unsqueeze(1)
+            self._dp_keep = keep
+        scales = torch.floor(keep + torch.rand(keep.shape[0], B, dtype=torch.float32, device=device)) / keep
+        return {n: ("scales", scales[2 * i], scales[2 * i + 1]) for i, (n, _) in enumerate(named)}
 
     def _audio_stream(self):
         if getattr(self, "_side_stream", None) is None:
@@ -327,6 +350,8 @@ class CSTS(nn.Module):
         if not inpt.is_cuda:
             raise L.CstsError("CSTS (csts_amd) runs on MI355X only: inputs must be GPU tensors; there is no CPU fallback")
         km = keep_masks or {}
+        if self.training and keep_masks is None:
+            km = self._draw_drop_paths(inpt.shape[0], inpt.device)
         self._refresh_w16()
         pe, pa = self.patch_embed, self.patch_embed_audio
         xt = ops.patch_embed(inpt.float(), pe.proj.weight, pe.proj.bias, self.pos_embed_spatial, self.pos_embed_temporal,

@@ -1,0 +1,150 @@
+"""Device-side optimizer step for the CSTS iteration: L2 gradient clip + AdamW + bf16 shadow
+refresh in three kernel launches over the whole parameter set (csts_adamw_step), instead of torch's ~65
+multi-tensor launches (fused AdamW + _foreach norm + _foreach mul + shadow copies).
+
+Mirrors the reference recipe: slowfast/models/optimizer.py:11-108 (AdamW, eps 1e-8, weight decay 0 for 1-D
+parameters and biases), tools/train_avgaze_net.py:101-109 (unscale -> clip_grad_norm_(1.0) -> step) and the
+per-iteration learning rate of slowfast/models/optimizer.py:122-130 (set through ``param_groups[i]["lr"]``).
+The interface follows torch.optim.Optimizer where the reference touches it: param_groups, step(), zero_grad(),
+state_dict() / load_state_dict().
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import lib as L
+
+CHUNK = 65536        # elements per workgroup: 256 KiB of fp32 gradient
+
+
+class FusedAdamW:
+    def __init__(self, param_groups: List[Dict], lr: float, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 0.0,
+                 shadows: Dict[int, torch.Tensor] = None):
+        """param_groups: [{"params": [...], "weight_decay": wd}, ...]; shadows: id(param) -> bf16 tensor kept equal
+        to the parameter (the GEMMs' bf16 operand)."""
+        self.param_groups = [dict(g) for g in param_groups]
+        params = [p for g in self.param_groups for p in g["params"]]
+        assert params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params), \
+            "FusedAdamW runs on MI355X: fp32 contiguous GPU parameters"
+        self.device = params[0].device
+        self.params = params
+        self.betas, self.eps, self.max_grad_norm = betas, float(eps), float(max_grad_norm)
+        self._lr = torch.tensor(float(lr), dtype=torch.float32, device=self.device)
+        for g in self.param_groups:
+            g["lr"] = self._lr           # one device scalar shared by all groups (the reference sets them all alike)
+        shadows = shadows or {}
+        n_total = sum(p.numel() for p in params)
+        # first / second moments: one flat buffer each, sliced per tensor (16-byte aligned slices)
+        offs, o = [], 0
+        for p in params:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4
+        self.exp_avg = torch.zeros(o, dtype=torch.float32, device=self.device)
+        self.exp_avg_sq = torch.zeros(o, dtype=torch.float32, device=self.device)
+        self._m = [self.exp_avg[a:a + p.numel()] for a, p in zip(offs, params)]
+        self._v = [self.exp_avg_sq[a:a + p.numel()] for a, p in zip(offs, params)]
+        self.state_t = torch.zeros(3, dtype=torch.float32, device=self.device)     # step, grad norm, clip coefficient
+        # tables
+        wd_of = {id(p): float(g["weight_decay"]) for g in self.param_groups for p in g["params"]}
+        tt = (L.OptTensor * len(params))()
+        chunk_tensor, chunk_off = [], []
+        self._shadow_refs = []
+        for i, p in enumerate(params):
+            sh = shadows.get(id(p))
+            if sh is not None:
+                assert sh.dtype == torch.bfloat16 and sh.numel() == p.numel() and sh.is_contiguous() and sh.device == p.device
+                self._shadow_refs.append(sh)
+            tt[i].p, tt[i].m, tt[i].v = p.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr()
+            tt[i].w16 = sh.data_ptr() if sh is not None else None
+            tt[i].n, tt[i].weight_decay = p.numel(), wd_of[id(p)]
+            for c0 in range(0, p.numel(), CHUNK):
+                chunk_tensor.append(i)
+                chunk_off.append(c0)
+        self._param_ptrs = [p.data_ptr() for p in params]
+        self.nchunks = len(chunk_tensor)
+        self._tensors = torch.frombuffer(bytearray(bytes(tt)), dtype=torch.uint8).to(self.device)
+        self._chunk_tensor = torch.tensor(chunk_tensor, dtype=torch.int32, device=self.device)
+        self._chunk_off = torch.tensor(chunk_off, dtype=torch.int64, device=self.device)
+        self._partial = torch.empty(self.nchunks, dtype=torch.float32, device=self.device)
+        # gradient addresses change from step to step in eager mode: they travel through a small ring of pinned host
+        # buffers (the host may run a full step ahead of the GPU, so a slot is reused only after its copy has executed);
+        # a captured graph gets a pinned buffer of its own that is never written again.
+        self._ring = [torch.zeros(len(params), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._ring_ev = [None] * len(self._ring)
+        self._ring_pos = 0
+        self._capture_pool = [torch.zeros(len(params), dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._captured_hosts = []
+        self._grads_dev = torch.zeros(len(params), dtype=torch.int64, device=self.device)
+        self.n_total = n_total
+
+    # ------------------------------------------------------------------ torch.optim-like surface
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @property
+    def grad_norm(self) -> torch.Tensor:
+        """Total L2 gradient norm of the last step (device scalar; what clip_grad_norm_ returns)."""
+        return self.state_t[1]
+
+    @torch.no_grad()
+    def step(self):
+        ptrs = []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                ptrs.append(0)
+                continue
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise L.CstsError("FusedAdamW needs fp32 contiguous gradients")
+            if p.data_ptr() != self._param_ptrs[i]:
+                raise L.CstsError("a parameter was re-allocated after the optimizer was built (rebuild the optimizer)")
+            ptrs.append(g.data_ptr())
+        if torch.cuda.is_current_stream_capturing():
+            if not self._capture_pool:
+                raise L.CstsError("FusedAdamW: more than 4 graph captures of step(); build a new optimizer")
+            host = self._capture_pool.pop()      # pre-allocated: no host allocation while a capture is open
+            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            self._captured_hosts.append(host)
+            self._grads_dev.copy_(host, non_blocking=True)
+        else:
+            k = self._ring_pos
+            self._ring_pos = (k + 1) % len(self._ring)
+            if self._ring_ev[k] is not None:
+                self._ring_ev[k].synchronize()
+            self._ring[k].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            self._grads_dev.copy_(self._ring[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ring_ev[k] = ev
+        a = L.OptArgs()
+        a.chunk_tensor, a.chunk_off = self._chunk_tensor.data_ptr(), self._chunk_off.data_ptr()
+        a.nchunks, a.chunk_elems = self.nchunks, CHUNK
+        a.tensors, a.grads, a.ntensors = self._tensors.data_ptr(), self._grads_dev.data_ptr(), len(self.params)
+        a.partial, a.state, a.lr = self._partial.data_ptr(), self.state_t.data_ptr(), self._lr.data_ptr()
+        a.beta1, a.beta2, a.eps, a.max_grad_norm = self.betas[0], self.betas[1], self.eps, self.max_grad_norm
+        L.check(L.load().csts_adamw_step(C.byref(a), torch.cuda.current_stream().cuda_stream), "csts_adamw_step")
+
+    def reset_state(self):
+        """Forget the moments and the step count (a fresh optimizer over the same parameters)."""
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.state_t.zero_()
+
+    def state_dict(self):
+        return {"state": {"step": self.state_t[0:1].clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()},
+                "param_groups": [{"lr": float(self._lr), "weight_decay": g["weight_decay"], "betas": self.betas, "eps": self.eps}
+                                 for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        self.state_t[0:1].copy_(st["step"])
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self._lr.fill_(float(sd["param_groups"][0]["lr"]))

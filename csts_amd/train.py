@@ -41,9 +41,11 @@ def set_lr(optimizer, new_lr: float):
             g["lr"] = new_lr
 
 
-def construct_optimizer(model, cfg, capturable: bool = False):
+def construct_optimizer(model, cfg, capturable: bool = False, device_fused: bool = True):
     """AdamW(eps 1e-8) with zero weight decay on 1-D parameters and biases
-    (slowfast/models/optimizer.py:11-108 for OPTIMIZING_METHOD adamw, ZERO_WD_1D_PARAM)."""
+    (slowfast/models/optimizer.py:11-108 for OPTIMIZING_METHOD adamw, ZERO_WD_1D_PARAM).
+    On the GPU this is csts_amd.optim.FusedAdamW: clip_grad_norm_ (train_avgaze_net.py:105-106) + AdamW + bf16 shadow
+    refresh in three launches; device_fused=False gives stock torch.optim.AdamW (the numerics cross-check)."""
     assert cfg.SOLVER.OPTIMIZING_METHOD == "adamw", "the CSTS YAMLs train with adamw"
     core = model.module if isinstance(model, GradAllReduce) else model
     skip = core.no_weight_decay() if hasattr(core, "no_weight_decay") else {}
@@ -60,6 +62,15 @@ def construct_optimizer(model, cfg, capturable: bool = False):
     groups = [g for g in ({"params": decay, "weight_decay": cfg.SOLVER.WEIGHT_DECAY},
                           {"params": no_decay, "weight_decay": 0.0}) if g["params"]]
     fused = all(p.is_cuda for g in groups for p in g["params"])     # one multi-tensor kernel per group on the GPU
+    if fused and device_fused and not cfg.SOLVER.CLIP_GRAD_VAL:
+        from .optim import FusedAdamW
+        shadows = {}
+        if hasattr(core, "_refresh_w16"):
+            core._refresh_w16()
+            shadows = {id(l.weight): l._w16 for l in getattr(core, "_w16_lins", [])}
+            core.w16_external = True
+        return FusedAdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, max_grad_norm=float(cfg.SOLVER.CLIP_GRAD_L2NORM or 0.0),
+                          shadows=shadows)
     kw = {}
     if fused and capturable:      # lr lives in a device tensor so that a captured step can follow the schedule
         kw = {"capturable": True}
@@ -97,12 +108,19 @@ def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: O
     if isinstance(model, GradAllReduce):
         model.finish()
     if optimizer is not None:
+        _clip_and_step(cfg, model, optimizer)
+    return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
+
+
+def _clip_and_step(cfg, model, optimizer):
+    """train_avgaze_net.py:101-109 (clip, then step); FusedAdamW clips inside its own kernels."""
+    from .optim import FusedAdamW
+    if not isinstance(optimizer, FusedAdamW):
         if cfg.SOLVER.CLIP_GRAD_VAL:
             torch.nn.utils.clip_grad_value_(model.parameters(), cfg.SOLVER.CLIP_GRAD_VAL)
         elif cfg.SOLVER.CLIP_GRAD_L2NORM:
             torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)
-        optimizer.step()
-    return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
+    optimizer.step()
 
 
 def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device) -> Dict[str, torch.Tensor]:
@@ -163,11 +181,7 @@ class GraphedTrainStep:
         loss, kld, nce, _ = compute_loss(self.cfg, self.model, self.static["video"], self.static["audio"],
                                          self.static["labels_hm"])
         loss.backward()
-        if self.cfg.SOLVER.CLIP_GRAD_VAL:
-            torch.nn.utils.clip_grad_value_(self.model.parameters(), self.cfg.SOLVER.CLIP_GRAD_VAL)
-        elif self.cfg.SOLVER.CLIP_GRAD_L2NORM:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg.SOLVER.CLIP_GRAD_L2NORM)
-        self.opt.step()
+        _clip_and_step(self.cfg, self.model, self.opt)
         return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
 
     def run(self, batch=None, lr: Optional[float] = None):
@@ -177,5 +191,7 @@ class GraphedTrainStep:
                     self.static[k].copy_(batch[k], non_blocking=True)
         if lr is not None:
             set_lr(self.opt, lr)
+        if hasattr(self.model, "_refresh_w16"):
+            self.model._refresh_w16()        # only acts after an out-of-band weight change (load_state_dict)
         self.graph.replay()
         return self.out

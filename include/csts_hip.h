@@ -172,6 +172,29 @@ int csts_egonce_fwd(const float* sim, float* loss, float* lse_row, float* lse_co
 int csts_egonce_bwd(const float* sim, const float* lse_row, const float* lse_col, const float* grad_out, float* dsim, int n,
                     float temperature, hipStream_t stream);
 
+/* ---- optimizer step ("next" row): clip_grad_norm_(params, max_norm) (tools/train_avgaze_net.py:105-106)
+ *      + torch.optim.AdamW (slowfast/models/optimizer.py:85-93; eps 1e-8, decoupled weight decay, per-tensor decay so that
+ *      1-D parameters and biases get 0, optimizer.py:48-50,98-104) over the whole parameter set in three launches, and the
+ *      refresh of the bf16 shadow weights the GEMMs read.  All pointers are DEVICE memory.  The parameter set is described
+ *      as chunks of at most chunk_elems elements that never straddle a tensor (chunk -> tensor id + element offset).
+ *      state = {step (incremented by the call), total gradient L2 norm (out), clip coefficient (out)} fp32[3];
+ *      lr is read from device memory, so a captured graph follows the schedule.  grads[i] == NULL skips tensor i. */
+typedef struct {
+  void* p; void* m; void* v;   /* fp32 parameter, exp_avg, exp_avg_sq */
+  void* w16;                   /* optional bf16 shadow of p (NULL: none) */
+  int64_t n;
+  float weight_decay; int pad_;
+} csts_opt_tensor;
+typedef struct {
+  const int32_t* chunk_tensor; const int64_t* chunk_off; int nchunks; int chunk_elems;
+  const csts_opt_tensor* tensors; const void* const* grads; int ntensors;
+  float* partial;              /* fp32[nchunks] workspace */
+  float* state;                /* fp32[3] */
+  const float* lr;
+  float beta1, beta2, eps, max_grad_norm;   /* max_grad_norm <= 0: no clipping */
+} csts_opt_args;
+int csts_adamw_step(const csts_opt_args* args, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,7 +283,7 @@ def test_graphed_train_step_matches_eager():
     state0 = copy.deepcopy(m2.state_dict())
     g = T.GraphedTrainStep(cfg, m2, opt_g, batch, warmup=1)
     m2.load_state_dict(state0)                                # undo warm-up / capture updates
-    opt_g.state.clear()
+    opt_g.reset_state() if hasattr(opt_g, "reset_state") else opt_g.state.clear()
     le = [float(T.train_step(cfg, m, batch, opt_e, lr=1e-4)[0]) for _ in range(2)]
     lg = [float(g.run(batch, lr=1e-4)[0]) for _ in range(2)]
     assert abs(le[0] - lg[0]) < 1e-4 and abs(le[1] - lg[1]) < 5e-3, (le, lg)

@@ -344,3 +344,44 @@ def test_losses_against_oracle():
     assert abs(float(ops.kldiv(p.detach(), None)) - float(
         ((p.detach().reshape(3, 4, -1) * torch.log(p.detach().reshape(3, 4, -1) + 1e-10)).sum(-1) + math.log(4096)).sum(-1).div(
             4 * math.log(4096)).mean())) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_fused_adamw_matches_torch_clip_plus_adamw():
+    """csts_adamw_step == clip_grad_norm_(1.0) + torch.optim.AdamW(eps 1e-8) (train_avgaze_net.py:101-109,
+    optimizer.py:85-93) on ragged tensor sizes (chunk boundaries, unaligned tails, a skipped tensor), per-tensor
+    weight decay, and the bf16 shadow it maintains."""
+    from csts_amd.optim import FusedAdamW, CHUNK
+    shapes = [(768, 300), (96,), (5,), (CHUNK + 1,), (1, 409, 96), (131, 7), (2 * CHUNK,), (33,)]
+    pa = [rnd(*s, seed=10 + i, scale=0.5).requires_grad_() for i, s in enumerate(shapes)]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    decay = [0, 4, 5, 6]
+    ga = [{"params": [pa[i] for i in decay], "weight_decay": 0.05},
+          {"params": [pa[i] for i in range(len(pa)) if i not in decay], "weight_decay": 0.0}]
+    gb = [{"params": [pb[i] for i in decay], "weight_decay": 0.05},
+          {"params": [pb[i] for i in range(len(pb)) if i not in decay], "weight_decay": 0.0}]
+    shadow = torch.empty(shapes[0], dtype=torch.bfloat16, device=DEV)
+    fused = FusedAdamW(ga, lr=1e-3, eps=1e-8, max_grad_norm=1.0, shadows={id(pa[0]): shadow})
+    ref = torch.optim.AdamW(gb, lr=1e-3, eps=1e-8, weight_decay=0.05)
+    for step, gscale in enumerate([1.0, 1e-4, 3.0, 0.02]):     # clipped, un-clipped, clipped, un-clipped
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 7:
+                a.grad, b.grad = None, None                     # a parameter without gradient is skipped (like torch)
+                continue
+            g = rnd(*shapes[i], seed=100 * step + i, scale=gscale)
+            a.grad, b.grad = g.clone(), g.clone()
+        lr = 1e-3 * (1 + step)
+        for grp in fused.param_groups:
+            grp["lr"].fill_(lr)
+        for grp in ref.param_groups:
+            grp["lr"] = lr
+        norm_ref = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ref.step()
+        fused.step()
+        assert abs(float(fused.grad_norm) - float(norm_ref)) < 1e-5 * float(norm_ref)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert rel_l2(a.detach(), b.detach()) < 2e-6, (step, i)
+    assert torch.equal(shadow, pa[0].detach().bfloat16())
+    assert torch.equal(pa[7].detach(), pb[7].detach())
+    m_ref = ref.state[pb[3]]["exp_avg"]
+    assert rel_l2(fused._m[[id(p) for p in fused.params].index(id(pa[3]))].view_as(m_ref), m_ref) < 1e-6
