@@ -89,7 +89,8 @@ template <int NV, int R, bool DYF32, bool XF32>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
-                                                     float* __restrict__ ws, int64_t rows, int C) {
+                                                     const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
+                                                     int C) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [LN_BWD_WAVES][2*C]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * LN_BWD_WAVES + w;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
   }
   const float invC = 1.f / C;
   for (int64_t row0 = wave * R; row0 < rows; row0 += nwaves * R) {
-    float d[R][NV], xv[R][NV], mu[R], rs[R];
+    float d[R][NV], xv[R][NV], ad[R][NV], mu[R], rs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t row = min(row0 + r, rows - 1);
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
         const int64_t i = row * C + min(lane + 64 * j, C - 1);
         d[r][j] = ldt<DYF32>(dy, i);
         xv[r][j] = ldt<XF32>(x, i);
+        ad[r][j] = addend ? ldt<XF32>(addend, i) : 0.f;     // residual-branch gradient folded into dx (wave-uniform test)
       }
     }
 #pragma unroll
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const int c = lane + 64 * j;
-          if (c < C) stt<XF32>(dx, (row0 + r) * C + c, rs[r] * (g[j] - s1 - xh[j] * s2));
+          if (c < C) stt<XF32>(dx, (row0 + r) * C + c, rs[r] * (g[j] - s1 - xh[j] * s2) + ad[r][j]);
         }
       }
     }
@@ -184,7 +186,42 @@ __global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restri
   }
 }
 
+// the same second stage for MANY independent reductions in one launch: blockIdx.y picks the descriptor
+__global__ __launch_bounds__(1024) void reduce_rows_batched_kernel(const csts_reduce_desc* __restrict__ descs) {
+  __shared__ float red[32][33];
+  const csts_reduce_desc d = descs[blockIdx.y];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t j = (int64_t)blockIdx.x * 32 + tx;
+  if ((int64_t)blockIdx.x * 32 >= d.ncols) return;     // block-uniform
+  float s = 0.f;
+  if (j < d.ncols) {
+    int64_t i = ty;
+    for (; i + 3 * 32 < d.nrows; i += 4 * 32) {
+      const float a = d.ws[i * d.ncols + j], b = d.ws[(i + 32) * d.ncols + j], c = d.ws[(i + 64) * d.ncols + j],
+                  e = d.ws[(i + 96) * d.ncols + j];
+      s += a; s += b; s += c; s += e;
+    }
+    for (; i < d.nrows; i += 32) s += d.ws[i * d.ncols + j];
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && j < d.ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) t += red[r][tx];
+    d.out[j] = t * d.scale;
+  }
+}
+
 }  // namespace
+
+extern "C" int csts_reduce_rows_batched(const csts_reduce_desc* device_descs, int n, int64_t max_ncols, hipStream_t stream) {
+  CSTS_REQUIRE(device_descs != nullptr && n > 0 && n < 65536 && max_ncols > 0, "bad args");
+  hipLaunchKernelGGL(reduce_rows_batched_kernel, dim3((unsigned)cdiv(max_ncols, 32), (unsigned)n), dim3(1024), 0, stream,
+                     device_descs);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
 
 int csts_reduce_rows_launch(const float* ws, float* out, int64_t nrows, int64_t ncols, float scale, hipStream_t s) {
   const dim3 grid((unsigned)cdiv(ncols, 32));
@@ -212,11 +249,11 @@ static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const voi
 }
 template <int NV, int R>
 static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
-                          const float* mean, const float* rstd, void* dx, float* ws, int64_t rows, int C) {
-  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
-  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
-  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, ws, rows, C);
+                          const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C) {
+  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
+  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
+  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
 }
 static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
 static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
@@ -241,12 +278,13 @@ extern "C" size_t csts_layernorm_bwd_workspace(int64_t rows, int C) {
 }
 
 extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma,
-                                  const float* mean, const float* rstd, void* dx, int dx_dt, float* dgamma,
-                                  float* dbeta, void* workspace, size_t ws_bytes, int64_t rows, int C,
+                                  const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
+                                  float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int64_t rows, int C,
                                   hipStream_t stream) {
-  CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "null pointer");
+  CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace, "null pointer");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
-  CSTS_REQUIRE(dbeta == dgamma + C, "dgamma/dbeta must be one contiguous [2*C] buffer");
+  CSTS_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta: both or neither (neither = deferred second stage)");
+  CSTS_REQUIRE(dgamma == nullptr || dbeta == dgamma + C, "dgamma/dbeta must be one contiguous [2*C] buffer");
   CSTS_REQUIRE(dx_dt == x_dt, "dx must have the dtype of x");
   const int64_t nb = ln_bwd_blocks(rows, C);
   CSTS_REQUIRE(ws_bytes >= (size_t)nb * 2 * C * sizeof(float), "workspace too small");
@@ -254,12 +292,14 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
-  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
-  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
-  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
-  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, ws, rows, C);
+  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
+  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
+  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
+  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
   CSTS_LAUNCH_CHECK();
-  csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
-  CSTS_LAUNCH_CHECK();
+  if (dgamma != nullptr) {
+    csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
+    CSTS_LAUNCH_CHECK();
+  }
   return 0;
 }

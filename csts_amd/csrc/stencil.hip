@@ -650,7 +650,7 @@ extern "C" size_t csts_dwconv_wgrad_workspace(const csts_dwconv_geom* a) {
 extern "C" int csts_dwconv_wgrad(const csts_dwconv_geom* a, const void* fine, int fine_dt, const void* coarse,
                                  int coarse_dt, float* dweight, void* workspace, size_t ws_bytes, hipStream_t stream) {
   CHECK_GEOM(a);
-  CSTS_REQUIRE(fine && coarse && dweight && workspace, "null pointer");
+  CSTS_REQUIRE(fine && coarse && workspace, "null pointer");     // dweight NULL: second stage deferred to the caller
   int slab, nslab; int64_t chunk, nchunk;
   wgrad_plan(a, slab, nslab, chunk, nchunk);
   CSTS_REQUIRE(a->C % slab == 0 && slab % a->HD == 0 && slab % 2 == 0, "channel slab must hold whole heads");
@@ -663,8 +663,10 @@ extern "C" int csts_dwconv_wgrad(const csts_dwconv_geom* a, const void* fine, in
   if (fine_dt == CSTS_F32) hipLaunchKernelGGL((dwconv_wgrad_kernel<true, true>), wg, wb, (size_t)slab * 27 * 4, stream, rg, fine, coarse, ws, slab, (int)chunk);
   else hipLaunchKernelGGL((dwconv_wgrad_kernel<false, false>), wg, wb, (size_t)slab * 27 * 4, stream, rg, fine, coarse, ws, slab, (int)chunk);
   CSTS_LAUNCH_CHECK();
-  csts_reduce_rows_launch(ws, dweight, nchunk * nslab, (int64_t)a->HD * 27, 1.f, stream);
-  CSTS_LAUNCH_CHECK();
+  if (dweight != nullptr) {
+    csts_reduce_rows_launch(ws, dweight, nchunk * nslab, (int64_t)a->HD * 27, 1.f, stream);
+    CSTS_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -13,6 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import ops as _ops
+
 
 _FORCE = False    # tests: exercise the collective code paths on a 1-rank process group
 
@@ -85,6 +87,10 @@ class GradAllReduce(nn.Module):
         self.module = module
         self.world = dist.get_world_size() if is_dist() else 1
         self.bucket_bytes = int(bucket_mb) * (1 << 20)
+        if self.world > 1 or _FORCE:
+            # bucket hooks read gradients in the middle of backward, on whichever stream autograd is replaying: the
+            # deferred (end-of-backward) second-stage reductions of ops.py would not have run yet -> keep them in line
+            _ops.DEFER_REDUCTIONS = False
         self._params = [p for p in module.parameters() if p.requires_grad]
         self._assign(list(reversed(self._params)))
         self._ready_order: List[torch.nn.Parameter] = []

@@ -68,6 +68,10 @@ class Im2colGeom(C.Structure):
                 ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Kpad", C.c_int)]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [("ws", vp), ("out", vp), ("nrows", i64), ("ncols", i64), ("scale", C.c_float), ("pad_", C.c_int)]
+
+
 class OptTensor(C.Structure):
     _fields_ = [("p", vp), ("m", vp), ("v", vp), ("w16", vp), ("n", i64), ("weight_decay", C.c_float), ("pad_", C.c_int)]
 
@@ -89,7 +93,8 @@ SYMBOLS = {
     "csts_gemm_v2_eligible": (_I, [C.POINTER(GemmArgs)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
-    "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),
+    "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, sz, i64, _I, vp]),
+    "csts_reduce_rows_batched": (_I, [vp, _I, i64, vp]),
     "csts_reduce_rows": (_I, [vp, vp, i64, i64, _F, vp]),
     "csts_dwconv_strided": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),
     "csts_dwconv_transposed": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),

@@ -121,7 +121,8 @@ class Block(nn.Module):
         B, N, Cc = x.shape
         H = self.heads
         thw = list(thw)
-        xn = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt)
+        # x + f(LN(x)): LN returns an alias of x whose gradient (the residual branch) is folded into its backward kernel
+        xn, x = ops.layer_norm(x.contiguous(), self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt, passthrough=True)
         w16 = lambda lin: getattr(lin, "_w16", None)      # bf16 shadow maintained by CSTS._refresh_w16 (bf16 mode)
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv))
         mask_mode, mT, mHW = L.MASK_NONE, 0, 0
@@ -153,7 +154,7 @@ class Block(nn.Module):
         s_attn, s_mlp = self._drop_scales(B, x.device, keep_masks)
         x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x_res, row_scale=s_attn, rows_per_scale=Nq, out_dt=L.F32,
                         compute=rt.compute, w16=w16(a.proj))
-        xn2 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt)
+        xn2, x1 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt, passthrough=True)
         base = x1
         if self.dim != self.dim_out:
             base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj))

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -53,6 +54,93 @@ def _need_gpu(*ts):
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class HostTable:
+    """Small host -> device table upload that is safe while the host runs ahead of the GPU (a ring of pinned buffers,
+    a slot is reused only after its copy has executed) and under HIP-graph capture (pre-allocated pinned buffers that
+    are never written again, so a replay copies the captured contents)."""
+
+    def __init__(self, nbytes: int, device, ring: int = 4, captures: int = 8):
+        self.nbytes, self.device = nbytes, device
+        self._ring = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(ring)]
+        self._ev = [None] * ring
+        self._pos = 0
+        self._pool = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(captures)]
+        self._captured = []
+        self.dev = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+
+    def upload(self, payload: bytes) -> int:
+        n = len(payload)
+        if n > self.nbytes:
+            raise L.CstsError(f"HostTable: {n} bytes > capacity {self.nbytes}")
+        src = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        if torch.cuda.is_current_stream_capturing():
+            if not self._pool:
+                raise L.CstsError("HostTable: out of capture buffers")
+            host = self._pool.pop()
+            self._captured.append(host)
+            host[:n].copy_(src)
+            self.dev[:n].copy_(host[:n], non_blocking=True)
+        else:
+            k = self._pos
+            self._pos = (k + 1) % len(self._ring)
+            if self._ev[k] is not None:
+                self._ev[k].synchronize()
+            self._ring[k][:n].copy_(src)
+            self.dev[:n].copy_(self._ring[k][:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ev[k] = ev
+        return self.dev.data_ptr()
+
+
+# Second stages of the cross-workgroup reductions of backward (LayerNorm dgamma/dbeta, stencil dweight): ~190 tiny
+# launches per step when done in line.  Inside a backward pass they are deferred instead: the first-stage kernels leave
+# their partial rows in a workspace, and ONE csts_reduce_rows_batched launch finishes all of them from an autograd final
+# callback (which runs on the caller's stream after the engine has joined every stream backward used).  The gradient
+# tensors handed to autograd are therefore complete when loss.backward() returns -- not before.
+_deferred = []          # (ws tensor, out tensor, nrows, ncols)
+_deferred_cb = [False]
+_deferred_tables = {}   # device index -> HostTable
+DEFER_REDUCTIONS = os.environ.get("CSTS_DEFER_REDUCE", "1") != "0"
+
+
+def _can_defer() -> bool:
+    if not DEFER_REDUCTIONS:
+        return False
+    if not _deferred_cb[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+        except RuntimeError:          # not inside a backward pass
+            return False
+        _deferred_cb[0] = True
+    return True
+
+
+def _defer(ws: torch.Tensor, out: torch.Tensor, nrows: int, ncols: int):
+    _deferred.append((ws, out, int(nrows), int(ncols)))
+
+
+def flush_deferred():
+    """Finish every deferred reduction on the current stream (idempotent; gradient-bucket hooks call it early)."""
+    _deferred_cb[0] = False
+    if not _deferred:
+        return
+    items = list(_deferred)
+    _deferred.clear()
+    dev = items[0][1].device
+    descs = (L.ReduceDesc * len(items))()
+    for i, (ws, out, nrows, ncols) in enumerate(items):
+        descs[i].ws, descs[i].out, descs[i].nrows, descs[i].ncols, descs[i].scale = ws.data_ptr(), out.data_ptr(), nrows, ncols, 1.0
+    tab = _deferred_tables.get(dev.index)
+    if tab is None:
+        tab = _deferred_tables[dev.index] = HostTable(C.sizeof(L.ReduceDesc) * 1024, dev)
+    for lo in range(0, len(items), 1024):
+        chunk = items[lo:lo + 1024]
+        ptr = tab.upload(bytes(descs)[lo * C.sizeof(L.ReduceDesc):(lo + len(chunk)) * C.sizeof(L.ReduceDesc)])
+        L.check(_lib().csts_reduce_rows_batched(ptr, len(chunk), max(it[3] for it in chunk), _stream()),
+                "csts_reduce_rows_batched")
 
 
 # ----------------------------------------------------------------------------------------- raw wrappers
@@ -125,12 +213,33 @@ def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: i
 
 
 # ----------------------------------------------------------------------------------------- LayerNorm
+def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what):
+    """dx (+ addend) and the [2*C] dgamma|dbeta buffer; the second stage is deferred inside a backward pass."""
+    dx = torch.empty_like(x)
+    dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+    nbytes = _lib().csts_layernorm_bwd_workspace(rows, Cc)
+    ws = _ws(nbytes, x.device)
+    defer = _can_defer()
+    L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
+                                      _p(addend), None if defer else _p(dgb), None if defer else _p(dgb, Cc), _p(ws),
+                                      ws.numel(), rows, Cc, _stream()), what)
+    if defer:
+        _defer(ws, dgb, nbytes // (2 * Cc * 4), 2 * Cc)
+    return dx, dgb
+
+
 class LayerNormFn(Function):
-    """nn.LayerNorm over the last dim (attention.py:192,214 eps 1e-6; :108,112,116 eps 1e-5)."""
+    """nn.LayerNorm over the last dim (attention.py:192,214 eps 1e-6; :108,112,116 eps 1e-5).
+
+    With ``passthrough`` the input is returned as a second output (an alias): the pre-norm residual pattern
+    x + f(LN(x)) (attention.py:242,247) then hands BOTH gradients of x to this node, and the backward kernel writes
+    dx = LN'(d_xn) + d_residual in one pass instead of leaving the sum to a separate autograd add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, out_dt: int):
+    def forward(ctx, x, gamma, beta, eps: float, out_dt: int, passthrough: bool):
         _need_gpu(x, gamma, beta)
+        if passthrough and not x.is_contiguous():
+            raise L.CstsError("layer_norm(passthrough=True) needs a contiguous input")
         x = x.contiguous()
         Cc = x.shape[-1]
         rows = x.numel() // Cc
@@ -140,25 +249,30 @@ class LayerNormFn(Function):
         L.check(_lib().csts_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), out_dt, _p(mean), _p(rstd), rows, Cc,
                                           eps, _stream()), "csts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.set_materialize_grads(False)
+        if passthrough:
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, gamma, mean, rstd = ctx.saved_tensors
+        if dy is None:                      # only the residual branch carried a gradient
+            return dpass, None, None, None, None, None
         dy = dy.contiguous()
         Cc = x.shape[-1]
         rows = x.numel() // Cc
-        dx = torch.empty_like(x)
-        dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
-        ws = _ws(_lib().csts_layernorm_bwd_workspace(rows, Cc), x.device)
-        L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
-                                          _p(dgb), _p(dgb, Cc), _p(ws), ws.numel(), rows, Cc, _stream()),
-                "csts_layernorm_bwd")
-        return dx, dgb[:Cc], dgb[Cc:], None, None
+        if dpass is not None:
+            dpass = dpass.contiguous()
+            if dpass.dtype != x.dtype:
+                dpass = dpass.to(x.dtype)
+        dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd")
+        return dx, dgb[:Cc], dgb[Cc:], None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, out_dt):
-    return LayerNormFn.apply(x, gamma, beta, eps, out_dt)
+def layer_norm(x, gamma, beta, eps, out_dt, passthrough: bool = False):
+    """passthrough=False: y.  passthrough=True: (y, x_alias) -- use x_alias wherever x is used afterwards."""
+    return LayerNormFn.apply(x, gamma, beta, eps, out_dt, passthrough)
 
 
 # ----------------------------------------------------------------------------------------- Linear
@@ -286,11 +400,7 @@ def _ln_rows_fwd(c, gamma, beta, HD, act_dt):
 
 def _ln_rows_bwd(dy, c, gamma, mean, rstd, HD):
     rows = c.numel() // HD
-    dc = torch.empty_like(c)
-    dgb = torch.empty(2 * HD, dtype=torch.float32, device=c.device)
-    ws = _ws(_lib().csts_layernorm_bwd_workspace(rows, HD), c.device)
-    L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(c), _dt(c), _p(gamma), _p(mean), _p(rstd), _p(dc), _dt(dc), _p(dgb),
-                                      _p(dgb, HD), _p(ws), ws.numel(), rows, HD, _stream()), "csts_layernorm_bwd(head)")
+    dc, dgb = _ln_bwd_call(dy, c, gamma, mean, rstd, None, rows, HD, "csts_layernorm_bwd(head)")
     return dc, dgb[:HD], dgb[HD:]
 
 
@@ -417,16 +527,20 @@ class AttnInnerFn(Function):
             wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
             wws = _ws(wsz, dev)
             dw = torch.empty(HD * 27, dtype=torch.float32, device=dev)
+            defer = _can_defer()
+            dwp = None if defer else _p(dw)
             if transposed:   # fine = dc (output side), coarse = qkv slot
                 L.check(lib.csts_dwconv_strided(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
                         "csts_dwconv_strided(bwd)")
-                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(dc), _dt(dc), _p(qkv, slot * Cc), _dt(qkv), _p(dw), _p(wws),
+                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(dc), _dt(dc), _p(qkv, slot * Cc), _dt(qkv), dwp, _p(wws),
                                               wws.numel(), s), "csts_dwconv_wgrad")
             else:            # fine = qkv slot, coarse = dc
                 L.check(lib.csts_dwconv_transposed(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
                         "csts_dwconv_transposed(bwd)")
-                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(dc), _dt(dc), _p(dw), _p(wws),
+                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(dc), _dt(dc), dwp, _p(wws),
                                               wws.numel(), s), "csts_dwconv_wgrad")
+            if defer:
+                _defer(wws, dw, wsz // (HD * 27 * 4), HD * 27)
             grads[slot] = (dw.view(HD, 1, 3, 3, 3), dg, db)
 
         if 0 in saved:

@@ -68,10 +68,16 @@ int csts_gemm_v2_eligible(const csts_gemm_args* args);   /* 1 when the fast bf16
 int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt, float* mean,
                        float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
 size_t csts_layernorm_bwd_workspace(int64_t rows, int C);
+/* addend (optional, dtype of dx): dx = LN'(dy) + addend -- the residual-branch gradient of x + f(LN(x)) (attention.py:242,247)
+ * folded in.  dgamma == dbeta == NULL defers the cross-workgroup second stage: workspace then holds
+ * csts_layernorm_bwd_workspace(rows, C) / (2*C*4) partial rows of [2*C] for csts_reduce_rows(_batched). */
 int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
-                       const float* rstd, void* dx, int dx_dt, float* dgamma, float* dbeta, void* workspace,
-                       size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
+                       const float* rstd, void* dx, int dx_dt, const void* addend, float* dgamma, float* dbeta,
+                       void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
 int csts_reduce_rows(const float* ws, float* out, int64_t nrows, int64_t ncols, float scale, hipStream_t stream);
+/* many deferred second stages (LayerNorm dgamma/dbeta, stencil dweight) in ONE launch; descriptors in DEVICE memory */
+typedef struct { const float* ws; float* out; int64_t nrows; int64_t ncols; float scale; int pad_; } csts_reduce_desc;
+int csts_reduce_rows_batched(const csts_reduce_desc* device_descs, int n, int64_t max_ncols, hipStream_t stream);
 
 /* ---- depthwise 3x3x3 token stencils: attention_pool's Conv3d (attention.py:11-49,104-116) and
  *      attention_upsample's ConvTranspose3d (attention.py:251-289,344-348).  "fine" is the larger grid.
@@ -87,6 +93,7 @@ int csts_dwconv_strided(const csts_dwconv_geom* g, const void* fine, int fine_dt
 int csts_dwconv_transposed(const csts_dwconv_geom* g, const void* coarse, int coarse_dt, const float* weight, void* fine,
                            int fine_dt, hipStream_t stream);    /* upsample fwd ; pool bwd-data */
 size_t csts_dwconv_wgrad_workspace(const csts_dwconv_geom* g);
+/* dweight NULL: second stage deferred (workspace = rows of [HD*27] partials, rows = workspace bytes / (HD*27*4)) */
 int csts_dwconv_wgrad(const csts_dwconv_geom* g, const void* fine, int fine_dt, const void* coarse, int coarse_dt,
                       float* dweight, void* workspace, size_t ws_bytes, hipStream_t stream);
 
