@@ -96,6 +96,7 @@ class GradAllReduce(nn.Module):
         self._ready_order: List[torch.nn.Parameter] = []
         self._observed = False
         self._pending = []
+        self._stream_events = {}
         for p in self._params:
             p.register_post_accumulate_grad_hook(self._hook)
         if is_dist():   # replicas start identical
@@ -124,6 +125,15 @@ class GradAllReduce(nn.Module):
             self._ready_order.append(p)
         bi = self._bucket_of[p]
         self._count[bi] += 1
+        if p.grad.is_cuda and (self.world > 1 or _FORCE):
+            # backward replays on more than one HIP stream (the audio trunk has its own): remember, per bucket and per
+            # stream, how far that stream had got when it produced one of the bucket's gradients
+            cur = torch.cuda.current_stream()
+            evs = self._stream_events.setdefault(bi, {})
+            ev = evs.get(cur.cuda_stream)
+            if ev is None:
+                ev = evs[cur.cuda_stream] = torch.cuda.Event()
+            ev.record(cur)
         if self._count[bi] == len(self._buckets[bi]):
             self._launch(bi)
 
@@ -131,6 +141,11 @@ class GradAllReduce(nn.Module):
         if self.world == 1 and not _FORCE:
             return
         ps = self._buckets[bi]
+        if ps[0].grad.is_cuda:
+            cur = torch.cuda.current_stream()
+            for sid, ev in self._stream_events.get(bi, {}).items():
+                if sid != cur.cuda_stream:
+                    cur.wait_event(ev)      # gradients of this bucket that were produced on another stream
         flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
         flat /= self.world
         work = dist.all_reduce(flat, async_op=True)
@@ -140,6 +155,8 @@ class GradAllReduce(nn.Module):
         """Wait for the outstanding buckets and write the averaged gradients back (call after backward)."""
         for work, flat, ps in self._pending:
             work.wait()
+            if flat.is_cuda:
+                flat.record_stream(torch.cuda.current_stream())    # allocated on the hook's stream, read here
             off = 0
             for p in ps:
                 n = p.numel()

@@ -240,6 +240,22 @@ def test_size_independent_properties_full_size():
     assert torch.allclose(heat.sum(dim=(-1, -2)), torch.ones(2, 1, 8, device=DEV), atol=1e-4)
 
 
+def test_backward_is_bitwise_reproducible():
+    """Two identical train steps (bf16 mode, two HIP streams, deferred reductions) give identical gradients: every
+    cross-workgroup reduction in the library has a fixed order and no kernel races with another stream."""
+    m, cfg = make_model("bf16")
+    batch = T.synthetic_batch(2, 8, 256, 77, DEV)
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        T.train_step(cfg, m, batch)
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    bad = [n for n in runs[0] if not torch.equal(runs[0][n], runs[1][n])]
+    assert not bad, bad[:10]
+
+
 def test_rccl_single_rank_collective_paths():
     """The N>1 code path (bucketed async all-reduce from autograd hooks, EgoNCE all-gather with grad, fused scalar
     all-reduce) executed for real on RCCL with a 1-rank group: API / stream / thread semantics, not transport."""
