@@ -90,8 +90,13 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
-                                                     int C) {
+                                                     int C, const float* __restrict__ gamma1) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [LN_BWD_WAVES][2*C]
+  // blockIdx.y = segment: a second tensor of the same shape stacked behind the first (rows each), with its own gamma and
+  // its own partial rows (the k and v LayerNorms of one attention in one launch)
+  const int64_t ro = (int64_t)blockIdx.y * rows;
+  if (blockIdx.y == 1) gamma = gamma1;
+  ws += (int64_t)blockIdx.y * gridDim.x * 2 * C;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * LN_BWD_WAVES + w;
   const int64_t nwaves = (int64_t)gridDim.x * LN_BWD_WAVES;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
     float d[R][NV], xv[R][NV], ad[R][NV], mu[R], rs[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = min(row0 + r, rows - 1);
+      const int64_t row = ro + min(row0 + r, rows - 1);
       mu[r] = mean[row];
       rs[r] = rstd[row];
 #pragma unroll
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const int c = lane + 64 * j;
-          if (c < C) stt<XF32>(dx, (row0 + r) * C + c, rs[r] * (g[j] - s1 - xh[j] * s2) + ad[r][j]);
+          if (c < C) stt<XF32>(dx, (ro + row0 + r) * C + c, rs[r] * (g[j] - s1 - xh[j] * s2) + ad[r][j]);
         }
       }
     }
@@ -249,11 +254,12 @@ static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const voi
 }
 template <int NV, int R>
 static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
-                          const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C) {
-  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
-  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
-  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C);
+                          const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C,
+                          const float* g1 = nullptr) {
+  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
+  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
+  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
 }
 static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
 static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
@@ -299,6 +305,34 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   CSTS_LAUNCH_CHECK();
   if (dgamma != nullptr) {
     csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
+    CSTS_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+/* two stacked tensors (rows each) with separate gammas, one launch; ws = 2 x csts_layernorm_bwd_workspace(rows, C) */
+extern "C" int csts_layernorm_bwd2(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma0,
+                                   const float* gamma1, const float* mean, const float* rstd, void* dx, int dx_dt,
+                                   float* dgb0, float* dgb1, void* workspace, size_t ws_bytes, int64_t rows, int C,
+                                   hipStream_t stream) {
+  CSTS_REQUIRE(dy && x && gamma0 && gamma1 && mean && rstd && dx && workspace, "null pointer");
+  CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
+  CSTS_REQUIRE(dx_dt == x_dt, "dx must have the dtype of x");
+  CSTS_REQUIRE((dgb0 == nullptr) == (dgb1 == nullptr), "dgb0/dgb1: both or neither (neither = deferred second stage)");
+  const int64_t nb = ln_bwd_blocks(rows, C);
+  CSTS_REQUIRE(ws_bytes >= (size_t)2 * nb * 2 * C * sizeof(float), "workspace too small");
+  const dim3 grid((unsigned)nb, 2);
+  const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
+  float* ws = reinterpret_cast<float*>(workspace);
+  const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
+  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
+  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
+  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
+  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
+  CSTS_LAUNCH_CHECK();
+  if (dgb0 != nullptr) {
+    csts_reduce_rows_launch(ws, dgb0, nb, 2 * C, 1.f, stream);
+    csts_reduce_rows_launch(ws + nb * 2 * C, dgb1, nb, 2 * C, 1.f, stream);
     CSTS_LAUNCH_CHECK();
   }
   return 0;

@@ -185,6 +185,166 @@ __global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const v
   }
 }
 
+// Fused pooling: depthwise conv (as dwconv_strided) + LayerNorm(hd) of the result, for up to two tensors that share the
+// geometry (k and v of one attention: attention.py:104-116 -> pool_k + norm_k, pool_v + norm_v), in ONE launch.
+// A group of GL lanes owns one (batch, out-token, head, slot) item, 8 channels per lane (HD/8 lanes active), so the
+// LayerNorm statistics are a shuffle reduction inside the group and the pooled row never leaves registers before it is
+// normalised.  Writes the pre-LN row (saved for backward), the normalised row, mean and rstd.
+struct PoolLnSlots {
+  const void* fine[2];
+  const float* w[2];
+  const float* gamma[2];
+  const float* beta[2];
+  void* conv[2];
+  void* y[2];
+  float* mean[2];
+  float* rstd[2];
+};
+template <bool F32> struct Raw8;
+template <> struct Raw8<true> { float4 a, b; };
+template <> struct Raw8<false> { uint4 a; };
+template <bool F32> __device__ __forceinline__ Raw8<F32> raw8_load(const void* base, int i) {
+  Raw8<F32> r;
+  if constexpr (F32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i);
+    r.a = q[0]; r.b = q[1];
+  } else {
+    r.a = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(base) + i);
+  }
+  return r;
+}
+template <bool F32> __device__ __forceinline__ void raw8_cvt(const Raw8<F32>& r, float (&o)[8]) {
+  if constexpr (F32) {
+    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+  } else {
+    o[0] = __uint_as_float(r.a.x << 16); o[1] = __uint_as_float(r.a.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.a.y << 16); o[3] = __uint_as_float(r.a.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.a.z << 16); o[5] = __uint_as_float(r.a.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.a.w << 16); o[7] = __uint_as_float(r.a.w & 0xffff0000u);
+  }
+}
+template <bool F32> __device__ __forceinline__ void st8t(void* base, int64_t i, const float (&o)[8]) {
+  if constexpr (F32) {
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + i);
+    q[0] = make_float4(o[0], o[1], o[2], o[3]);
+    q[1] = make_float4(o[4], o[5], o[6], o[7]);
+  } else {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)o[j];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(base) + i) = v;
+  }
+}
+
+template <int GL, bool F32>
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlots sl, int nslots, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [nslots][28][HD]
+  const Geom& g = rg.g;
+  const int HD = g.HD, H = g.C / HD;
+  {   // stage both slots' weights (tap-major, one zero row each)
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    for (int s2 = 0; s2 < nslots; ++s2) {
+      float* dst = wl + s2 * 28 * HD;
+      const float* w = sl.w[s2];
+      for (int i = tid; i < HD * 27; i += nthr) {
+        const int c = i / 27, k = i - c * 27;
+        dst[k * HD + c] = w[i];
+      }
+      for (int i = tid; i < HD; i += nthr) dst[27 * HD + i] = 0.f;
+    }
+    __syncthreads();
+  }
+  const int lane_in = threadIdx.x % GL;
+  const bool active = lane_in * 8 < HD;
+  const int c8 = min(lane_in * 8, HD - 8);                    // idle lanes shadow the last active one (loads stay in range)
+  const int groups_per_block = blockDim.x / GL;
+  const int ntok = g.Tc * g.Hc * g.Wc;
+  const int per_slot = g.B * ntok * H;
+  const int total = per_slot * nslots;
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  const float invHD = 1.f / HD;
+  for (int item = blockIdx.x * groups_per_block + threadIdx.x / GL; item < total; item += gridDim.x * groups_per_block) {
+    const int slot = item / per_slot;
+    int r = item - slot * per_slot;
+    const int head = r % H;
+    const int bt = r / H;
+    int b, ot, oh, ow;
+    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+    const int c = head * HD + c8;
+    int tof[3], hof[3], xof[3];
+    bool tv[3], hv[3], xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
+      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
+    }
+    const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
+    const float* wls = wl + slot * 28 * HD + c8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      Raw8<F32> raw[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw8_load<F32>(fb, tof[kt] + hof[kh] + xof[kw]);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (tv[kt] && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
+          const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * HD]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * HD + 4]);
+          float v[8];
+          raw8_cvt<F32>(raw[kh * 3 + kw], v);
+          acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;
+          acc[4] += v[4] * w1.x; acc[5] += v[5] * w1.y; acc[6] += v[6] * w1.z; acc[7] += v[7] * w1.w;
+        }
+    }
+    // the pre-LN row is stored in the activation dtype and the statistics are taken from the STORED values, exactly
+    // like the two-kernel path (conv -> round -> LayerNorm) and the reference (attention.py:37-47)
+    if constexpr (!F32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = (float)(bf16)acc[j];
+    }
+    float s1 = 0.f;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s1 += acc[j];
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    const float mu = s1 * invHD;
+    float s2 = 0.f;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = acc[j] - mu; s2 += d * d; }
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rs = rsqrtf(s2 * invHD + eps);
+    if (active) {
+      const int64_t off = (int64_t)b * g.c_bs + (int64_t)(bt - b * ntok) * cts + c;
+      st8t<F32>(sl.conv[slot], off, acc);
+      const float4 g0 = *reinterpret_cast<const float4*>(sl.gamma[slot] + c8), g1 = *reinterpret_cast<const float4*>(sl.gamma[slot] + c8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sl.beta[slot] + c8), b1 = *reinterpret_cast<const float4*>(sl.beta[slot] + c8 + 4);
+      float y[8];
+      y[0] = (acc[0] - mu) * rs * g0.x + b0.x; y[1] = (acc[1] - mu) * rs * g0.y + b0.y;
+      y[2] = (acc[2] - mu) * rs * g0.z + b0.z; y[3] = (acc[3] - mu) * rs * g0.w + b0.w;
+      y[4] = (acc[4] - mu) * rs * g1.x + b1.x; y[5] = (acc[5] - mu) * rs * g1.y + b1.y;
+      y[6] = (acc[6] - mu) * rs * g1.z + b1.z; y[7] = (acc[7] - mu) * rs * g1.w + b1.w;
+      st8t<F32>(sl.y[slot], off, y);
+      if (lane_in == 0) {
+        const int64_t row = (int64_t)bt * H + head;       // row index of the (B*N, H) x HD LayerNorm
+        sl.mean[slot][row] = mu;
+        sl.rstd[slot][row] = rs;
+      }
+    }
+  }
+}
+
 // candidate taps of one axis of the transposed form: k with (f + 1 - k) % s == 0, o = (f + 1 - k) / s.
 // stride 1: three candidates, stride 2: two (parity), stride >= 4: at most one.
 template <int N>
@@ -203,10 +363,19 @@ __device__ __forceinline__ void axis_cand(int f, int s, int ls, int nc, int (&k)
 }
 
 // fine[b,f,c] = sum_{k : (f+1-k) % s == 0} coarse[b, (f+1-k)/s, c] * w[c%HD][k]      (4 channels per thread)
+// up to two tensors that share one geometry (the k and v pools of one attention): blockIdx.y picks the slot
+struct Slots2 {
+  const void* src[2];
+  void* dst[2];
+  const float* w[2];
+};
+
 template <int NT, int NH, int NW, bool CF32, bool FF32>
-__global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, const void* __restrict__ coarse,
-                                                                const float* __restrict__ w, void* __restrict__ fine) {
+__global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slots2 sl) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
+  const void* __restrict__ coarse = sl.src[blockIdx.y];
+  const float* __restrict__ w = sl.w[blockIdx.y];
+  void* __restrict__ fine = sl.dst[blockIdx.y];
   const Geom& g = rg.g;
   stage_weights_z(w, wl, g.HD);
   const int CQ = g.C / VEC;
@@ -255,10 +424,17 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, cons
 
 // partial dW: block = (slab/2 channel pairs) x (token lanes), chunk of coarse tokens -> ws[part][HD*27]
 // token lanes and heads of a slab are folded in LDS in a fixed order (bitwise reproducible).
+struct WgSlots2 {
+  const void* fine[2];
+  const void* coarse[2];
+  float* ws[2];
+};
 template <bool FF32, bool CF32>
-__global__ void dwconv_wgrad_kernel(RowGeom rg, const void* __restrict__ fine, const void* __restrict__ coarse,
-                                    float* __restrict__ ws, int slab, int chunk) {
+__global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [slab][27]
+  const void* __restrict__ fine = sl.fine[blockIdx.z];
+  const void* __restrict__ coarse = sl.coarse[blockIdx.z];
+  float* __restrict__ ws = sl.ws[blockIdx.z];
   const Geom& g = rg.g;
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int cl = 2 * tx;
@@ -598,14 +774,19 @@ extern "C" int csts_dwconv_strided(const csts_dwconv_geom* a, const void* fine, 
   return 0;
 }
 
-extern "C" int csts_dwconv_transposed(const csts_dwconv_geom* a, const void* coarse, int coarse_dt, const float* weight,
-                                      void* fine, int fine_dt, hipStream_t stream) {
+static int transposed_launch(const csts_dwconv_geom* a, int nslots, const void* const* coarse, int coarse_dt,
+                             const float* const* weight, void* const* fine, int fine_dt, hipStream_t stream) {
   CHECK_GEOM(a);
-  CSTS_REQUIRE(fine && weight && coarse, "null pointer");
-  CSTS_REQUIRE(((uintptr_t)fine & 15) == 0 && ((uintptr_t)coarse & 15) == 0, "tensors must be 16-byte aligned");
+  CSTS_REQUIRE(nslots == 1 || nslots == 2, "nslots must be 1 or 2");
+  Slots2 sl{};
+  for (int i = 0; i < nslots; ++i) {
+    CSTS_REQUIRE(fine[i] && weight[i] && coarse[i], "null pointer");
+    CSTS_REQUIRE(((uintptr_t)fine[i] & 15) == 0 && ((uintptr_t)coarse[i] & 15) == 0, "tensors must be 16-byte aligned");
+    sl.src[i] = coarse[i]; sl.dst[i] = fine[i]; sl.w[i] = weight[i];
+  }
   RowGeom rg; fill_geom(a, rg);
   const int64_t total = (int64_t)a->B * a->Tf * a->Hf * a->Wf * (a->C / VEC);
-  const dim3 grid(grid_for(total)), block(256);
+  const dim3 grid(grid_for(total), nslots), block(256);
   const size_t sm = (size_t)a->HD * 28 * 4;
   CSTS_REQUIRE(coarse_dt == fine_dt, "transposed stencil: both tensors must have the same dtype");
   const bool f32 = fine_dt == CSTS_F32;
@@ -613,8 +794,8 @@ extern "C" int csts_dwconv_transposed(const csts_dwconv_geom* a, const void* coa
   const int key = nc(a->st) * 100 + nc(a->sh) * 10 + nc(a->sw);
 #define TR_CASE(NT, NH, NW)                                                                                          \
   case NT * 100 + NH * 10 + NW:                                                                                      \
-    if (f32) hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, true, true>), grid, block, sm, stream, rg, coarse, weight, fine); \
-    else hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, false, false>), grid, block, sm, stream, rg, coarse, weight, fine); \
+    if (f32) hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, true, true>), grid, block, sm, stream, rg, sl); \
+    else hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, false, false>), grid, block, sm, stream, rg, sl);   \
     break;
   switch (key) {
     TR_CASE(3, 3, 3) TR_CASE(3, 3, 2) TR_CASE(3, 3, 1) TR_CASE(3, 2, 3) TR_CASE(3, 2, 2) TR_CASE(3, 2, 1)
@@ -627,6 +808,17 @@ extern "C" int csts_dwconv_transposed(const csts_dwconv_geom* a, const void* coa
 #undef TR_CASE
   CSTS_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int csts_dwconv_transposed(const csts_dwconv_geom* a, const void* coarse, int coarse_dt, const float* weight,
+                                      void* fine, int fine_dt, hipStream_t stream) {
+  return transposed_launch(a, 1, &coarse, coarse_dt, &weight, &fine, fine_dt, stream);
+}
+
+extern "C" int csts_dwconv_transposed2(const csts_dwconv_geom* a, const void* const coarse[2], int coarse_dt,
+                                       const float* const weight[2], void* const fine[2], int fine_dt, hipStream_t stream) {
+  CSTS_REQUIRE(coarse && weight && fine, "null pointer");
+  return transposed_launch(a, 2, coarse, coarse_dt, weight, fine, fine_dt, stream);
 }
 
 static void wgrad_plan(const csts_dwconv_geom* a, int& slab, int& nslab, int64_t& chunk, int64_t& nchunk) {
@@ -647,26 +839,80 @@ extern "C" size_t csts_dwconv_wgrad_workspace(const csts_dwconv_geom* a) {
   return (size_t)nchunk * nslab * a->HD * 27 * sizeof(float);
 }
 
-extern "C" int csts_dwconv_wgrad(const csts_dwconv_geom* a, const void* fine, int fine_dt, const void* coarse,
-                                 int coarse_dt, float* dweight, void* workspace, size_t ws_bytes, hipStream_t stream) {
+static int wgrad_launch(const csts_dwconv_geom* a, int nslots, const void* const* fine, int fine_dt, const void* const* coarse,
+                        int coarse_dt, float* const* dweight, void* workspace, size_t ws_bytes, hipStream_t stream) {
   CHECK_GEOM(a);
-  CSTS_REQUIRE(fine && coarse && workspace, "null pointer");     // dweight NULL: second stage deferred to the caller
+  CSTS_REQUIRE(nslots == 1 || nslots == 2, "nslots must be 1 or 2");
+  CSTS_REQUIRE(workspace != nullptr, "null workspace");
   int slab, nslab; int64_t chunk, nchunk;
   wgrad_plan(a, slab, nslab, chunk, nchunk);
   CSTS_REQUIRE(a->C % slab == 0 && slab % a->HD == 0 && slab % 2 == 0, "channel slab must hold whole heads");
-  CSTS_REQUIRE(ws_bytes >= (size_t)nchunk * nslab * a->HD * 27 * sizeof(float), "workspace too small");
+  const size_t per_slot = (size_t)nchunk * nslab * a->HD * 27;
+  CSTS_REQUIRE(ws_bytes >= per_slot * nslots * sizeof(float), "workspace too small");
   RowGeom rg; fill_geom(a, rg);
-  float* ws = reinterpret_cast<float*>(workspace);
+  WgSlots2 sl{};
+  for (int i = 0; i < nslots; ++i) {
+    CSTS_REQUIRE(fine[i] && coarse[i], "null pointer");
+    sl.fine[i] = fine[i]; sl.coarse[i] = coarse[i];
+    sl.ws[i] = reinterpret_cast<float*>(workspace) + per_slot * i;
+  }
   const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 512 / (slab / 2)), chunk / 2));
   CSTS_REQUIRE(coarse_dt == fine_dt, "stencil wgrad: both tensors must have the same dtype");
-  const dim3 wg(nslab, (unsigned)nchunk), wb(slab / 2, lanes);
-  if (fine_dt == CSTS_F32) hipLaunchKernelGGL((dwconv_wgrad_kernel<true, true>), wg, wb, (size_t)slab * 27 * 4, stream, rg, fine, coarse, ws, slab, (int)chunk);
-  else hipLaunchKernelGGL((dwconv_wgrad_kernel<false, false>), wg, wb, (size_t)slab * 27 * 4, stream, rg, fine, coarse, ws, slab, (int)chunk);
+  const dim3 wg(nslab, (unsigned)nchunk, nslots), wb(slab / 2, lanes);
+  if (fine_dt == CSTS_F32) hipLaunchKernelGGL((dwconv_wgrad_kernel<true, true>), wg, wb, (size_t)slab * 27 * 4, stream, rg, sl, slab, (int)chunk);
+  else hipLaunchKernelGGL((dwconv_wgrad_kernel<false, false>), wg, wb, (size_t)slab * 27 * 4, stream, rg, sl, slab, (int)chunk);
   CSTS_LAUNCH_CHECK();
-  if (dweight != nullptr) {
-    csts_reduce_rows_launch(ws, dweight, nchunk * nslab, (int64_t)a->HD * 27, 1.f, stream);
-    CSTS_LAUNCH_CHECK();
+  for (int i = 0; i < nslots; ++i) {
+    if (dweight != nullptr && dweight[i] != nullptr) {     // NULL: second stage deferred to the caller
+      csts_reduce_rows_launch(sl.ws[i], dweight[i], nchunk * nslab, (int64_t)a->HD * 27, 1.f, stream);
+      CSTS_LAUNCH_CHECK();
+    }
   }
+  return 0;
+}
+
+extern "C" int csts_dwconv_wgrad(const csts_dwconv_geom* a, const void* fine, int fine_dt, const void* coarse,
+                                 int coarse_dt, float* dweight, void* workspace, size_t ws_bytes, hipStream_t stream) {
+  return wgrad_launch(a, 1, &fine, fine_dt, &coarse, coarse_dt, &dweight, workspace, ws_bytes, stream);
+}
+
+extern "C" int csts_dwconv_wgrad2(const csts_dwconv_geom* a, const void* const fine[2], int fine_dt, const void* const coarse[2],
+                                  int coarse_dt, float* const dweight[2], void* workspace, size_t ws_bytes, hipStream_t stream) {
+  CSTS_REQUIRE(fine && coarse, "null pointer");
+  return wgrad_launch(a, 2, fine, fine_dt, coarse, coarse_dt, dweight, workspace, ws_bytes, stream);
+}
+
+extern "C" int csts_pool_ln_fwd(const csts_pool_ln_args* a, hipStream_t stream) {
+  CSTS_REQUIRE(a != nullptr, "null args");
+  const csts_dwconv_geom* gm = &a->geom;
+  CHECK_GEOM(gm);
+  CSTS_REQUIRE(a->nslots == 1 || a->nslots == 2, "nslots must be 1 or 2");
+  CSTS_REQUIRE(a->dt == CSTS_F32 || a->dt == CSTS_BF16, "bad dtype");
+  PoolLnSlots sl{};
+  for (int i = 0; i < a->nslots; ++i) {
+    CSTS_REQUIRE(a->fine[i] && a->weight[i] && a->gamma[i] && a->beta[i] && a->conv_out[i] && a->y[i] && a->mean[i] && a->rstd[i],
+                 "null pointer");
+    CSTS_REQUIRE(((uintptr_t)a->fine[i] & 15) == 0 && ((uintptr_t)a->conv_out[i] & 15) == 0 && ((uintptr_t)a->y[i] & 15) == 0 &&
+                     ((uintptr_t)a->gamma[i] & 15) == 0 && ((uintptr_t)a->beta[i] & 15) == 0,
+                 "tensors must be 16-byte aligned");
+    sl.fine[i] = a->fine[i]; sl.w[i] = a->weight[i]; sl.gamma[i] = a->gamma[i]; sl.beta[i] = a->beta[i];
+    sl.conv[i] = a->conv_out[i]; sl.y[i] = a->y[i]; sl.mean[i] = a->mean[i]; sl.rstd[i] = a->rstd[i];
+  }
+  RowGeom rg; fill_geom(gm, rg);
+  const int gl = gm->HD <= 128 ? 16 : 32;
+  const int64_t items = (int64_t)gm->B * gm->Tc * gm->Hc * gm->Wc * (gm->C / gm->HD) * a->nslots;
+  const int gpb = 256 / gl;
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv(items, gpb), 2048)), block(256);
+  const size_t sm = (size_t)a->nslots * gm->HD * 28 * 4;
+  const bool f32 = a->dt == CSTS_F32;
+  if (gl == 16) {
+    if (f32) hipLaunchKernelGGL((pool_ln_fwd_kernel<16, true>), grid, block, sm, stream, rg, sl, a->nslots, a->eps);
+    else hipLaunchKernelGGL((pool_ln_fwd_kernel<16, false>), grid, block, sm, stream, rg, sl, a->nslots, a->eps);
+  } else {
+    if (f32) hipLaunchKernelGGL((pool_ln_fwd_kernel<32, true>), grid, block, sm, stream, rg, sl, a->nslots, a->eps);
+    else hipLaunchKernelGGL((pool_ln_fwd_kernel<32, false>), grid, block, sm, stream, rg, sl, a->nslots, a->eps);
+  }
+  CSTS_LAUNCH_CHECK();
   return 0;
 }
 

@@ -44,6 +44,13 @@ class DwconvGeom(C.Structure):
                 ("coarse_batch_stride", i64), ("coarse_token_stride", i64)]
 
 
+class PoolLnArgs(C.Structure):
+    _fields_ = [("geom", DwconvGeom), ("nslots", C.c_int),
+                ("fine", vp * 2), ("weight", vp * 2), ("gamma", vp * 2), ("beta", vp * 2),
+                ("conv_out", vp * 2), ("y", vp * 2), ("mean", vp * 2), ("rstd", vp * 2),
+                ("dt", C.c_int), ("eps", C.c_float)]
+
+
 class PoolGeom(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int),
                 ("Ti", C.c_int), ("Hi", C.c_int), ("Wi", C.c_int),
@@ -95,11 +102,15 @@ SYMBOLS = {
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, sz, i64, _I, vp]),
     "csts_reduce_rows_batched": (_I, [vp, _I, i64, vp]),
+    "csts_layernorm_bwd2": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),
     "csts_reduce_rows": (_I, [vp, vp, i64, i64, _F, vp]),
     "csts_dwconv_strided": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),
     "csts_dwconv_transposed": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),
     "csts_dwconv_wgrad_workspace": (sz, [C.POINTER(DwconvGeom)]),
     "csts_dwconv_wgrad": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, _I, vp, vp, sz, vp]),
+    "csts_dwconv_transposed2": (_I, [C.POINTER(DwconvGeom), vp * 2, _I, vp * 2, vp * 2, _I, vp]),
+    "csts_dwconv_wgrad2": (_I, [C.POINTER(DwconvGeom), vp * 2, _I, vp * 2, _I, vp * 2, vp, sz, vp]),
+    "csts_pool_ln_fwd": (_I, [C.POINTER(PoolLnArgs), vp]),
     "csts_maxpool_fwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, vp, vp]),
     "csts_maxpool_bwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, vp, vp]),
     "csts_trilinear_fwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, _I, vp, _I, vp]),

@@ -447,15 +447,37 @@ class AttnInnerFn(Function):
             saved[slot] = (c, mean, rstd, g)
             return (y, 0, (n_out * Cc, Cc, HD), n_out), out_thw
 
+        def pooled_fused(slots, ws_, gammas, betas, stride):
+            """Conv-pool + LayerNorm(hd) of 1 or 2 slots that share the geometry in ONE launch (csts_pool_ln_fwd)."""
+            ns = len(slots)
+            g = _conv_geom(B, Cc, HD, list(thw), stride, N * 3 * Cc, 3 * Cc, 0, Cc)
+            n_out = g.Tc * g.Hc * g.Wc
+            g.coarse_batch_stride = n_out * Cc
+            rows = B * n_out * H
+            c = torch.empty(ns, B, n_out, Cc, dtype=qkv.dtype, device=dev)
+            y = torch.empty_like(c)
+            mean = torch.empty(ns, rows, dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
+            pa = L.PoolLnArgs()
+            pa.geom, pa.nslots, pa.dt, pa.eps = g, ns, _dt(qkv), 1e-5
+            for i, slot in enumerate(slots):
+                pa.fine[i], pa.weight[i], pa.gamma[i], pa.beta[i] = _p(qkv, slot * Cc), _p(ws_[i]), _p(gammas[i]), _p(betas[i])
+                pa.conv_out[i], pa.y[i], pa.mean[i], pa.rstd[i] = _p(c[i]), _p(y[i]), _p(mean[i]), _p(rstd[i])
+            L.check(lib.csts_pool_ln_fwd(C.byref(pa), s), "csts_pool_ln_fwd")
+            for i, slot in enumerate(slots):
+                saved[slot] = (c[i], mean[i], rstd[i], g)
+            if ns == 2:
+                saved["kv"] = (c, mean, rstd, g)       # stacked pair: one-launch backward kernels
+            return [(y[i], 0, (n_out * Cc, Cc, HD), n_out) for i in range(ns)]
+
         if kind == "dec":
             qd, _ = pooled(0, wq, gq, bq, stride_q, True)
         elif has_pool_q:
-            qd, _ = pooled(0, wq, gq, bq, stride_q, False)
+            qd, = pooled_fused([0], [wq], [gq], [bq], stride_q)
         else:
             qd = slot_view(0)
         if has_pool_kv:
-            kd, _ = pooled(1, wk, gk, bk, stride_kv, False)
-            vd, _ = pooled(2, wv, gv, bv, stride_kv, False)
+            kd, vd = pooled_fused([1, 2], [wk, wv], [gk, gv], [bk, bv], stride_kv)
         else:
             kd, vd = slot_view(1), slot_view(2)
         Nq, Nk = qd[3], kd[3]
@@ -500,7 +522,12 @@ class AttnInnerFn(Function):
                 return t, 0, (n_rows * Cc, Cc, HD)
             return dqkv, slot * Cc, (N * 3 * Cc, 3 * Cc, HD)
 
-        tq, tk, tv = grad_target(0, Nq), grad_target(1, Nk), grad_target(2, Nk)
+        tq = grad_target(0, Nq)
+        if "kv" in saved:               # dK | dV stacked like the saved pooled pair
+            dkv = torch.empty(2, B, Nk, Cc, dtype=qkv.dtype, device=dev)
+            tk, tv = (dkv[0], 0, (Nk * Cc, Cc, HD)), (dkv[1], 0, (Nk * Cc, Cc, HD))
+        else:
+            tk, tv = grad_target(1, Nk), grad_target(2, Nk)
         a = L.AttnArgs()
         a.Q, a.K, a.V = _p(qd[0], qd[1]), _p(kd[0], kd[1]), _p(vd[0], vd[1])
         a.O, a.LSE, a.dO, a.delta = _p(o), _p(lse), _p(do), _p(delta)
@@ -543,9 +570,44 @@ class AttnInnerFn(Function):
                 _defer(wws, dw, wsz // (HD * 27 * 4), HD * 27)
             grads[slot] = (dw.view(HD, 1, 3, 3, 3), dg, db)
 
+        def pooled_bwd_kv():
+            """LayerNorm backward, transposed conv (data gradient) and stencil weight gradient of the k AND v pools,
+            one launch each."""
+            c2, mean2, rstd2, g = saved["kv"]
+            rows = B * Nk * H
+            dc2 = torch.empty_like(c2)
+            dgb = torch.empty(2, 2 * HD, dtype=torch.float32, device=dev)
+            nbytes = lib.csts_layernorm_bwd_workspace(rows, HD)
+            lws = _ws(2 * nbytes, dev)
+            defer = _can_defer()
+            L.check(lib.csts_layernorm_bwd2(_p(dkv), _dt(dkv), _p(c2), _dt(c2), _p(gk), _p(gv), _p(mean2), _p(rstd2), _p(dc2),
+                                            _dt(dc2), None if defer else _p(dgb[0]), None if defer else _p(dgb[1]), _p(lws),
+                                            lws.numel(), rows, HD, s), "csts_layernorm_bwd2")
+            if defer:
+                nrow = nbytes // (2 * HD * 4)
+                _defer(lws[:nbytes], dgb[0], nrow, 2 * HD)
+                _defer(lws[nbytes:], dgb[1], nrow, 2 * HD)
+            vp2 = C.c_void_p * 2
+            L.check(lib.csts_dwconv_transposed2(C.byref(g), vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), vp2(_p(wk), _p(wv)),
+                                                vp2(_p(dqkv, Cc), _p(dqkv, 2 * Cc)), _dt(dqkv), s), "csts_dwconv_transposed2")
+            wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
+            wws = _ws(2 * wsz, dev)
+            dw = torch.empty(2, HD * 27, dtype=torch.float32, device=dev)
+            dwp = vp2(None, None) if defer else vp2(_p(dw[0]), _p(dw[1]))
+            L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(qkv, Cc), _p(qkv, 2 * Cc)), _dt(qkv), vp2(_p(dc2[0]), _p(dc2[1])),
+                                           _dt(dc2), dwp, _p(wws), wws.numel(), s), "csts_dwconv_wgrad2")
+            if defer:
+                nrow = wsz // (HD * 27 * 4)
+                _defer(wws[:wsz], dw[0], nrow, HD * 27)
+                _defer(wws[wsz:], dw[1], nrow, HD * 27)
+            for i, slot in enumerate((1, 2)):
+                grads[slot] = (dw[i].view(HD, 1, 3, 3, 3), dgb[i, :HD], dgb[i, HD:])
+
         if 0 in saved:
             pooled_bwd(0, tq[0], wq, gq, kind == "dec")
-        if 1 in saved:
+        if "kv" in saved:
+            pooled_bwd_kv()
+        elif 1 in saved:
             pooled_bwd(1, tk[0], wk, gk, False)
             pooled_bwd(2, tv[0], wv, gv, False)
         gq_ = grads.get(0, (None, None, None))

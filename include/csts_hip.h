@@ -74,6 +74,12 @@ size_t csts_layernorm_bwd_workspace(int64_t rows, int C);
 int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
                        const float* rstd, void* dx, int dx_dt, const void* addend, float* dgamma, float* dbeta,
                        void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
+/* two stacked tensors of `rows` rows each (dy, x, dx, mean, rstd contiguous: [2][rows]...) with their own gammas in one
+ * launch (norm_k and norm_v of one attention); dgb0/dgb1 = [2*C] dgamma|dbeta of each, or both NULL to defer the second
+ * stage: workspace = 2 x csts_layernorm_bwd_workspace(rows, C), tensor i's partial rows at offset i * that size */
+int csts_layernorm_bwd2(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma0, const float* gamma1,
+                        const float* mean, const float* rstd, void* dx, int dx_dt, float* dgb0, float* dgb1,
+                        void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
 int csts_reduce_rows(const float* ws, float* out, int64_t nrows, int64_t ncols, float scale, hipStream_t stream);
 /* many deferred second stages (LayerNorm dgamma/dbeta, stencil dweight) in ONE launch; descriptors in DEVICE memory */
 typedef struct { const float* ws; float* out; int64_t nrows; int64_t ncols; float scale; int pad_; } csts_reduce_desc;
@@ -96,6 +102,26 @@ size_t csts_dwconv_wgrad_workspace(const csts_dwconv_geom* g);
 /* dweight NULL: second stage deferred (workspace = rows of [HD*27] partials, rows = workspace bytes / (HD*27*4)) */
 int csts_dwconv_wgrad(const csts_dwconv_geom* g, const void* fine, int fine_dt, const void* coarse, int coarse_dt,
                       float* dweight, void* workspace, size_t ws_bytes, hipStream_t stream);
+
+/* two tensors that share one geometry (the k and v pools of one attention) in one launch each; workspace of wgrad2 =
+ * 2 x csts_dwconv_wgrad_workspace(g), slot i's partial rows at offset i * that size */
+int csts_dwconv_transposed2(const csts_dwconv_geom* g, const void* const coarse[2], int coarse_dt, const float* const weight[2],
+                            void* const fine[2], int fine_dt, hipStream_t stream);
+int csts_dwconv_wgrad2(const csts_dwconv_geom* g, const void* const fine[2], int fine_dt, const void* const coarse[2],
+                       int coarse_dt, float* const dweight[2], void* workspace, size_t ws_bytes, hipStream_t stream);
+/* attention_pool fused (attention.py:11-49): depthwise Conv3d k=3 p=1 stride s of the head-split q/k/v slot + LayerNorm(hd)
+ * of the pooled rows, for nslots (1 or 2) tensors sharing the geometry.  conv_out = pre-LN pooled tensor (needed by
+ * backward), y = normalised tensor, mean/rstd fp32 [B * N_coarse * heads]; all tensors of dtype dt. */
+typedef struct {
+  csts_dwconv_geom geom;        /* coarse strides describe conv_out AND y */
+  int nslots;
+  const void* fine[2];
+  const float* weight[2]; const float* gamma[2]; const float* beta[2];
+  void* conv_out[2]; void* y[2];
+  float* mean[2]; float* rstd[2];
+  int dt; float eps;
+} csts_pool_ln_args;
+int csts_pool_ln_fwd(const csts_pool_ln_args* args, hipStream_t stream);
 
 /* ---- residual-path resampling: MaxPool3d skip (attention.py:193-195,234-236,240), nn.Upsample trilinear skip
  *      (attention.py:463-467,471) and F.interpolate of the patch feature (custom_multimodal_builder.py:479).
