@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
-                                                     int C, const float* __restrict__ gamma1) {
+                                                     int C, const float* __restrict__ gamma1, bf16* __restrict__ dx16) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [LN_BWD_WAVES][2*C]
   // blockIdx.y = segment: a second tensor of the same shape stacked behind the first (rows each), with its own gamma and
   // its own partial rows (the k and v LayerNorms of one attention in one launch)
@@ -144,7 +144,11 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const int c = lane + 64 * j;
-          if (c < C) stt<XF32>(dx, (ro + row0 + r) * C + c, rs[r] * (g[j] - s1 - xh[j] * s2) + ad[r][j]);
+          if (c < C) {
+            const float val = rs[r] * (g[j] - s1 - xh[j] * s2) + ad[r][j];
+            stt<XF32>(dx, (ro + row0 + r) * C + c, val);
+            if (dx16) dx16[(ro + row0 + r) * C + c] = (bf16)val;   // the copy the next GEMMs read (they round to bf16 anyway)
+          }
         }
       }
     }
@@ -255,11 +259,11 @@ static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const voi
 template <int NV, int R>
 static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
                           const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C,
-                          const float* g1 = nullptr) {
-  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
-  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
-  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
-  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1);
+                          const float* g1 = nullptr, bf16* dx16 = nullptr) {
+  if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
 }
 static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
 static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
@@ -285,8 +289,8 @@ extern "C" size_t csts_layernorm_bwd_workspace(int64_t rows, int C) {
 
 extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma,
                                   const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
-                                  float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int64_t rows, int C,
-                                  hipStream_t stream) {
+                                  void* dx_bf16, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
+                                  int64_t rows, int C, hipStream_t stream) {
   CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace, "null pointer");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
   CSTS_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta: both or neither (neither = deferred second stage)");
@@ -298,10 +302,10 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
-  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
-  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
-  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
-  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C);
+  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
+  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
+  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
+  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
   CSTS_LAUNCH_CHECK();
   if (dgamma != nullptr) {
     csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);

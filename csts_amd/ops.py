@@ -184,8 +184,8 @@ def colsum(X: torch.Tensor, batch: int, M: int, N: int, row_weight: Optional[tor
     return out
 
 
-def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, rows_per_scale: int, M: int, N: int) -> torch.Tensor:
-    out = torch.empty_like(x)
+def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, rows_per_scale: int, M: int, N: int, out_dt=None) -> torch.Tensor:
+    out = torch.empty_like(x) if out_dt is None else torch.empty(x.shape, dtype=torch_dtype(out_dt), device=x.device)
     L.check(_lib().csts_scale_rows(_p(x), _dt(x), _p(row_scale), rows_per_scale, _p(out), _dt(out), M, N, _stream()),
             "csts_scale_rows")
     return out
@@ -213,19 +213,37 @@ def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: i
 
 
 # ----------------------------------------------------------------------------------------- LayerNorm
-def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what):
-    """dx (+ addend) and the [2*C] dgamma|dbeta buffer; the second stage is deferred inside a backward pass."""
+BF16_GRAD_COPY = os.environ.get("CSTS_BF16_GRAD_COPY", "1") != "0"
+
+
+def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False):
+    """dx (+ addend) and the [2*C] dgamma|dbeta buffer; the second stage is deferred inside a backward pass.
+    want16: also emit a bf16 copy of dx, attached as dx._csts_bf16, for the weight/data-gradient GEMMs that read it next
+    (LinearFn / MlpFn backward pick it up; any other consumer simply ignores the attribute)."""
     dx = torch.empty_like(x)
+    dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want16 and BF16_GRAD_COPY) else None
     dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
     nbytes = _lib().csts_layernorm_bwd_workspace(rows, Cc)
     ws = _ws(nbytes, x.device)
     defer = _can_defer()
     L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
-                                      _p(addend), None if defer else _p(dgb), None if defer else _p(dgb, Cc), _p(ws),
+                                      _p(addend), _p(dx16), None if defer else _p(dgb), None if defer else _p(dgb, Cc), _p(ws),
                                       ws.numel(), rows, Cc, _stream()), what)
     if defer:
         _defer(ws, dgb, nbytes // (2 * Cc * 4), 2 * Cc)
+    if dx16 is not None:
+        dx._csts_bf16 = dx16
     return dx, dgb
+
+
+def _grad16(dy: torch.Tensor, compute: int):
+    """The bf16 copy of a residual-stream gradient left by the LayerNorm backward that produced it (or None)."""
+    if compute != BF16 or dy.dtype != torch.float32:
+        return None
+    d16 = getattr(dy, "_csts_bf16", None)
+    if d16 is None or d16.shape != dy.shape or d16.device != dy.device:
+        return None
+    return d16
 
 
 class LayerNormFn(Function):
@@ -266,7 +284,8 @@ class LayerNormFn(Function):
             dpass = dpass.contiguous()
             if dpass.dtype != x.dtype:
                 dpass = dpass.to(x.dtype)
-        dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd")
+        dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd",
+                               want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16))
         return dx, dgb[:Cc], dgb[Cc:], None, None, None
 
 
@@ -304,8 +323,12 @@ class LinearFn(Function):
     def backward(ctx, dy):
         x, W, row_scale = ctx.saved_tensors
         M, N, K, rps, compute, has_b, has_res, res_dtype = ctx.meta
+        d16 = _grad16(dy, compute) if dy.is_contiguous() else None
         dy = dy.contiguous()
-        dys = scale_rows(dy, row_scale, rps, M, N) if row_scale is not None else dy
+        if row_scale is not None:          # drop-path: the scaled copy goes straight to bf16 when the GEMMs run in bf16
+            dys = scale_rows(dy, row_scale, rps, M, N, out_dt=BF16 if (compute == BF16 and BF16_GRAD_COPY) else None)
+        else:
+            dys = d16 if d16 is not None else dy
         dx = dW = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -358,8 +381,12 @@ class MlpFn(Function):
     def backward(ctx, dy):
         x, W1, W2, h, g, row_scale = ctx.saved_tensors
         M, K, Hd, N, rps, compute, has_res = ctx.meta
+        d16 = _grad16(dy, compute) if dy.is_contiguous() else None
         dy = dy.contiguous()
-        dys = scale_rows(dy, row_scale, rps, M, N) if row_scale is not None else dy
+        if row_scale is not None:
+            dys = scale_rows(dy, row_scale, rps, M, N, out_dt=BF16 if (compute == BF16 and BF16_GRAD_COPY) else None)
+        else:
+            dys = d16 if d16 is not None else dy
         dW2, db2 = _wgrad(dys, g, M, N, Hd, compute, want_bias=True)
         dh = torch.empty_like(h)
         gemm(L.GEMM_NN, dys, 0, N, W2, 0, Hd, dh, Hd, M, Hd, N, compute=compute, epilogue=L.EPI_DGELU, aux=h)

@@ -69,11 +69,12 @@ int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float*
                        float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
 size_t csts_layernorm_bwd_workspace(int64_t rows, int C);
 /* addend (optional, dtype of dx): dx = LN'(dy) + addend -- the residual-branch gradient of x + f(LN(x)) (attention.py:242,247)
- * folded in.  dgamma == dbeta == NULL defers the cross-workgroup second stage: workspace then holds
+ * folded in.  dx_bf16 (optional): a bf16 copy of dx for the GEMMs that consume it next (they round to bf16 while staging
+ * anyway, so results are unchanged while they read half the bytes).  dgamma == dbeta == NULL defers the cross-workgroup second stage: workspace then holds
  * csts_layernorm_bwd_workspace(rows, C) / (2*C*4) partial rows of [2*C] for csts_reduce_rows(_batched). */
 int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
-                       const float* rstd, void* dx, int dx_dt, const void* addend, float* dgamma, float* dbeta,
-                       void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
+                       const float* rstd, void* dx, int dx_dt, const void* addend, void* dx_bf16, float* dgamma,
+                       float* dbeta, void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
 /* two stacked tensors of `rows` rows each (dy, x, dx, mean, rstd contiguous: [2][rows]...) with their own gammas in one
  * launch (norm_k and norm_v of one attention); dgb0/dgb1 = [2*C] dgamma|dbeta of each, or both NULL to defer the second
  * stage: workspace = 2 x csts_layernorm_bwd_workspace(rows, C), tensor i's partial rows at offset i * that size */
