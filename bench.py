@@ -49,46 +49,71 @@ def parse():
 
 
 class GemmTimer:
-    """HIP-event timing of every csts_gemm launch (events recorded on the launch stream = torch's current stream)."""
+    """HIP-event timing of every csts_gemm call at the C-ABI boundary (events recorded on the launch stream = torch's
+    current stream).  Each call is attributed to the kernel csts_gemm picks for it (csts_gemm_plan), named exactly as
+    rocprofv3 prints it, so the live numbers can be checked against profiles/*_kernel_stats.csv."""
+
+    class _Proxy:
+        def __init__(self, lib, owner):
+            self._lib, self._owner = lib, owner
+
+        def __getattr__(self, name):
+            fn = getattr(self._lib, name)
+            if name != "csts_gemm":
+                return fn
+            owner, lib = self._owner, self._lib
+
+            def timed(argsref, stream):
+                import ctypes as C
+                a = argsref._obj
+                v2, tr, ns = C.c_int(), C.c_int(), C.c_int()
+                lib.csts_gemm_plan(argsref, C.byref(v2), C.byref(tr), C.byref(ns))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(argsref, stream)
+                e1.record()
+                tf = lambda b: "true" if b else "false"
+                if v2.value:
+                    name = (f"gemm2_kernel<{tf(a.layout != 2)}, {tf(a.layout == 0)}, {tf(a.a_dt == 0)}, {tf(a.b_dt == 0)}, "
+                            f"{tr.value // 64}, 2>")
+                else:
+                    name = f"gemm_kernel<{tf(a.layout != 2)}, {tf(a.layout == 0)}, {tf(a.compute == 0)}>"
+                esz = lambda dt: 4 if dt == 0 else 2
+                byt = a.M * a.K * esz(a.a_dt) + a.N * a.K * esz(a.b_dt) + a.M * a.N * esz(a.c_dt)
+                owner.records.append((name, ns.value, 2.0 * a.M * a.N * a.K, byt, e0, e1, (a.layout, a.M, a.N, a.K, ns.value)))
+                return rc
+            return timed
 
     def __init__(self):
-        self.records = []   # (key, flops, bytes, ev0, ev1)
+        self.records = []   # (kernel name, nsplit, flops, bytes, ev0, ev1, shape)
 
     def install(self):
-        from csts_amd import ops
-        self._orig = ops.gemm
-        timer = self
-
-        def timed(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, **kw):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            timer._orig(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, **kw)
-            e1.record()
-            byt = M * K * A.element_size() + N * K * B.element_size() + M * N * Cm.element_size()
-            timer.records.append(((layout, kw.get("compute")), 2.0 * M * N * K, byt, e0, e1, (M, N, K, kw.get("split_k", 1))))
-        ops.gemm = timed
+        from csts_amd import lib as L
+        self._orig = L.load()
+        L._lib = GemmTimer._Proxy(self._orig, self)
 
     def remove(self):
-        from csts_amd import ops
-        ops.gemm = self._orig
+        from csts_amd import lib as L
+        L._lib = self._orig
 
     def summary(self):
+        """kernel name -> [launches, flops, bytes, seconds, has_finish_pass]"""
         torch.cuda.synchronize()
         agg = {}
-        for key, fl, by, e0, e1, _shape in self.records:
-            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+        for name, ns, fl, by, e0, e1, _shape in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, False])
             a[0] += 1
             a[1] += fl
             a[2] += by
             a[3] += e0.elapsed_time(e1) * 1e-3
+            a[4] = a[4] or ns > 1
         return agg
 
     def dump_shapes(self, path):
         torch.cuda.synchronize()
         per = {}
-        for key, fl, by, e0, e1, shape in self.records:
-            a = per.setdefault((key[0],) + shape, [0, 0.0, fl, by])
+        for name, ns, fl, by, e0, e1, shape in self.records:
+            a = per.setdefault(shape, [0, 0.0, fl, by])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
         rows = sorted(per.items(), key=lambda kv: -kv[1][1])
@@ -259,17 +284,28 @@ def main():
         agg = gt.summary()
         if args.dump_gemm:
             gt.dump_shapes(args.dump_gemm)
-        from csts_amd import lib as L
-        key = (L.GEMM_NT, L.BF16 if args.compute == "bf16" else L.F32)
-        n, fl, by, sec = agg.get(key, (0, 0.0, 0.0, 1.0))
+        # dominant kernel = the single-kernel GEMM variant (no split-K finishing pass inside the event pair) with the most time
+        single = {k: v for k, v in agg.items() if not v[4]}
+        name = max(single, key=lambda k: single[k][3]) if single else None
+        n, fl, by, sec, _ = agg.get(name, (0, 0.0, 0.0, 1.0, False))
         tot_sec = sum(a[3] for a in agg.values())
         tot_fl = sum(a[1] for a in agg.values())
-        roof = {"bound": "mfma", "kernel": "gemm_kernel<NT, %s> (x W^T: qkv/proj/fc1/fc2/patch-embed/fusion)" % args.compute,
-                "achieved": round(fl / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3,
-                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / (PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3), 4),
-                "traffic": None, "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
+        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
+        traffic = None
+        try:     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py), same command, same kernel
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if name in pmc["kernels"]:
+                traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
+                "traffic": traffic, "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
                 "algorithmic_flop_per_launch": round(fl / max(n, 1)), "algorithmic_bytes_per_launch": round(by / max(n, 1)),
-                "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2), "all_gemm_ms_per_step": round(tot_sec / 2 * 1e3, 2)}
+                "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2), "all_gemm_ms_per_step": round(tot_sec / 2 * 1e3, 2),
+                "per_kernel": {k: {"launches_per_step": v[0] // 2, "avg_us": round(v[3] / v[0] * 1e6, 1),
+                                   "tflops": round(v[1] / v[3] / 1e12, 1), "ms_per_step": round(v[3] / 2 * 1e3, 3)}
+                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3])[:8]}}
     if world > 1:
         torch.distributed.barrier()
 

@@ -726,6 +726,21 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
 
 extern "C" int csts_gemm_v2_eligible(const csts_gemm_args* a) { return a != nullptr && v2_ok(a) ? 1 : 0; }
 
+// Which kernel csts_gemm would launch for these arguments (host-only; used by bench.py to name the kernel a timed call
+// ran, exactly as rocprofv3 prints it): v2 = 1 -> gemm2_kernel<A_KC, B_KC, A_F32, B_F32, tile_rows / 64, 2>, else gemm_kernel.
+extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, int* nsplit) {
+  CSTS_REQUIRE(a != nullptr && v2 && tile_rows && nsplit, "null pointer");
+  const int split = a->split_k > 1 ? a->split_k : 1;
+  const bool use_v2 = v2_ok(a);
+  const int bk = use_v2 ? BK2 : BK;
+  const int64_t k_chunk = cdiv(cdiv(a->K, bk), split) * bk;
+  const int64_t ns = cdiv(a->K, k_chunk);
+  *v2 = use_v2 ? 1 : 0;
+  *nsplit = (int)ns;
+  *tile_rows = use_v2 ? pick_tile_rows(a, cdiv(a->N, BN) * ns) : BM;
+  return 0;
+}
+
 extern "C" size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k) {
   if (split_k <= 1) return 0;
   // upper bound over both kernels' k-chunking (v1: BK 32, v2: BK 64)

@@ -40,6 +40,56 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colP g, const void* __re
   }
 }
 
+// Row-strip form: one workgroup per (b, to, ho).  The Cin*KT*KH input rows that strip of Wo patches touches are staged in
+// LDS with coalesced 16-byte loads (rows outside the volume as zeros), then the Wo x Kpad slab of col is written with
+// 16-byte stores, each thread gathering 8 consecutive k from LDS.  HBM sees every input row ~KH/sh times (L2 absorbs most
+// of that) and every col byte once; the element-per-thread form above re-fetched the input ~13x (rocprofv3 FETCH_SIZE).
+template <bool XF32, bool CF32>
+__global__ __launch_bounds__(256) void im2col_strip_kernel(Im2colP g, const void* __restrict__ x, void* __restrict__ col) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];   // [Cin*KT*KH][W]
+  const int nrows = g.Cin * g.KT * g.KH;
+  const int tid = threadIdx.x;
+  int blk = blockIdx.x;
+  const int ho = blk % g.Ho; blk /= g.Ho;
+  const int to = blk % g.To;
+  const int b = blk / g.To;
+  const int W4 = g.W / 4;
+  for (int i = tid; i < nrows * W4; i += 256) {
+    const int r = i / W4, w4 = i - r * W4;
+    const int kh = r % g.KH, kt = (r / g.KH) % g.KT, ci = r / (g.KH * g.KT);
+    const int t = to * g.st - g.pt + kt, h = ho * g.sh - g.ph + kh;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < g.T && h >= 0 && h < g.H) {
+      const int64_t off = ((((int64_t)b * g.Cin + ci) * g.T + t) * g.H + h) * g.W + 4 * w4;
+      if constexpr (XF32) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + off);
+      else {
+        const bf16x4 q = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(x) + off);
+        v = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
+      }
+    }
+    *reinterpret_cast<float4*>(&rows[(int64_t)r * g.W + 4 * w4]) = v;
+  }
+  __syncthreads();
+  const int K8 = g.Kpad / 8;
+  const int64_t row0 = (((int64_t)b * g.To + to) * g.Ho + ho) * g.Wo;
+  for (int i = tid; i < g.Wo * K8; i += 256) {
+    const int wo = i / K8, k0 = (i - wo * K8) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      float val = 0.f;
+      if (k < g.K) {
+        const int r = k / g.KW;                       // row index (ci, kt, kh)
+        const int w = wo * g.sw - g.pw + (k - r * g.KW);
+        if (w >= 0 && w < g.W) val = rows[r * g.W + w];
+      }
+      v[j] = val;
+    }
+    st8_from_f32(col, CF32 ? CSTS_F32 : CSTS_BF16, (row0 + wo) * g.Kpad + k0, v);
+  }
+}
+
 // pos[n][c] = spatial[n % HW][c] + temporal[n / HW][c]   (custom_multimodal_builder.py:362-366)
 __global__ void posembed_kernel(const float* __restrict__ ps, const float* __restrict__ pt, float* __restrict__ pos,
                                 int T, int HW, int C) {
@@ -314,6 +364,19 @@ extern "C" int csts_im2col(const csts_im2col_geom* g, const void* x, int x_dt, v
   p.Kpad = g->Kpad;
   CSTS_REQUIRE(p.Kpad >= p.K, "Kpad < K");
   CSTS_REQUIRE(p.To == g->To && p.Ho == g->Ho && p.Wo == g->Wo, "output grid mismatch");
+  const size_t strip_lds = (size_t)p.Cin * p.KT * p.KH * p.W * 4;
+  const int64_t strips = (int64_t)p.B * p.To * p.Ho;
+  if (strip_lds <= 65536 && p.W % 4 == 0 && p.Kpad % 8 == 0 && strips < ((int64_t)1 << 31) && aligned16(x) &&
+      aligned16(col)) {
+    const bool xf = x_dt == CSTS_F32, cf = col_dt == CSTS_F32;
+    const dim3 grid((unsigned)strips), block(256);
+    if (xf && cf) hipLaunchKernelGGL((im2col_strip_kernel<true, true>), grid, block, strip_lds, stream, p, x, col);
+    else if (xf) hipLaunchKernelGGL((im2col_strip_kernel<true, false>), grid, block, strip_lds, stream, p, x, col);
+    else if (cf) hipLaunchKernelGGL((im2col_strip_kernel<false, true>), grid, block, strip_lds, stream, p, x, col);
+    else hipLaunchKernelGGL((im2col_strip_kernel<false, false>), grid, block, strip_lds, stream, p, x, col);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   const int64_t total = (int64_t)p.B * p.To * p.Ho * p.Wo * p.Kpad;
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p, x, x_dt, col, col_dt);
   CSTS_LAUNCH_CHECK();

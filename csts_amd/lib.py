@@ -98,6 +98,7 @@ SYMBOLS = {
     "csts_gemm": (_I, [C.POINTER(GemmArgs), vp]),
     "csts_gemm_splitk_workspace": (sz, [i64, i64, i64, _I]),
     "csts_gemm_v2_eligible": (_I, [C.POINTER(GemmArgs)]),
+    "csts_gemm_plan": (_I, [C.POINTER(GemmArgs), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, sz, i64, _I, vp]),

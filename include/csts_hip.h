@@ -61,6 +61,7 @@ typedef struct {
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
 size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);
+int csts_gemm_plan(const csts_gemm_args* args, int* v2, int* tile_rows, int* nsplit);   /* which kernel / tile / k-split csts_gemm picks */
 int csts_gemm_v2_eligible(const csts_gemm_args* args);   /* 1 when the fast bf16 kernel (and fused colsum) applies */
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
