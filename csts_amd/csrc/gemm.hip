@@ -588,6 +588,130 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
   }
 }
 
+// =====================================================================================================
+// Grouped weight gradients: MANY independent dW = dY^T X problems (every Linear of the model) in ONE launch.
+// A lone weight gradient of this model has 9..36 output tiles and a reduction over 2 k..262 k tokens, so by itself it
+// needs a deep split-K (slabs + finishing pass) just to occupy the chip.  Queued up for a whole backward pass there are
+// thousands of (tile, token-chunk) work items: the chunk can be long (8192 tokens: a 128-step main loop) and most
+// problems need no split at all.  One workgroup per item; items are independent (a problem with several chunks writes
+// one partial slab per chunk, finished by csts_reduce_rows_batched).  Same tile machinery as gemm2_kernel (TN form).
+// =====================================================================================================
+template <bool A_F32, int MT>
+__global__ __launch_bounds__(256, (MT == 2) ? 3 : 4) void wgrad_grouped_kernel(const csts_wgrad_item* __restrict__ items) {
+  constexpr int BM2 = 64 * MT, NTHR = 256;
+  typedef Oper<false, A_F32, BM2, NTHR> OA;
+  typedef Oper<false, false, 128, NTHR> OB;
+  constexpr int STAGE_BYTES = (OA::LDS_ELEMS + OB::LDS_ELEMS) * 2;
+  constexpr int CS_BYTES = 64 * CS_LD * 4;
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem_raw[SMEM_BYTES];
+  bf16* As = reinterpret_cast<bf16*>(smem_raw);
+  bf16* Bs = As + OA::LDS_ELEMS;
+  const csts_wgrad_item it = items[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = it.m0, n0 = it.n0, M = it.M, N = it.N;
+  const int64_t kbeg = it.kbeg, kend = it.kend;
+  const int nk = (int)((kend - kbeg + BK2 - 1) / BK2);
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr int CPAIRS = BM2 / 2, TPP = NTHR / CPAIRS, KSL = BK2 / TPP;
+  const bool do_colsum = it.colsum != nullptr && n0 == 0;
+  float cs0 = 0.f, cs1 = 0.f;
+
+  OA oa;
+  OB ob;
+  oa.load(it.A, it.lda, m0, M, kbeg, kend, tid);
+  ob.load(it.B, it.ldb, n0, N, kbeg, kend, tid);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    oa.store(As, tid);
+    ob.store(Bs, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      oa.load(it.A, it.lda, m0, M, kbeg + (int64_t)(kt + 1) * BK2, kend, tid);
+      ob.load(it.B, it.ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK2, kend, tid);
+    }
+    if (do_colsum) {
+      const int cp = tid % CPAIRS, k0s = (tid / CPAIRS) * KSL;
+#pragma unroll
+      for (int kk = 0; kk < KSL; ++kk) {
+        const bf16x2 t = *reinterpret_cast<const bf16x2*>(&As[(k0s + kk) * OA::OC_LD + 2 * cp]);
+        cs0 += (float)t[0];
+        cs1 += (float)t[1];
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      bf16x8 a[MT], b[2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = OA::frag(As, wm * 32 * MT + i * 32, ks, lane);
+      b[0] = OB::frag(Bs, wn * 64, ks, lane);
+      b[1] = OB::frag(Bs, wn * 64 + 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+
+  if (do_colsum) {
+    float* red = reinterpret_cast<float*>(smem_raw);           // [TPP][BM2]
+    const int cp = tid % CPAIRS, sl = tid / CPAIRS;
+    red[sl * BM2 + 2 * cp] = cs0;
+    red[sl * BM2 + 2 * cp + 1] = cs1;
+    __syncthreads();
+    if (tid < BM2 && m0 + tid < M) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < TPP; ++q) t += red[q * BM2 + tid];
+      it.colsum[m0 + tid] = t;
+    }
+    __syncthreads();
+  }
+
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+  const int col = (tid & 15) * 8;
+  const int64_t n = n0 + col;
+  constexpr int NGRP = BM2 / 64;
+#pragma unroll
+  for (int g = 0; g < NGRP; ++g) {
+    if (g > 0) __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int unit = wm * MT + mt;
+      if ((unit >> 1) != g) continue;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[((unit & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS_LD + wn * 64 + nt * 32 + (lane & 31)] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < 1024 / NTHR; ++i) {
+      const int row = (tid >> 4) + (NTHR / 16) * i;
+      const int64_t m = m0 + g * 64 + row;
+      if (m >= M) continue;
+      const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col]);
+      const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col + 4]);
+      float4* dst = reinterpret_cast<float4*>(it.C + m * it.ldc + n);
+      dst[0] = c0;
+      dst[1] = c1;
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC, bool A_F32, bool B_F32>
 void launch2(const Params& p, int bm, dim3 grid, hipStream_t s) {
   if (bm == 256) hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, A_F32, B_F32, 4, 2>), grid, dim3(256), 0, s, p);
@@ -746,4 +870,23 @@ extern "C" size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, in
   // upper bound over both kernels' k-chunking (v1: BK 32, v2: BK 64)
   const int64_t c1 = cdiv(cdiv(K, BK), split_k) * BK, c2 = cdiv(cdiv(K, BK2), split_k) * BK2;
   return (size_t)std::max(cdiv(K, c1), cdiv(K, c2)) * M * (N + 1) * sizeof(float);   // + colsum partials
+}
+
+// items: DEVICE array.  Every item: A = dY [tokens][M] (a_f32 ? fp32 : bf16, lda), B = X [tokens][N] bf16 (ldb), C fp32
+// [M][N] tile target (ldc; the weight gradient itself or one chunk's partial slab), tokens [kbeg, kend), tile origin
+// (m0, n0), rows = tile height (64 or 128; the whole launch uses one height).  colsum (optional): sum over the chunk's
+// tokens of dY[:, m] for the tile's rows (bias gradient), written by the n0 == 0 tiles.
+extern "C" int csts_wgrad_grouped(const csts_wgrad_item* device_items, int nitems, int a_f32, int tile_rows, hipStream_t stream) {
+  CSTS_REQUIRE(device_items != nullptr && nitems > 0, "no items");
+  CSTS_REQUIRE(tile_rows == 64 || tile_rows == 128, "tile_rows must be 64 or 128");
+  const dim3 grid((unsigned)nitems), block(256);
+  if (a_f32) {
+    if (tile_rows == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<true, 2>), grid, block, 0, stream, device_items);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<true, 1>), grid, block, 0, stream, device_items);
+  } else {
+    if (tile_rows == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<false, 2>), grid, block, 0, stream, device_items);
+    else hipLaunchKernelGGL((wgrad_grouped_kernel<false, 1>), grid, block, 0, stream, device_items);
+  }
+  CSTS_LAUNCH_CHECK();
+  return 0;
 }

@@ -75,6 +75,11 @@ class Im2colGeom(C.Structure):
                 ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Kpad", C.c_int)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("colsum", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("kbeg", i64), ("kend", i64), ("M", C.c_int), ("N", C.c_int), ("m0", C.c_int), ("n0", C.c_int)]
+
+
 class ReduceDesc(C.Structure):
     _fields_ = [("ws", vp), ("out", vp), ("nrows", i64), ("ncols", i64), ("scale", C.c_float), ("pad_", C.c_int)]
 
@@ -98,6 +103,7 @@ SYMBOLS = {
     "csts_gemm": (_I, [C.POINTER(GemmArgs), vp]),
     "csts_gemm_splitk_workspace": (sz, [i64, i64, i64, _I]),
     "csts_gemm_v2_eligible": (_I, [C.POINTER(GemmArgs)]),
+    "csts_wgrad_grouped": (_I, [vp, _I, _I, _I, vp]),
     "csts_gemm_plan": (_I, [C.POINTER(GemmArgs), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),

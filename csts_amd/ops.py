@@ -118,29 +118,118 @@ def _can_defer() -> bool:
     return True
 
 
-def _defer(ws: torch.Tensor, out: torch.Tensor, nrows: int, ncols: int):
+def _defer(ws: torch.Tensor, out, nrows: int, ncols: int):
+    """out: the tensor to fill, or its raw device address (see queue_wgrad for why no reference may be held)."""
     _deferred.append((ws, out, int(nrows), int(ncols)))
 
 
 def flush_deferred():
-    """Finish every deferred reduction on the current stream (idempotent; gradient-bucket hooks call it early)."""
+    """Finish the queued weight gradients and every deferred reduction on the current stream (idempotent)."""
     _deferred_cb[0] = False
+    flush_wgrads()
     if not _deferred:
         return
-    items = list(_deferred)
+    items = sorted(_deferred, key=lambda it: it[3])
     _deferred.clear()
-    dev = items[0][1].device
-    descs = (L.ReduceDesc * len(items))()
-    for i, (ws, out, nrows, ncols) in enumerate(items):
-        descs[i].ws, descs[i].out, descs[i].nrows, descs[i].ncols, descs[i].scale = ws.data_ptr(), out.data_ptr(), nrows, ncols, 1.0
+    dev = items[0][0].device
     tab = _deferred_tables.get(dev.index)
     if tab is None:
-        tab = _deferred_tables[dev.index] = HostTable(C.sizeof(L.ReduceDesc) * 1024, dev)
-    for lo in range(0, len(items), 1024):
-        chunk = items[lo:lo + 1024]
-        ptr = tab.upload(bytes(descs)[lo * C.sizeof(L.ReduceDesc):(lo + len(chunk)) * C.sizeof(L.ReduceDesc)])
-        L.check(_lib().csts_reduce_rows_batched(ptr, len(chunk), max(it[3] for it in chunk), _stream()),
-                "csts_reduce_rows_batched")
+        tab = _deferred_tables[dev.index] = HostTable(C.sizeof(L.ReduceDesc) * 2048, dev, ring=4, captures=8)
+    # one launch per size class (the grid is sized by the widest reduction of the launch)
+    descs = (L.ReduceDesc * len(items))()
+    for i, (ws, out, nrows, ncols) in enumerate(items):
+        descs[i].ws, descs[i].out = ws.data_ptr(), (out if isinstance(out, int) else out.data_ptr())
+        descs[i].nrows, descs[i].ncols, descs[i].scale = nrows, ncols, 1.0
+    raw = bytes(descs)
+    sz = C.sizeof(L.ReduceDesc)
+    if len(items) > 2048:
+        raise L.CstsError("too many deferred reductions in one backward pass")
+    base = tab.upload(raw)
+    lo = 0
+    while lo < len(items):
+        hi = lo + 1
+        while hi < len(items) and items[hi][3] <= 4 * items[lo][3]:
+            hi += 1
+        L.check(_lib().csts_reduce_rows_batched(base + lo * sz, hi - lo, items[hi - 1][3], _stream()), "csts_reduce_rows_batched")
+        lo = hi
+
+
+# Weight gradients of the Linear layers (dW = dY^T X) are off the critical path of backward: inside a backward pass they
+# are queued and computed by csts_wgrad_grouped at the end, all layers in one launch per dY dtype.  A weight gradient on
+# its own needs a deep split-K to fill the chip; together they provide thousands of (tile, token-chunk) work items, so
+# chunks are long (WGRAD_CHUNK tokens) and most layers need no split-K partials at all.
+GROUP_WGRADS = os.environ.get("CSTS_GROUP_WGRADS", "1") != "0"
+WGRAD_CHUNK = 8192
+_wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
+_wg_tables = {}
+
+
+def queue_wgrad(dY, X, tokens, N, K, want_bias):
+    """Queue dW[N,K] = dY[tokens,N]^T X[tokens,K] (+ db[N]) for the grouped launch; returns (dW, db) to hand to autograd
+    now (complete when backward returns), or None when the problem has to run in line."""
+    if not (GROUP_WGRADS and DEFER_REDUCTIONS and X.dtype == torch.bfloat16 and dY.dtype in (torch.float32, torch.bfloat16)
+            and N % 8 == 0 and K % 8 == 0 and dY.is_contiguous() and X.is_contiguous() and tokens >= 256):
+        return None
+    if not _can_defer():
+        return None
+    dW = torch.empty(N, K, dtype=torch.float32, device=dY.device)
+    db = torch.empty(N, dtype=torch.float32, device=dY.device) if want_bias else None
+    # Only the ADDRESSES of dW / db are kept: autograd's AccumulateGrad adopts a gradient tensor as p.grad without a copy
+    # only while nobody else references it (a second reference would make it clone the still-empty buffer now).  The
+    # memory stays alive as p.grad until the grouped launch at the end of this backward pass.
+    _wgq.append((dY, X, dW.data_ptr(), (db.data_ptr() if db is not None else 0), tokens, N, K))
+    return dW, db
+
+
+def flush_wgrads():
+    if not _wgq:
+        return
+    q = list(_wgq)
+    _wgq.clear()
+    dev = q[0][0].device
+    tab = _wg_tables.get(dev.index)
+    if tab is None:
+        tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=3, captures=4)
+    keep = []
+    for a_f32 in (False, True):
+        for rows in (128, 64):
+            items = []
+            for (dY, X, dW, db, tokens, N, K) in q:
+                if (dY.dtype == torch.float32) != a_f32:
+                    continue
+                # 64-row tiles where 128 would pad the output by more than a fifth (N = 96, 288, ...)
+                pad128 = -(-N // 128) * 128
+                tile = 64 if (pad128 - N) * 5 > N else 128
+                if tile != rows:
+                    continue
+                nch = -(-tokens // WGRAD_CHUNK)
+                if nch > 1:
+                    slab = torch.empty(nch, N, K, dtype=torch.float32, device=dev)
+                    _defer(slab, dW, nch, N * K)
+                    cs = None
+                    if db:
+                        cs = torch.empty(nch, N, dtype=torch.float32, device=dev)
+                        _defer(cs, db, nch, N)
+                    keep.append((slab, cs))
+                for c in range(nch):
+                    kb, ke = c * WGRAD_CHUNK, min(tokens, (c + 1) * WGRAD_CHUNK)
+                    Cp = dW if nch == 1 else slab.data_ptr() + c * N * K * 4
+                    csp = 0 if not db else (db if nch == 1 else cs.data_ptr() + c * N * 4)
+                    for m0 in range(0, N, rows):
+                        for n0 in range(0, K, 128):
+                            items.append((ke - kb, dY.data_ptr(), X.data_ptr(), Cp, csp, N, K, K, kb, ke, N, K, m0, n0))
+            if not items:
+                continue
+            items.sort(key=lambda t: -t[0])            # longest chunks first: the short ones fill the tail
+            arr = (L.WgradItem * len(items))()
+            for i, t in enumerate(items):
+                (_, arr[i].A, arr[i].B, arr[i].C, arr[i].colsum, arr[i].lda, arr[i].ldb, arr[i].ldc, arr[i].kbeg, arr[i].kend,
+                 arr[i].M, arr[i].N, arr[i].m0, arr[i].n0) = t
+            if len(items) > 16384:
+                raise L.CstsError("too many grouped weight-gradient work items")
+            ptr = tab.upload(bytes(arr))
+            L.check(_lib().csts_wgrad_grouped(ptr, len(items), 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
+    del q, keep
 
 
 # ----------------------------------------------------------------------------------------- raw wrappers
@@ -199,9 +288,16 @@ def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
     return max(1, min(512 // max(tiles, 1), math.ceil(Kred / 512)))
 
 
-def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int, want_bias: bool = False):
+def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int, want_bias: bool = False,
+           allow_queue: bool = True):
     """dW[N,K] = dY[M,N]^T X[M,K] (fp32, split over M); with want_bias also db[N] = colsum(dY), fused into the same
-    kernel when the bf16 v2 GEMM applies."""
+    kernel when the bf16 v2 GEMM applies.  Inside a backward pass the problem is queued for the grouped end-of-backward
+    launch (queue_wgrad): the returned tensors are then complete when backward returns, NOT before -- callers that
+    post-process dW themselves pass allow_queue=False."""
+    if compute == BF16 and allow_queue:
+        queued = queue_wgrad(dY, X, M, N, K, want_bias)
+        if queued is not None:
+            return queued if want_bias else queued[0]
     split = _wgrad_split(N, K, M)
     det = split > 1 and _lib().csts_gemm_splitk_workspace(N, K, M, split) <= SPLITK_WS_LIMIT
     dW = (torch.zeros if (split > 1 and not det) else torch.empty)(N, K, dtype=torch.float32, device=dY.device)
@@ -784,7 +880,7 @@ class PatchEmbedFn(Function):
         B, N, T, HW, Cout, K, Kpad, compute, wshape = ctx.meta
         dy = dy.contiguous()
         M = B * N
-        dWp = _wgrad(dy, col, M, Cout, Kpad, compute)
+        dWp = _wgrad(dy, col, M, Cout, Kpad, compute, allow_queue=False)
         dW = dWp[:, :K].reshape(wshape)
         db = colsum(dy, 1, M, Cout)
         dpos = colsum(dy, 1, B, N * Cout)                       # sum over batch -> (N*Cout)

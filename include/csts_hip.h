@@ -64,6 +64,19 @@ size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);
 int csts_gemm_plan(const csts_gemm_args* args, int* v2, int* tile_rows, int* nsplit);   /* which kernel / tile / k-split csts_gemm picks */
 int csts_gemm_v2_eligible(const csts_gemm_args* args);   /* 1 when the fast bf16 kernel (and fused colsum) applies */
 
+/* Grouped weight gradients: every dW[M,N] = dY[tokens,M]^T X[tokens,N] of a backward pass (nn.Linear weight gradients of
+ * attention.py:88-89, common.py:20-21 ...) as (tile, token-chunk) work items of ONE launch; items live in DEVICE memory.
+ * A (dY) is bf16 or fp32 for the whole launch (a_f32), B (X) bf16, C fp32 (the gradient itself, or one chunk's partial slab
+ * to be summed by csts_reduce_rows_batched); tile_rows (64 | 128) x 128 tiles, all of one height per launch.
+ * colsum (optional): bias-gradient partial sum over the item's tokens for the tile's rows (written by n0 == 0 tiles). */
+typedef struct {
+  const void* A; const void* B; float* C; float* colsum;
+  int64_t lda, ldb, ldc;
+  int64_t kbeg, kend;
+  int M, N, m0, n0;
+} csts_wgrad_item;
+int csts_wgrad_grouped(const csts_wgrad_item* device_items, int nitems, int a_f32, int tile_rows, hipStream_t stream);
+
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */
 int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt, float* mean,
