@@ -222,7 +222,39 @@ __global__ __launch_bounds__(1024) void reduce_rows_batched_kernel(const csts_re
   }
 }
 
+// wide, shallow reductions (split-K partial slabs of the grouped weight gradients: a handful of rows, up to millions of
+// columns): one thread per 4 consecutive columns, rows summed in order -> 16-byte loads, no idle row lanes
+__global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const csts_reduce_desc* __restrict__ descs) {
+  const csts_reduce_desc d = descs[blockIdx.y];
+  const int64_t nvec = d.ncols >> 2;           // host guarantees ncols % 4 == 0 and 16-byte aligned pointers
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* p = reinterpret_cast<const float4*>(d.ws) + v;
+    int64_t i = 0;
+    for (; i + 3 < d.nrows; i += 4) {
+      const float4 a = p[i * nvec], b = p[(i + 1) * nvec], c = p[(i + 2) * nvec], e = p[(i + 3) * nvec];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+      s.x += e.x; s.y += e.y; s.z += e.z; s.w += e.w;
+    }
+    for (; i < d.nrows; ++i) {
+      const float4 a = p[i * nvec];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    reinterpret_cast<float4*>(d.out)[v] = make_float4(s.x * d.scale, s.y * d.scale, s.z * d.scale, s.w * d.scale);
+  }
+}
+
 }  // namespace
+
+extern "C" int csts_reduce_rows_wide(const csts_reduce_desc* device_descs, int n, int64_t max_ncols, hipStream_t stream) {
+  CSTS_REQUIRE(device_descs != nullptr && n > 0 && n < 65536 && max_ncols > 0, "bad args");
+  const unsigned gx = (unsigned)std::min<int64_t>(cdiv(max_ncols / 4, 256), 4096);
+  hipLaunchKernelGGL(reduce_rows_wide_kernel, dim3(gx, (unsigned)n), dim3(256), 0, stream, device_descs);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int csts_reduce_rows_batched(const csts_reduce_desc* device_descs, int n, int64_t max_ncols, hipStream_t stream) {
   CSTS_REQUIRE(device_descs != nullptr && n > 0 && n < 65536 && max_ncols > 0, "bad args");

@@ -109,6 +109,7 @@ SYMBOLS = {
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, sz, i64, _I, vp]),
     "csts_reduce_rows_batched": (_I, [vp, _I, i64, vp]),
+    "csts_reduce_rows_wide": (_I, [vp, _I, i64, vp]),
     "csts_layernorm_bwd2": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),
     "csts_reduce_rows": (_I, [vp, vp, i64, i64, _F, vp]),
     "csts_dwconv_strided": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, vp, _I, vp]),

@@ -99,6 +99,8 @@ int csts_reduce_rows(const float* ws, float* out, int64_t nrows, int64_t ncols, 
 /* many deferred second stages (LayerNorm dgamma/dbeta, stencil dweight) in ONE launch; descriptors in DEVICE memory */
 typedef struct { const float* ws; float* out; int64_t nrows; int64_t ncols; float scale; int pad_; } csts_reduce_desc;
 int csts_reduce_rows_batched(const csts_reduce_desc* device_descs, int n, int64_t max_ncols, hipStream_t stream);
+/* same contract for wide, shallow reductions (few rows, many columns): needs ncols % 4 == 0 and 16-byte aligned ws / out */
+int csts_reduce_rows_wide(const csts_reduce_desc* device_descs, int n, int64_t max_ncols, hipStream_t stream);
 
 /* ---- depthwise 3x3x3 token stencils: attention_pool's Conv3d (attention.py:11-49,104-116) and
  *      attention_upsample's ConvTranspose3d (attention.py:251-289,344-348).  "fine" is the larger grid.
