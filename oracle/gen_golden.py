@@ -338,6 +338,24 @@ def gen_model():
     save("model_T16_B1.npz", logits=t2n(lg), v_emb=t2n(v16), a_emb=t2n(a16))
 
 
+def gen_model_t32():
+    """BASELINE config 5 geometry: the Aria YAML with DATA.NUM_FRAMES 32 (the longer-T token grid), B = 1 forward."""
+    from slowfast.models.custom_multimodal_builder import CSTS
+    cfg = get_cfg()
+    cfg.merge_from_file("/root/reference/configs/Aria/CSTS_Aria_Gaze_Forecast.yaml")
+    cfg.NUM_GPUS = 0
+    cfg.MODEL.LOSS_FUNC = "kldiv+egonce"
+    cfg.DATA.NUM_FRAMES = 32
+    m = load_seeded(CSTS(cfg)).eval()
+    b = O.synthetic_batch(1, 32, 256, seed=1003)
+    with torch.no_grad():
+        lg, v, a = m([b["video"]], b["audio"], return_embed=True)
+    heat = ref_utils.frame_softmax(lg, 2)
+    save("model_T32_B1_aria.npz", logits=t2n(lg).astype(np.float16), v_emb=t2n(v), a_emb=t2n(a),
+         argmax=t2n(heat).reshape(32, -1).argmax(-1).astype(np.int32),
+         logits_head=t2n(lg).reshape(-1)[:4096].astype(np.float32))
+
+
 def gen_lr():
     from slowfast.utils import lr_policy
     cfg = make_cfg(8)
@@ -355,3 +373,5 @@ if __name__ == "__main__":
         gen_lr()
     if "model" in what:
         gen_model()
+    if "model" in what or "t32" in what:
+        gen_model_t32()

@@ -211,6 +211,31 @@ def test_T16_forward_fp32():
     assert rel_l2(lg, g["logits"]) < 1e-4 and rel_l2(v, g["v_emb"]) < 1e-4 and rel_l2(a, g["a_emb"]) < 1e-4
 
 
+def test_T32_aria_forward_fp32_and_bf16():
+    """BASELINE config 5 geometry: CSTS_Aria_Gaze_Forecast.yaml with DATA.NUM_FRAMES 32 (4x the token grid of the YAML
+    default: K/V of 4096 tokens per head exceed LDS, the attention kernels tile over N_kv with the online softmax)."""
+    aria = os.path.join(os.path.dirname(YAML), "..", "Aria", "CSTS_Aria_Gaze_Forecast.yaml")
+    g = _load("model_T32_B1_aria.npz")
+    b = dev_batch(1, 32, 1003)
+    for compute, tol in (("fp32", 1e-3), ("bf16", 5e-2)):
+        cfg = load_yaml(aria, ["NUM_GPUS", 1, "MODEL.LOSS_FUNC", "kldiv+egonce", "DATA.NUM_FRAMES", 32, "CSTS_AMD.COMPUTE", compute])
+        _MODELS.clear()
+        m = build_model(cfg)
+        m.load_state_dict(O.seeded_params(32, 256), strict=True)
+        m.eval()
+        with torch.no_grad():
+            lg, v, a = m([b["video"]], b["audio"], return_embed=True)
+        assert lg.shape == (1, 1, 32, 64, 64)
+        assert rel_l2(lg, g["logits"].astype("float32")) < tol            # golden stored as fp16 (5e-4 of its own)
+        if compute == "fp32":
+            assert rel_l2(lg.flatten()[:4096], g["logits_head"]) < 1e-4   # fp32 slice of the golden
+            assert rel_l2(v, g["v_emb"]) < 1e-4 and rel_l2(a, g["a_emb"]) < 1e-4
+            heat = ops.frame_softmax(lg, 2.0)
+            assert (heat.reshape(32, -1).argmax(-1).cpu().numpy() == g["argmax"]).all()
+        del m
+    torch.cuda.empty_cache()
+
+
 def test_train_step_runs_bf16_b4():
     """BASELINE config 3 shape: bs=4 train step (fwd + KLDiv + 0.05 EgoNCE + bwd + clip + AdamW), bf16 mode."""
     m, cfg = make_model("bf16")

@@ -346,6 +346,38 @@ def test_losses_against_oracle():
             4 * math.log(4096)).mean())) < 1e-5
 
 
+def test_grouped_weight_gradients_match_inline():
+    """Linear / MLP weight and bias gradients through the grouped end-of-backward launch (several token chunks with
+    split-K partial slabs, fp32 and bf16 dY) == the in-line split-K GEMMs == torch, bf16 mode."""
+    M, Cin, Hd, Cout = 20000, 192, 768, 96          # 20000 tokens: 3 chunks of WGRAD_CHUNK
+    x = rnd(M, Cin, seed=1).bfloat16()
+    W1, b1 = rnd(Hd, Cin, seed=2, scale=0.05), rnd(Hd, seed=3, scale=0.1)
+    W2, b2 = rnd(Cout, Hd, seed=4, scale=0.05), rnd(Cout, seed=5, scale=0.1)
+    res = rnd(M, Cout, seed=6)
+    dy = rnd(M, Cout, seed=7)
+
+    def run(grouped):
+        old = ops.GROUP_WGRADS
+        ops.GROUP_WGRADS = grouped
+        try:
+            ps = [t.clone().requires_grad_() for t in (W1, b1, W2, b2)]
+            y = ops.mlp(x, ps[0], ps[1], ps[2], ps[3], residual=res, act_dt=L.BF16, out_dt=L.F32, compute=L.BF16)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in ps]
+        finally:
+            ops.GROUP_WGRADS = old
+
+    g_grouped, g_inline = run(True), run(False)
+    xr = x.float()
+    w = [t.clone().requires_grad_() for t in (W1, b1, W2, b2)]
+    yr = F.linear(F.gelu(F.linear(xr, w[0].bfloat16().float(), w[1])), w[2].bfloat16().float(), w[3]) + res
+    yr.backward(dy)
+    for a, b_, r in zip(g_grouped, g_inline, w):
+        assert rel_l2(a, b_) < 2e-3
+        assert rel_l2(a, r.grad) < 2e-2
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def test_fused_adamw_matches_torch_clip_plus_adamw():
     """csts_adamw_step == clip_grad_norm_(1.0) + torch.optim.AdamW(eps 1e-8) (train_avgaze_net.py:101-109,

@@ -206,3 +206,20 @@ def test_T16_forward():
     g = _load("model_T16_B1.npz")
     assert lg.shape == (1, 1, 16, 64, 64)
     assert rel_l2(lg, g["logits"]) < TOL and rel_l2(v, g["v_emb"]) < TOL and rel_l2(a, g["a_emb"]) < TOL
+
+
+def test_T32_aria_forward():
+    """BASELINE config 5 geometry (CSTS_Aria_Gaze_Forecast.yaml + DATA.NUM_FRAMES 32, the longer-T token grid): the
+    oracle against the fixture generated from the reference (logits stored as fp16 plus an fp32 slice, embeddings,
+    per-frame argmax)."""
+    P = O.seeded_params(32, 256)
+    b = O.synthetic_batch(1, 32, 256, seed=1003)
+    with torch.no_grad():
+        lg, v, a = O.csts_forward(P, b["video"], b["audio"], 32, 256, return_embed=True)
+    g = _load("model_T32_B1_aria.npz")
+    assert lg.shape == (1, 1, 32, 64, 64)
+    assert rel_l2(lg, g["logits"].astype(np.float32)) < 1e-3              # fp16 storage
+    assert rel_l2(lg.reshape(-1)[:4096], g["logits_head"]) < TOL
+    assert rel_l2(v, g["v_emb"]) < TOL and rel_l2(a, g["a_emb"]) < TOL
+    heat = O.frame_softmax(lg, 2.0)
+    assert (heat.reshape(32, -1).argmax(-1).numpy() == g["argmax"]).all()
