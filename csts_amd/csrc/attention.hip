@@ -502,26 +502,36 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnP p, int HD) {
 }
 
 // delta[b,h,q] = sum_d dO * O   (32 lanes per row)
+// delta[b,h,q] = sum_d O * dO : a group of GL lanes per row, 8 elements (one 16-byte load of O and of dO) per lane,
+// HD/8 lanes active; rows are walked token-major (heads innermost) so a wave reads contiguous memory
+template <int GL>
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p, int HD) {
-  const int sub = threadIdx.x & 31;
-  const int64_t rows = (int64_t)p.B * p.H * p.Nq;
-  const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
+  const int sub = threadIdx.x % GL;
+  const bool active = sub * 8 < HD;
+  const int c8 = min(sub * 8, HD - 8);
+  const int64_t rows = (int64_t)p.B * p.Nq * p.H;
+  const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
+  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) / GL;
   for (int64_t row = row0; row < rows; row += stride) {
-    const int q = (int)(row % p.Nq);
-    const int64_t bh = row / p.Nq;
-    const int head = (int)(bh % p.H), b = (int)(bh / p.H);
-    const int64_t oo = (int64_t)b * p.o_bs + (int64_t)q * p.o_ts + (int64_t)head * p.o_hs;
-    const int64_t od = (int64_t)b * p.do_bs + (int64_t)q * p.do_ts + (int64_t)head * p.do_hs;
+    const int head = (int)(row % p.H);
+    const int64_t bq = row / p.H;
+    const int q = (int)(bq % p.Nq), b = (int)(bq / p.Nq);
+    const int64_t oo = (int64_t)b * p.o_bs + (int64_t)q * p.o_ts + (int64_t)head * p.o_hs + c8;
+    const int64_t od = (int64_t)b * p.do_bs + (int64_t)q * p.do_ts + (int64_t)head * p.do_hs + c8;
+    float o8[8], d8[8];
+    ld8_as_f32(p.O, p.dt, oo, o8);
+    ld8_as_f32(p.dO, p.dt, od, d8);
     float s = 0.f;
-    for (int d = sub; d < HD; d += 32) s += ld_as_f32(p.O, p.dt, oo + d) * ld_as_f32(p.dO, p.dt, od + d);
+    if (active) {
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (sub == 0) const_cast<float*>(p.delta)[row] = s;
+      for (int j = 0; j < 8; ++j) s += o8[j] * d8[j];
+    }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) const_cast<float*>(p.delta)[((int64_t)b * p.H + head) * p.Nq + q] = s;
   }
 }
 
-// probabilities for the visualisation outputs (return_spatial_attn / return_temporal_attn), tiny N only
 __global__ __launch_bounds__(256) void attn_probs_kernel(AttnP p, int HD, float* probs) {
   const int64_t total = (int64_t)p.B * p.H * p.Nq * p.Nk;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -651,8 +661,12 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
   // 1. delta = rowsum(dO * O)
   {
     const int64_t rows = (int64_t)a->B * a->H * a->Nq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)std::min<int64_t>(cdiv(rows * 32, 256), 8192)), dim3(256), 0,
-                       stream, p, a->head_dim);
+    if (a->head_dim <= 128)
+      hipLaunchKernelGGL(attn_delta_kernel<16>, dim3((unsigned)std::min<int64_t>(cdiv(rows * 16, 256), 8192)), dim3(256), 0,
+                         stream, p, a->head_dim);
+    else
+      hipLaunchKernelGGL(attn_delta_kernel<32>, dim3((unsigned)std::min<int64_t>(cdiv(rows * 32, 256), 8192)), dim3(256), 0,
+                         stream, p, a->head_dim);
     CSTS_LAUNCH_CHECK();
   }
   // 2. dQ

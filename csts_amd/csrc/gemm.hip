@@ -564,12 +564,12 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
       if (p.epilogue == CSTS_EPI_GELU) {
         if (p.aux != nullptr) st8_from_f32(p.aux, p.aux_dt, m * p.ldaux + n, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        for (int j = 0; j < 8; ++j) v[j] = (p.aux_dt == CSTS_BF16) ? gelu_fast(v[j]) : gelu_f(v[j]);
       } else if (p.epilogue == CSTS_EPI_DGELU) {
         float h[8];
         ld8_as_f32(p.aux, p.aux_dt, m * p.ldaux + n, h);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= dgelu_f(h[j]);
+        for (int j = 0; j < 8; ++j) v[j] *= (p.aux_dt == CSTS_BF16) ? dgelu_fast(h[j]) : dgelu_f(h[j]);
       }
       if (p.row_scale != nullptr) {
         const float sc = p.row_scale[m / p.rows_per_scale];
@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256, (MT == 2) ? 3 : 4) void wgrad_grouped_kernel(c
   bf16* As = reinterpret_cast<bf16*>(smem_raw);
   bf16* Bs = As + OA::LDS_ELEMS;
   const csts_wgrad_item it = items[blockIdx.x];
+  if (it.A == nullptr) return;          // padding slot (the host equalises the per-XCD lists); block-uniform
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = it.m0, n0 = it.n0, M = it.M, N = it.N;

@@ -223,15 +223,35 @@ def flush_wgrads():
                             items.append((ke - kb, dY.data_ptr(), X.data_ptr(), Cp, csp, N, K, K, kb, ke, N, K, m0, n0))
             if not items:
                 continue
-            items.sort(key=lambda t: -t[0])            # longest chunks first: the short ones fill the tail
-            arr = (L.WgradItem * len(items))()
-            for i, t in enumerate(items):
-                (_, arr[i].A, arr[i].B, arr[i].C, arr[i].colsum, arr[i].lda, arr[i].ldb, arr[i].ldc, arr[i].kbeg, arr[i].kend,
-                 arr[i].M, arr[i].N, arr[i].m0, arr[i].n0) = t
-            if len(items) > 16384:
+            # Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2: the tiles of
+            # one tile-row (same dY panel, items are appended row by row) go to ONE XCD, rows are spread over the XCDs by
+            # load (long chunks first), and XCD x's list is laid out at positions x, x + 8, x + 16, ...
+            # (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles of a row landed on different XCDs)
+            groups, cur = [], []
+            for t in items:
+                if cur and (t[1], t[3], t[8], t[12]) != (cur[0][1], cur[0][3], cur[0][8], cur[0][12]):
+                    groups.append(cur)
+                    cur = []
+                cur.append(t)
+            groups.append(cur)
+            groups.sort(key=lambda g_: -g_[0][0] * len(g_))
+            lists, load = [[] for _ in range(8)], [0] * 8
+            for g_ in groups:
+                x = load.index(min(load))
+                lists[x].extend(g_)
+                load[x] += g_[0][0] * len(g_)
+            depth = max(len(l_) for l_ in lists)
+            n_items = depth * 8
+            if n_items > 16384:
                 raise L.CstsError("too many grouped weight-gradient work items")
+            arr = (L.WgradItem * n_items)()            # zero-initialised: padding slots have A == NULL (the kernel skips them)
+            for x in range(8):
+                for slot, t in enumerate(lists[x]):
+                    i = slot * 8 + x
+                    (_, arr[i].A, arr[i].B, arr[i].C, arr[i].colsum, arr[i].lda, arr[i].ldb, arr[i].ldc, arr[i].kbeg,
+                     arr[i].kend, arr[i].M, arr[i].N, arr[i].m0, arr[i].n0) = t
             ptr = tab.upload(bytes(arr))
-            L.check(_lib().csts_wgrad_grouped(ptr, len(items), 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
+            L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
     del q, keep
 
 
