@@ -298,8 +298,15 @@ def main():
                 traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(fl / sec / 1e12, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / peak, 4),
+        # the binding roofline of this kernel: t_min = max(flops / P_mfma, algorithmic bytes / P_hbm)
+        t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        hbm_bound = t_hbm > t_mfma
+        roof = {"bound": "hbm" if hbm_bound else "mfma", "kernel": name,
+                "achieved": round(by / sec / 1e9, 1) if hbm_bound else round(fl / sec / 1e12, 2),
+                "peak": PEAK_HBM_GBS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(max(t_mfma, t_hbm) / sec, 4),
+                "mfma_tflops": round(fl / sec / 1e12, 2), "mfma_frac": round(t_mfma / sec, 4),
+                "algorithmic_gbps": round(by / sec / 1e9, 1), "hbm_frac": round(t_hbm / sec, 4),
                 "traffic": traffic, "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
                 "algorithmic_flop_per_launch": round(fl / max(n, 1)), "algorithmic_bytes_per_launch": round(by / max(n, 1)),
                 "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2), "all_gemm_ms_per_step": round(tot_sec / 2 * 1e3, 2),
