@@ -167,6 +167,203 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Vectorised forms (C % 8 == 0, the only case the model produces: C in {96, 192, 384, 768}): a group of GL lanes owns a
+// row, every lane NCH chunks of 8 consecutive channels -> 16-byte loads / stores instead of one element per lane per
+// instruction, statistics by shuffles inside the group, 64 / GL rows per wave and R rows in flight per group.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool F32> __device__ __forceinline__ void ld8t(const void* p, int64_t i, float (&o)[8]) {
+  if constexpr (F32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+    const float4 a = q[0], b = q[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p) + i);
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+}
+template <bool F32> __device__ __forceinline__ void st8t(void* p, int64_t i, const float (&o)[8]) {
+  if constexpr (F32) {
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + i);
+    q[0] = make_float4(o[0], o[1], o[2], o[3]);
+    q[1] = make_float4(o[4], o[5], o[6], o[7]);
+  } else {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)o[j];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p) + i) = v;
+  }
+}
+template <int GL> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int GL, int NCH, int R, bool XF32, bool YF32>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, void* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                         int C, float eps) {
+  const int sub = threadIdx.x % GL;
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GL, ngrp = (int64_t)gridDim.x * 256 / GL;
+  int c0[NCH];
+  bool act[NCH];
+  float gm[NCH][8], bt[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (sub + GL * i) * 8;
+    act[i] = c < C;
+    c0[i] = min(c, C - 8);
+    ld8t<true>(gamma, c0[i], gm[i]);
+    ld8t<true>(beta, c0[i], bt[i]);
+  }
+  const float invC = 1.f / C;
+  for (int64_t row0 = grp * R; row0 < rows; row0 += ngrp * R) {
+    float v[R][NCH][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = min(row0 + r, rows - 1);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) ld8t<XF32>(x, row * C + c0[i], v[r][i]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (act[i]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += v[r][i][j];
+        }
+      const float mu = group_sum<GL>(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (act[i]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = v[r][i][j] - mu; q += d * d; }
+        }
+      const float rs = rsqrtf(group_sum<GL>(q) * invC + eps);
+      const int64_t row = row0 + r;
+      if (row < rows) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (act[i]) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[r][i][j] - mu) * rs * gm[i][j] + bt[i][j];
+            st8t<YF32>(y, row * C + c0[i], o);
+          }
+        if (sub == 0) {
+          if (mean) mean[row] = mu;
+          if (rstd) rstd[row] = rs;
+        }
+      }
+    }
+  }
+}
+
+template <int GL, int NCH, int R, bool DYF32, bool XF32>
+__global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, void* __restrict__ dx,
+                                                         const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
+                                                         int C, const float* __restrict__ gamma1, bf16* __restrict__ dx16) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [512 / GL groups][2*C]
+  const int64_t ro = (int64_t)blockIdx.y * rows;               // segment (second stacked tensor), see ln_bwd_kernel
+  if (blockIdx.y == 1) gamma = gamma1;
+  ws += (int64_t)blockIdx.y * gridDim.x * 2 * C;
+  const int sub = threadIdx.x % GL, gib = threadIdx.x / GL;    // group in block
+  constexpr int GPB = 512 / GL;
+  const int64_t grp = (int64_t)blockIdx.x * GPB + gib, ngrp = (int64_t)gridDim.x * GPB;
+  int c0[NCH];
+  bool act[NCH];
+  float gm[NCH][8], dg[NCH][8], db[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (sub + GL * i) * 8;
+    act[i] = c < C;
+    c0[i] = min(c, C - 8);
+    ld8t<true>(gamma, c0[i], gm[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+  }
+  const float invC = 1.f / C;
+  for (int64_t row0 = grp * R; row0 < rows; row0 += ngrp * R) {
+    float d[R][NCH][8], xv[R][NCH][8], ad[R][NCH][8], mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = ro + min(row0 + r, rows - 1);
+      mu[r] = mean[row];
+      rs[r] = rstd[row];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        ld8t<DYF32>(dy, row * C + c0[i], d[r][i]);
+        ld8t<XF32>(x, row * C + c0[i], xv[r][i]);
+        if (addend) ld8t<XF32>(addend, row * C + c0[i], ad[r][i]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ad[r][i][j] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool live = row0 + r < rows;
+      float s1 = 0.f, s2 = 0.f;
+      float xh[NCH][8], g[NCH][8];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const bool ok = live && act[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dd = ok ? d[r][i][j] : 0.f;
+          xh[i][j] = ok ? (xv[r][i][j] - mu[r]) * rs[r] : 0.f;
+          g[i][j] = dd * gm[i][j];
+          dg[i][j] += dd * xh[i][j];
+          db[i][j] += dd;
+          s1 += g[i][j];
+          s2 += g[i][j] * xh[i][j];
+        }
+      }
+      s1 = group_sum<GL>(s1) * invC;
+      s2 = group_sum<GL>(s2) * invC;
+      if (live) {
+        const int64_t row = ro + row0 + r;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+          if (act[i]) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rs[r] * (g[i][j] - s1 - xh[i][j] * s2) + ad[r][i][j];
+            st8t<XF32>(dx, row * C + c0[i], o);
+            if (dx16) st8t<false>(dx16, row * C + c0[i], o);   // the copy the next GEMMs read (they round to bf16 anyway)
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if (act[i]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[gib * 2 * C + c0[i] + j] = dg[i][j];
+        red[gib * 2 * C + C + c0[i] + j] = db[i][j];
+      }
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float t = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < GPB; ++k) t += red[k * 2 * C + i];
+    ws[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
 // out[j] = sum_i ws[i][j]   (deterministic second stage of every cross-block reduction in the library)
 // block = 32 columns x RL row-lanes; fixed summation order -> bitwise reproducible
 template <int RL>
@@ -297,6 +494,42 @@ static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st
   else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   else hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
 }
+template <int GL, int NCH, int R>
+static void ln_fwd_vec_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const void* x, const float* g, const float* b, void* y,
+                              float* mean, float* rstd, int64_t rows, int C, float eps) {
+  if (xf && yf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, true, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+  else if (xf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, true, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+  else if (yf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, false, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+  else hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, false, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+}
+template <int GL, int NCH, int R>
+static void ln_bwd_vec_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
+                              const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C,
+                              const float* g1, bf16* dx16) {
+  if (df && xf) hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, true, true>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (df) hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, true, false>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (xf) hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, false, true>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, false, false>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+}
+// vector kernels: C % 8 == 0 and every pointer 16-byte aligned
+static bool ln_vec_ok(int C, std::initializer_list<const void*> ptrs) {
+  if (C % 8 != 0 || C < 8 || C > 1024) return false;
+  for (const void* q : ptrs)
+    if (q != nullptr && !aligned16(q)) return false;
+  return true;
+}
+static int ln_group_lanes(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
+static int64_t ln_fwd_vec_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows * ln_group_lanes(C), 256 * 2), 4096); }
+static bool ln_bwd_vec(bool df, bool xf, dim3 grid, hipStream_t st, const void* dy, const void* x, const float* g, const float* mean,
+                       const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C, const float* g1, bf16* dx16) {
+  const size_t sh = (size_t)(512 / ln_group_lanes(C)) * 2 * C * sizeof(float);
+  if (sh > 65536) return false;
+  if (C <= 128) ln_bwd_vec_launch<16, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (C <= 256) ln_bwd_vec_launch<32, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (C <= 512) ln_bwd_vec_launch<64, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else ln_bwd_vec_launch<64, 2, 1>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  return true;
+}
 static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
 static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
 static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, LN_BWD_WAVES * rows_per_wave(C)), 512); }
@@ -305,8 +538,17 @@ extern "C" int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, c
                                   float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t stream) {
   CSTS_REQUIRE(x && gamma && beta && y, "null pointer");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
-  const dim3 grid((unsigned)ln_fwd_blocks(rows, C));
   const bool xf = x_dt == CSTS_F32, yf = y_dt == CSTS_F32;
+  if (ln_vec_ok(C, {x, y, gamma, beta})) {
+    const dim3 vgrid((unsigned)ln_fwd_vec_blocks(rows, C));
+    if (C <= 128) ln_fwd_vec_launch<16, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    else if (C <= 256) ln_fwd_vec_launch<32, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    else if (C <= 512) ln_fwd_vec_launch<64, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    else ln_fwd_vec_launch<64, 2, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
+  const dim3 grid((unsigned)ln_fwd_blocks(rows, C));
   if (C <= 128) ln_fwd_launch<2, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
   else if (C <= 192) ln_fwd_launch<3, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
   else if (C <= 384) ln_fwd_launch<6, 2>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
@@ -334,6 +576,15 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
+  if (ln_vec_ok(C, {dy, x, dx, addend, dx_bf16, gamma}) &&
+      ln_bwd_vec(df, xf, grid, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16))) {
+    CSTS_LAUNCH_CHECK();
+    if (dgamma != nullptr) {
+      csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
+      CSTS_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
   else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
   else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
@@ -361,6 +612,16 @@ extern "C" int csts_layernorm_bwd2(const void* dy, int dy_dt, const void* x, int
   const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
+  if (ln_vec_ok(C, {dy, x, dx, gamma0, gamma1}) && ((rows * C) % 8 == 0) &&
+      ln_bwd_vec(df, xf, grid, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1, nullptr)) {
+    CSTS_LAUNCH_CHECK();
+    if (dgb0 != nullptr) {
+      csts_reduce_rows_launch(ws, dgb0, nb, 2 * C, 1.f, stream);
+      csts_reduce_rows_launch(ws + nb * 2 * C, dgb1, nb, 2 * C, 1.f, stream);
+      CSTS_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
   else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
   else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1);
