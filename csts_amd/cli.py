@@ -82,12 +82,18 @@ def train(cfg):
     dev = torch.device("cuda", torch.cuda.current_device())
     steps = cfg.CSTS_AMD.STEPS_PER_EPOCH
     model.train()
+    graphed = None        # single GPU: the iteration is captured into a HIP graph (the step is launch-bound from Python)
     for epoch in range(cfg.SOLVER.MAX_EPOCH):
         t0 = time.time()
         for it in range(steps):
             batch = T.synthetic_batch(b, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, 1000 + rank + 7919 * (epoch * steps + it), dev)
             lr = T.get_lr_at_epoch(cfg, epoch + float(it) / steps)
-            loss, kld, nce = T.train_step(cfg, model, batch, optimizer, lr)
+            if world == 1 and getattr(cfg.CSTS_AMD, "HIP_GRAPH", True):
+                if graphed is None:
+                    graphed = T.GraphedTrainStep(cfg, model, optimizer, batch)
+                loss, kld, nce = graphed.run(batch, lr)
+            else:
+                loss, kld, nce = T.train_step(cfg, model, batch, optimizer, lr)
             if (it + 1) % cfg.LOG_PERIOD == 0:
                 vals = T.du.all_reduce([loss, kld] + ([nce] if nce is not None else []))
                 lv = float(vals[0])

@@ -185,9 +185,67 @@ def queue_wgrad(dY, X, tokens, N, K, want_bias):
     return dW, db
 
 
+_WG_DTYPE = None
+_wg_plans = {}          # (tuple of (tokens, N, K) per problem) -> cached work-item layout
+
+
+def _wg_dtype():
+    global _WG_DTYPE
+    if _WG_DTYPE is None:
+        import numpy as np
+        _WG_DTYPE = np.dtype([("A", "u8"), ("B", "u8"), ("C", "u8"), ("colsum", "u8"), ("lda", "i8"), ("ldb", "i8"), ("ldc", "i8"),
+                              ("kbeg", "i8"), ("kend", "i8"), ("M", "i4"), ("N", "i4"), ("m0", "i4"), ("n0", "i4")], align=True)
+        assert _WG_DTYPE.itemsize == C.sizeof(L.WgradItem)
+    return _WG_DTYPE
+
+
+def _wg_plan(sig):
+    """Work-item layout of one grouped launch for the problem list `sig` = ((tokens, N, K), ...): everything except the
+    device addresses, which change from step to step.  Cached: building ~7000 items in Python costs ~15 ms.
+
+    Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2: the tiles of one
+    tile-row (same dY panel) go to ONE XCD, rows are spread over the XCDs by load (long chunks first), and XCD x's list is
+    laid out at positions x, x + 8, x + 16, ... (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles of a row
+    landed on different XCDs).  Padding slots keep A == NULL (the kernel skips them)."""
+    import numpy as np
+    plan = _wg_plans.get(sig)
+    if plan is not None:
+        return plan
+    groups = []
+    for pi, (tokens, N, K) in enumerate(sig):
+        nch = -(-tokens // WGRAD_CHUNK)
+        for c in range(nch):
+            kb, ke = c * WGRAD_CHUNK, min(tokens, (c + 1) * WGRAD_CHUNK)
+            for m0 in range(0, N, 128):
+                groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for n0 in range(0, K, 128)])
+    groups.sort(key=lambda g_: -g_[0][0] * len(g_))
+    lists, load = [[] for _ in range(8)], [0] * 8
+    for g_ in groups:
+        x = load.index(min(load))
+        lists[x].extend(g_)
+        load[x] += g_[0][0] * len(g_)
+    depth = max(len(l_) for l_ in lists)
+    n_items = depth * 8
+    if n_items > 16384:
+        raise L.CstsError("too many grouped weight-gradient work items")
+    tmpl = np.zeros(n_items, dtype=_wg_dtype())
+    pidx = np.full(n_items, -1, dtype=np.int64)
+    chunk = np.zeros(n_items, dtype=np.int64)
+    for x in range(8):
+        for slot, (_, pi, c, kb, ke, m0, n0) in enumerate(lists[x]):
+            i = slot * 8 + x
+            tokens, N, K = sig[pi]
+            tmpl[i] = (0, 0, 0, 0, N, K, K, kb, ke, N, K, m0, n0)
+            pidx[i], chunk[i] = pi, c
+    valid = pidx >= 0
+    plan = _wg_plans[sig] = (tmpl, valid, pidx[valid], chunk[valid], n_items)
+    return plan
+
+
 def flush_wgrads():
     if not _wgq:
         return
+    import numpy as np
     q = list(_wgq)
     _wgq.clear()
     dev = q[0][0].device
@@ -196,62 +254,35 @@ def flush_wgrads():
         tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=3, captures=4)
     keep = []
     for a_f32 in (False, True):
-        for rows in (128, 64):
-            items = []
-            for (dY, X, dW, db, tokens, N, K) in q:
-                if (dY.dtype == torch.float32) != a_f32:
-                    continue
-                # 64-row tiles where 128 would pad the output by more than a fifth (N = 96, 288, ...)
-                tile = 128           # measured: the 128-row kernel does 650 TF/s, the 64-row one 300 -- padding is cheaper
-                if tile != rows:
-                    continue
-                nch = -(-tokens // WGRAD_CHUNK)
-                if nch > 1:
-                    slab = torch.empty(nch, N, K, dtype=torch.float32, device=dev)
-                    _defer(slab, dW, nch, N * K)
-                    cs = None
-                    if db:
-                        cs = torch.empty(nch, N, dtype=torch.float32, device=dev)
-                        _defer(cs, db, nch, N)
-                    keep.append((slab, cs))
-                for c in range(nch):
-                    kb, ke = c * WGRAD_CHUNK, min(tokens, (c + 1) * WGRAD_CHUNK)
-                    Cp = dW if nch == 1 else slab.data_ptr() + c * N * K * 4
-                    csp = 0 if not db else (db if nch == 1 else cs.data_ptr() + c * N * 4)
-                    for m0 in range(0, N, rows):
-                        for n0 in range(0, K, 128):
-                            items.append((ke - kb, dY.data_ptr(), X.data_ptr(), Cp, csp, N, K, K, kb, ke, N, K, m0, n0))
-            if not items:
-                continue
-            # Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2: the tiles of
-            # one tile-row (same dY panel, items are appended row by row) go to ONE XCD, rows are spread over the XCDs by
-            # load (long chunks first), and XCD x's list is laid out at positions x, x + 8, x + 16, ...
-            # (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles of a row landed on different XCDs)
-            groups, cur = [], []
-            for t in items:
-                if cur and (t[1], t[3], t[8], t[12]) != (cur[0][1], cur[0][3], cur[0][8], cur[0][12]):
-                    groups.append(cur)
-                    cur = []
-                cur.append(t)
-            groups.append(cur)
-            groups.sort(key=lambda g_: -g_[0][0] * len(g_))
-            lists, load = [[] for _ in range(8)], [0] * 8
-            for g_ in groups:
-                x = load.index(min(load))
-                lists[x].extend(g_)
-                load[x] += g_[0][0] * len(g_)
-            depth = max(len(l_) for l_ in lists)
-            n_items = depth * 8
-            if n_items > 16384:
-                raise L.CstsError("too many grouped weight-gradient work items")
-            arr = (L.WgradItem * n_items)()            # zero-initialised: padding slots have A == NULL (the kernel skips them)
-            for x in range(8):
-                for slot, t in enumerate(lists[x]):
-                    i = slot * 8 + x
-                    (_, arr[i].A, arr[i].B, arr[i].C, arr[i].colsum, arr[i].lda, arr[i].ldb, arr[i].ldc, arr[i].kbeg,
-                     arr[i].kend, arr[i].M, arr[i].N, arr[i].m0, arr[i].n0) = t
-            ptr = tab.upload(bytes(arr))
-            L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
+        probs = [t for t in q if (t[0].dtype == torch.float32) == a_f32]
+        if not probs:
+            continue
+        tmpl, valid, pidx, chunk, n_items = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs))
+        A = np.empty(len(probs), dtype=np.uint64); B = np.empty_like(A); Cb = np.empty_like(A); Cs = np.zeros_like(A)
+        cstride = np.zeros(len(probs), dtype=np.uint64); sstride = np.zeros_like(cstride)
+        for i, (dY, X, dW, db, tokens, N, K) in enumerate(probs):
+            A[i], B[i] = dY.data_ptr(), X.data_ptr()
+            nch = -(-tokens // WGRAD_CHUNK)
+            if nch == 1:
+                Cb[i], Cs[i] = dW, db
+            else:          # several token chunks: one partial slab per chunk, summed by the batched reducer
+                slab = torch.empty(nch, N, K, dtype=torch.float32, device=dev)
+                _defer(slab, dW, nch, N * K)
+                Cb[i], cstride[i] = slab.data_ptr(), N * K * 4
+                cs = None
+                if db:
+                    cs = torch.empty(nch, N, dtype=torch.float32, device=dev)
+                    _defer(cs, db, nch, N)
+                    Cs[i], sstride[i] = cs.data_ptr(), N * 4
+                keep.append((slab, cs))
+        arr = tmpl.copy()
+        ch = chunk.astype(np.uint64)
+        arr["A"][valid] = A[pidx]
+        arr["B"][valid] = B[pidx]
+        arr["C"][valid] = Cb[pidx] + ch * cstride[pidx]
+        arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
+        ptr = tab.upload(arr.tobytes())
+        L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, 128, _stream()), "csts_wgrad_grouped")
     del q, keep
 
 

@@ -101,8 +101,11 @@ def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: O
     Returns (loss, kld, nce) as device tensors (no host sync)."""
     if optimizer is not None and lr is not None:
         set_lr(optimizer, lr)
-    for p in model.parameters():
-        p.grad = None
+    if optimizer is not None and hasattr(optimizer, "params"):
+        optimizer.zero_grad(set_to_none=True)        # cached parameter list (nn.Module.parameters() walks the tree: ~5 ms)
+    else:
+        for p in model.parameters():
+            p.grad = None
     loss, kld, nce, _ = compute_loss(cfg, model, batch["video"], batch["audio"], batch["labels_hm"], keep_masks)
     loss.backward()
     if isinstance(model, GradAllReduce):

@@ -1,0 +1,23 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from csts_amd import ops, lib as L
+dev = torch.device("cuda:0")
+x = torch.randn(4, 2048, 384, device=dev, requires_grad=True)
+g = torch.ones(384, device=dev, requires_grad=True); b = torch.zeros(384, device=dev, requires_grad=True)
+for pt in (False, True):
+    for _ in range(20): ops.layer_norm(x, g, b, 1e-6, L.BF16, passthrough=pt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(500): out = ops.layer_norm(x, g, b, 1e-6, L.BF16, passthrough=pt)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print("passthrough", pt, "host us/call %.1f" % ((t1 - t0) / 500 * 1e6))
+# chain: output alias feeds the next call (as in the model)
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    h = x
+    for _ in range(200):
+        y, h = ops.layer_norm(h, g, b, 1e-6, L.BF16, passthrough=True)
+    t1 = time.perf_counter(); torch.cuda.synchronize()
+    print("chained alias: host us/call %.1f" % ((t1 - t0) / 200 * 1e6))
