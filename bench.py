@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--rehearse-dist", action="store_true",
+                   help="run the N>1 code path (RCCL process group, GradAllReduce buckets, eager step) with ONE rank")
     p.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph (single GPU only)")
     p.add_argument("--op-breakdown", default=None, help="write per-C-ABI-entry device time of one eager step to this file")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
@@ -192,9 +194,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_path = world > 1 or args.rehearse_dist
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29655")
+        if world == 1:
+            torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            from csts_amd import distributed as _du
+            _du._FORCE = True        # 1-rank rehearsal: take the collective code paths anyway
+        else:
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     from csts_amd.config import load_yaml
@@ -208,8 +217,10 @@ def main():
                      "MODEL.LOSS_ALPHA", 0.05, "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute])
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg)
+    if dist_path and not isinstance(model, GradAllReduce):
+        model = GradAllReduce(model, bucket_mb=cfg.CSTS_AMD.GRAD_BUCKET_MB)
     model.train()
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not dist_path and not args.no_graph
     opt = T.construct_optimizer(model, cfg, capturable=use_graph)
     batch = T.synthetic_batch(b, args.frames, 256, 1000 + rank, dev)      # resident in HBM before timing
     lr = T.get_lr_at_epoch(cfg, 0.0)
@@ -225,7 +236,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_path:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -237,7 +248,7 @@ def main():
         loss, kld, nce = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_path:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -246,7 +257,8 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     roof = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (they contain the gradient collectives); rank 0 reports its own timings
         gt = GemmTimer()
         gt.install()
         core = model.module if hasattr(model, "module") else model
@@ -275,14 +287,14 @@ def main():
             ot.remove()
             ops_ms = ot.summary(1)
             tot = t_ev0.elapsed_time(t_ev1)
-            with open(args.op_breakdown, "w") as f:
+            with open(args.op_breakdown if rank == 0 else os.devnull, "w") as f:
                 f.write(f"single-stream eager step {tot:.2f} ms; C-ABI kernels {sum(v['ms'] for v in ops_ms.values()):.2f} ms; "
                         f"torch-native remainder (optimizer, clip, autograd adds, casts, fills) {tot - sum(v['ms'] for v in ops_ms.values()):.2f} ms\n")
                 for k, v in ops_ms.items():
                     f.write(f"{k:28s} {v['calls']:5d} calls {v['ms']:8.3f} ms\n")
         core.two_streams = two
         agg = gt.summary()
-        if args.dump_gemm:
+        if args.dump_gemm and rank == 0:
             gt.dump_shapes(args.dump_gemm)
         # dominant kernel = the single-kernel GEMM variant (no split-K finishing pass inside the event pair) with the most time
         single = {k: v for k, v in agg.items() if not v[4]}
@@ -313,7 +325,7 @@ def main():
                 "per_kernel": {k: {"launches_per_step": v[0] // 2, "avg_us": round(v[3] / v[0] * 1e6, 1),
                                    "tflops": round(v[1] / v[3] / 1e12, 1), "ms_per_step": round(v[3] / 2 * 1e3, 3)}
                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3])[:8]}}
-    if world > 1:
+    if dist_path:
         torch.distributed.barrier()
 
     if rank == 0:
@@ -325,7 +337,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
             "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml train step (fwd + KLDiv + 0.05*EgoNCE + bwd"
-                                   f"{' + RCCL grad all-reduce' if world > 1 else ''} + clip + AdamW), "
+                                   f"{' + RCCL grad all-reduce' if dist_path else ''} + clip + AdamW), "
                                    f"{args.frames}x256^2 video + 24 kHz STFT audio, b={b}/GPU",
                        "global_batch": b * world, "frames": args.frames, "crop": 256, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                        "note": "256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)"},
@@ -342,7 +354,7 @@ def main():
             except Exception as e:  # keep the line valid even if the host runs out of memory
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_path:
         torch.distributed.destroy_process_group()
 
 

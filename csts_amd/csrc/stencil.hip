@@ -723,6 +723,11 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void
 }
 
 int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 8); }
+// kernels that stage the 27 x HD weight table per workgroup: fewer, fatter workgroups amortise the staging
+int grid_for_staged(int64_t total) {
+  static const int cap = getenv("CSTS_STENCIL_GRID_CAP") ? atoi(getenv("CSTS_STENCIL_GRID_CAP")) : 256 * 8;
+  return (int)std::min<int64_t>(cdiv(total, 256), cap);
+}
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -763,7 +768,7 @@ extern "C" int csts_dwconv_strided(const csts_dwconv_geom* a, const void* fine, 
   CSTS_REQUIRE(((uintptr_t)fine & 15) == 0 && ((uintptr_t)coarse & 15) == 0, "tensors must be 16-byte aligned");
   RowGeom rg; fill_geom(a, rg);
   const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc * (a->C / VEC);
-  const dim3 grid(grid_for(total)), block(256);
+  const dim3 grid(grid_for_staged(total)), block(256);
   const size_t sm = (size_t)a->HD * 28 * 4;
   const bool ff = fine_dt == CSTS_F32, cf = coarse_dt == CSTS_F32;
   if (ff && cf) hipLaunchKernelGGL((dwconv_strided_kernel<true, true>), grid, block, sm, stream, rg, fine, weight, coarse);
@@ -786,7 +791,7 @@ static int transposed_launch(const csts_dwconv_geom* a, int nslots, const void* 
   }
   RowGeom rg; fill_geom(a, rg);
   const int64_t total = (int64_t)a->B * a->Tf * a->Hf * a->Wf * (a->C / VEC);
-  const dim3 grid(grid_for(total), nslots), block(256);
+  const dim3 grid(grid_for_staged(total), nslots), block(256);
   const size_t sm = (size_t)a->HD * 28 * 4;
   CSTS_REQUIRE(coarse_dt == fine_dt, "transposed stencil: both tensors must have the same dtype");
   const bool f32 = fine_dt == CSTS_F32;
@@ -902,7 +907,7 @@ extern "C" int csts_pool_ln_fwd(const csts_pool_ln_args* a, hipStream_t stream) 
   const int gl = gm->HD <= 128 ? 16 : 32;
   const int64_t items = (int64_t)gm->B * gm->Tc * gm->Hc * gm->Wc * (gm->C / gm->HD) * a->nslots;
   const int gpb = 256 / gl;
-  const dim3 grid((unsigned)std::min<int64_t>(cdiv(items, gpb), 2048)), block(256);
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv(items, gpb), grid_for_staged((int64_t)1 << 40))), block(256);
   const size_t sm = (size_t)a->nslots * gm->HD * 28 * 4;
   const bool f32 = a->dt == CSTS_F32;
   if (gl == 16) {

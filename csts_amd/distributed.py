@@ -96,7 +96,10 @@ class GradAllReduce(nn.Module):
         self._ready_order: List[torch.nn.Parameter] = []
         self._observed = False
         self._pending = []
-        self._stream_events = {}
+        self._bucket_streams = {}
+        self._avg_op = None
+        if is_dist() and dist.get_backend() == "nccl":
+            self._avg_op = dist.ReduceOp.AVG
         for p in self._params:
             p.register_post_accumulate_grad_hook(self._hook)
         if is_dist():   # replicas start identical
@@ -126,14 +129,10 @@ class GradAllReduce(nn.Module):
         bi = self._bucket_of[p]
         self._count[bi] += 1
         if p.grad.is_cuda and (self.world > 1 or _FORCE):
-            # backward replays on more than one HIP stream (the audio trunk has its own): remember, per bucket and per
-            # stream, how far that stream had got when it produced one of the bucket's gradients
+            # backward replays on more than one HIP stream (the audio trunk has its own): remember which streams
+            # produced gradients of this bucket, so that its launch can wait for them
             cur = torch.cuda.current_stream()
-            evs = self._stream_events.setdefault(bi, {})
-            ev = evs.get(cur.cuda_stream)
-            if ev is None:
-                ev = evs[cur.cuda_stream] = torch.cuda.Event()
-            ev.record(cur)
+            self._bucket_streams.setdefault(bi, {})[cur.cuda_stream] = cur
         if self._count[bi] == len(self._buckets[bi]):
             self._launch(bi)
 
@@ -143,25 +142,34 @@ class GradAllReduce(nn.Module):
         ps = self._buckets[bi]
         if ps[0].grad.is_cuda:
             cur = torch.cuda.current_stream()
-            for sid, ev in self._stream_events.get(bi, {}).items():
+            for sid, st in self._bucket_streams.get(bi, {}).items():
                 if sid != cur.cuda_stream:
-                    cur.wait_event(ev)      # gradients of this bucket that were produced on another stream
-        flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
-        flat /= self.world
-        work = dist.all_reduce(flat, async_op=True)
-        self._pending.append((work, flat, ps))
+                    cur.wait_stream(st)      # gradients of this bucket that were produced on another stream
+        # one flat fp32 buffer per bucket, every tensor's slot 16-byte aligned (the optimizer kernels read the averaged
+        # gradients straight out of it through p.grad views); filled by ONE multi-tensor copy
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.empty(total, dtype=torch.float32, device=ps[0].grad.device)
+        views = [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, ps)]
+        torch._foreach_copy_(views, [p.grad for p in ps])
+        if self._avg_op is not None:
+            work = dist.all_reduce(flat, op=self._avg_op, async_op=True)      # RCCL averages in the collective itself
+        else:
+            flat /= self.world
+            work = dist.all_reduce(flat, async_op=True)
+        self._pending.append((work, flat, ps, views))
 
     def finish(self):
-        """Wait for the outstanding buckets and write the averaged gradients back (call after backward)."""
-        for work, flat, ps in self._pending:
+        """Wait for the outstanding buckets and hand the averaged gradients back (call after backward): every p.grad
+        becomes a VIEW of its bucket's flat buffer -- no copy back."""
+        for work, flat, ps, views in self._pending:
             work.wait()
             if flat.is_cuda:
-                flat.record_stream(torch.cuda.current_stream())    # allocated on the hook's stream, read here
-            off = 0
-            for p in ps:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+                flat.record_stream(torch.cuda.current_stream())    # allocated on the hook's stream, read from here on
+            for p, v in zip(ps, views):
+                p.grad = v
         self._pending = []
         self._count = [0] * len(self._buckets)
         if not self._observed and self._ready_order:
