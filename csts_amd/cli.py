@@ -118,7 +118,12 @@ def test(cfg):
     dev = torch.device("cuda", torch.cuda.current_device())
     batch = T.synthetic_batch(b, cfg.DATA.NUM_FRAMES, cfg.DATA.TEST_CROP_SIZE, 2000, dev)
     preds = losses.frame_softmax(model([batch["video"]], batch["audio"]), temperature=2)
-    _log({"_type": "test", "preds_shape": list(preds.shape), "preds_sum": float(preds.sum())})
+    # tools/test_avgaze_net.py:66-69: min-max rescale per frame, then the adaptive-threshold F1 -- both on the device
+    from . import metrics
+    f1, recall, precision, threshold = metrics.adaptive_f1(preds, batch["labels_hm"], batch["labels"],
+                                                           dataset=cfg.TEST.DATASET, rescale=True)
+    _log({"_type": "test", "preds_shape": list(preds.shape), "preds_sum": float(preds.sum()), "f1": f1, "recall": recall,
+          "precision": precision, "threshold": float(threshold)})
 
 
 def main(argv=None):

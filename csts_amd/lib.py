@@ -149,6 +149,8 @@ SYMBOLS = {
     "csts_egonce_fwd": (_I, [vp, vp, vp, vp, _I, _F, vp]),
     "csts_egonce_bwd": (_I, [vp, vp, vp, vp, vp, _I, _F, vp]),
     "csts_adamw_step": (_I, [C.POINTER(OptArgs), vp]),
+    "csts_adaptive_f1_workspace": (sz, [i64, _I]),
+    "csts_adaptive_f1": (_I, [vp, vp, vp, vp, _I, i64, _I, _I, vp, vp, sz, vp]),
 }
 
 _lib = None

@@ -245,6 +245,14 @@ typedef struct {
 } csts_opt_args;
 int csts_adamw_step(const csts_opt_args* args, hipStream_t stream);
 
+/* ---- evaluation metric ("next" row): metrics.adaptive_f1 (slowfast/utils/metrics.py:9-74) with the
+ *      per-frame min-max rescale of its callers (tools/test_avgaze_net.py:66-68, tools/train_avgaze_net.py:125-127) folded
+ *      in (rescale != 0).  preds, labels_hm: fp32 [nframes][hw]; tracked[f] != 0 marks the fixation frames that count
+ *      (metrics.py:64-65); thresholds fp32 [nthr] (nthr <= 64).  out = {f1, recall, precision, index of the best threshold}. */
+size_t csts_adaptive_f1_workspace(int64_t nframes, int nthr);
+int csts_adaptive_f1(const float* preds, const float* labels_hm, const uint8_t* tracked, const float* thresholds, int nthr,
+                     int64_t nframes, int hw, int rescale, float* out, void* workspace, size_t ws_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -555,3 +555,40 @@ def synthetic_batch(B: int, num_frames: int = 8, crop: int = 256, seed: int = 10
     labels = torch.stack([cx / 63, cy / 63, torch.zeros_like(cx)], dim=-1).double()
     out = {"video": video, "audio": audio, "labels_hm": hm, "labels": labels}
     return {k: v.to(device) for k, v in out.items()}
+
+
+# --------------------------------------------------------------------------------------- evaluation metric
+def minmax_rescale(preds):
+    """Per-frame min-max rescale applied before the metric (tools/test_avgaze_net.py:66-68, train_avgaze_net.py:125-127)."""
+    flat = preds.reshape(preds.shape[:-2] + (preds.shape[-1] * preds.shape[-2],))
+    mn, mx = flat.min(dim=-1, keepdim=True)[0], flat.max(dim=-1, keepdim=True)[0]
+    return ((flat - mn) / (mx - mn + 1e-6)).reshape(preds.shape)
+
+
+def adaptive_f1(preds, labels_hm, labels, dataset):
+    """Best F1 over the dataset's threshold sweep on fixation frames (slowfast/utils/metrics.py:9-74), without the
+    (n_thr, B, T, H, W) temporaries: per-frame counts per threshold, then the same means / f1 / argmax."""
+    import numpy as np
+    if "forecast" in dataset and "aria" not in dataset:
+        thresholds = np.linspace(0.01, 0.07, 31)                      # metrics.py:35-37
+    elif "forecast" in dataset and "aria" in dataset:
+        thresholds = np.linspace(0.0, 0.02, 21)                       # :38-40
+    else:
+        thresholds = np.linspace(0, 0.02, 11)                         # :41-43
+    p = preds.squeeze(1)
+    lab = (labels_hm > 0.001)                                          # :47
+    tp, fgp = [], []
+    for t in thresholds:
+        pr = p > float(t)                                              # :49
+        tp.append((pr & lab).sum(dim=(2, 3)).float())
+        fgp.append(pr.sum(dim=(2, 3)).float())
+    tp, fgp = torch.stack(tp), torch.stack(fgp)                        # (n_thr, B, T)
+    fgl = lab.sum(dim=(2, 3)).float().unsqueeze(0).expand_as(tp)
+    fixation_idx = 1 if dataset == "egteagaze" else 0                  # :56-62
+    tracked = torch.where(labels.reshape(-1, labels.shape[2])[:, 2] == fixation_idx)[0]     # :63-64
+    tp, fgp, fgl = [x.reshape(x.shape[0], -1).index_select(1, tracked) for x in (tp, fgp, fgl)]
+    recall = (tp / (fgl + 1e-6)).mean(dim=1)                           # :68
+    precision = (tp / (fgp + 1e-6)).mean(dim=1)                        # :69
+    f1 = (2 * recall * precision) / (recall + precision + 1e-6)        # :70
+    i = int(torch.argmax(f1))
+    return float(f1[i]), float(recall[i]), float(precision[i]), thresholds[i]

@@ -356,6 +356,28 @@ def gen_model_t32():
          logits_head=t2n(lg).reshape(-1)[:4096].astype(np.float32))
 
 
+def gen_metrics():
+    """adaptive_f1 of the reference (slowfast/utils/metrics.py) on seeded heat maps, all three threshold tables."""
+    from slowfast.utils import metrics as ref_metrics
+    g = torch.Generator().manual_seed(4321)
+    B, T = 3, 8
+    logits = torch.randn(B, 1, T, 64, 64, generator=g) * 2.0
+    batch = O.synthetic_batch(B, T, 256, seed=55)
+    hm = batch["labels_hm"]
+    # pull the prediction towards the label so that the sweep has a non-trivial optimum
+    logits = logits + 40.0 * hm.unsqueeze(1) / hm.amax(dim=(-1, -2), keepdim=True).unsqueeze(1)
+    preds = ref_utils.frame_softmax(logits, 2)
+    flat = preds.view(preds.size()[:-2] + (preds.size(-1) * preds.size(-2),))
+    resc = ((flat - flat.min(dim=-1, keepdim=True)[0]) / (flat.max(dim=-1, keepdim=True)[0] - flat.min(dim=-1, keepdim=True)[0] + 1e-6)).view(preds.size())
+    labels = batch["labels"].clone()
+    labels[0, 2, 2] = 1.0          # untracked frames (type != fixation) are skipped
+    labels[2, 5, 2] = 2.0
+    out = {}
+    for ds in ("ego4d_av_gaze_forecast", "aria_av_gaze_forecast", "ego4d_av_gaze"):
+        out[ds] = np.array(ref_metrics.adaptive_f1(resc, hm, labels, dataset=ds), dtype=np.float64)
+    save("metrics_f1.npz", logits=t2n(logits).astype(np.float32), labels=t2n(labels), **out)
+
+
 def gen_lr():
     from slowfast.utils import lr_policy
     cfg = make_cfg(8)
@@ -371,6 +393,8 @@ if __name__ == "__main__":
         gen_blocks()
     if "lr" in what:
         gen_lr()
+    if "metrics" in what or "blocks" in what:
+        gen_metrics()
     if "model" in what:
         gen_model()
     if "model" in what or "t32" in what:

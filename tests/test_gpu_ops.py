@@ -417,3 +417,26 @@ def test_fused_adamw_matches_torch_clip_plus_adamw():
     assert torch.equal(pa[7].detach(), pb[7].detach())
     m_ref = ref.state[pb[3]]["exp_avg"]
     assert rel_l2(fused._m[[id(p) for p in fused.params].index(id(pa[3]))].view_as(m_ref), m_ref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ evaluation metric
+def test_adaptive_f1_on_device():
+    """csts_adaptive_f1 (min-max rescale folded in) == the reference's adaptive_f1 (fixture generated by importing
+    slowfast/utils/metrics.py) == the oracle, on all three threshold tables; counts are integers -> exact up to the
+    fp32 means."""
+    import numpy as np
+    from csts_amd import metrics as M
+    from conftest import GOLDEN
+    import os
+    g = np.load(os.path.join(GOLDEN, "metrics_f1.npz"))
+    logits, labels = torch.from_numpy(g["logits"]).to(DEV), torch.from_numpy(g["labels"]).to(DEV)
+    hm = O.synthetic_batch(3, 8, 256, seed=55)["labels_hm"].to(DEV)
+    preds = ops.frame_softmax(logits, 2.0)
+    for ds in ("ego4d_av_gaze_forecast", "aria_av_gaze_forecast", "ego4d_av_gaze"):
+        f1, rec, prec, thr = M.adaptive_f1(preds, hm, labels, ds, rescale=True)
+        ref = g[ds]
+        assert abs(f1 - ref[0]) < 2e-6 and abs(rec - ref[1]) < 2e-6 and abs(prec - ref[2]) < 2e-6 and abs(thr - ref[3]) < 1e-12, (ds, f1, ref)
+        f1b, *_ = M.adaptive_f1(O.minmax_rescale(preds.cpu()).to(DEV), hm, labels, ds, rescale=False)
+        assert abs(f1b - ref[0]) < 2e-6
+    with pytest.raises(NotImplementedError):
+        M.adaptive_f1(preds, hm, labels, "kinetics")

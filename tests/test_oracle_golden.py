@@ -223,3 +223,15 @@ def test_T32_aria_forward():
     assert rel_l2(v, g["v_emb"]) < TOL and rel_l2(a, g["a_emb"]) < TOL
     heat = O.frame_softmax(lg, 2.0)
     assert (heat.reshape(32, -1).argmax(-1).numpy() == g["argmax"]).all()
+
+
+def test_adaptive_f1_metric():
+    """slowfast/utils/metrics.py:9-74 on reference-generated fixtures (three threshold tables, untracked frames)."""
+    g = _load("metrics_f1.npz")
+    logits, labels = torch.from_numpy(g["logits"]), torch.from_numpy(g["labels"])
+    hm = O.synthetic_batch(3, 8, 256, seed=55)["labels_hm"]
+    preds = O.minmax_rescale(O.frame_softmax(logits, 2.0))
+    for ds in ("ego4d_av_gaze_forecast", "aria_av_gaze_forecast", "ego4d_av_gaze"):
+        f1, rec, prec, thr = O.adaptive_f1(preds, hm, labels, ds)
+        ref = g[ds]
+        assert abs(f1 - ref[0]) < 1e-6 and abs(rec - ref[1]) < 1e-6 and abs(prec - ref[2]) < 1e-6 and abs(thr - ref[3]) < 1e-12, (ds, f1, ref)
