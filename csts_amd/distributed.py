@@ -96,7 +96,6 @@ class GradAllReduce(nn.Module):
         self._ready_order: List[torch.nn.Parameter] = []
         self._observed = False
         self._pending = []
-        self._bucket_streams = {}
         self._avg_op = None
         if is_dist() and dist.get_backend() == "nccl":
             self._avg_op = dist.ReduceOp.AVG
@@ -121,19 +120,25 @@ class GradAllReduce(nn.Module):
         for bi, b in enumerate(self._buckets):
             for p in b:
                 self._bucket_of[p] = bi
+                p._csts_bucket = bi          # read by the per-gradient hook (524 calls per step: keep it to a few lookups)
         self._count = [0] * len(self._buckets)
+        self._bucket_len = [len(b) for b in self._buckets]
+        self._bucket_streams = {}
+        self._iters_since_assign = 0
 
     def _hook(self, p):
         if not self._observed:
             self._ready_order.append(p)
-        bi = self._bucket_of[p]
-        self._count[bi] += 1
-        if p.grad.is_cuda and (self.world > 1 or _FORCE):
-            # backward replays on more than one HIP stream (the audio trunk has its own): remember which streams
-            # produced gradients of this bucket, so that its launch can wait for them
+        bi = p._csts_bucket
+        c = self._count[bi] + 1
+        self._count[bi] = c
+        if self._iters_since_assign < 2 and p.grad.is_cuda and (self.world > 1 or _FORCE):
+            # backward replays on more than one HIP stream (the audio trunk has its own): learn, during the first two
+            # iterations after a bucket assignment, which streams produce gradients of this bucket (the graph is static),
+            # so that its launch can wait for them
             cur = torch.cuda.current_stream()
             self._bucket_streams.setdefault(bi, {})[cur.cuda_stream] = cur
-        if self._count[bi] == len(self._buckets[bi]):
+        if c == self._bucket_len[bi]:
             self._launch(bi)
 
     def _launch(self, bi):
@@ -172,6 +177,7 @@ class GradAllReduce(nn.Module):
                 p.grad = v
         self._pending = []
         self._count = [0] * len(self._buckets)
+        self._iters_since_assign += 1
         if not self._observed and self._ready_order:
             self._observed = True
             if len(self._ready_order) == len(self._params):
