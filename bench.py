@@ -259,6 +259,10 @@ def main():
     roof = None
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the gradient collectives); rank 0 reports its own timings
+        from csts_amd import ops as _ops
+        _mode = _ops.GROUP_WGRADS
+        if use_graph and _mode == "capture":
+            _ops.GROUP_WGRADS = "always"      # instrument the same kernel set the captured (timed) step runs
         gt = GemmTimer()
         gt.install()
         core = model.module if hasattr(model, "module") else model
@@ -293,6 +297,7 @@ def main():
                 for k, v in ops_ms.items():
                     f.write(f"{k:28s} {v['calls']:5d} calls {v['ms']:8.3f} ms\n")
         core.two_streams = two
+        _ops.GROUP_WGRADS = _mode
         agg = gt.summary()
         if args.dump_gemm and rank == 0:
             gt.dump_shapes(args.dump_gemm)

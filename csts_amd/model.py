@@ -11,6 +11,7 @@ through csts_amd.ops -> libcsts_hip.so.  Compute mode comes from ``cfg.CSTS_AMD.
 from __future__ import annotations
 
 import math
+import weakref
 from functools import partial
 from typing import Dict, List, Optional
 
@@ -21,6 +22,9 @@ from torch.nn.init import trunc_normal_
 from . import ops
 from . import lib as L
 from .registry import MODEL_REGISTRY
+
+
+_SIDE_STREAMS = weakref.WeakKeyDictionary()     # model -> HIP stream of its audio trunk
 
 
 def round_width(width, multiplier, min_width=1, divisor=1):
@@ -333,9 +337,11 @@ class CSTS(nn.Module):
         return {n: ("scales", scales[2 * i], scales[2 * i + 1]) for i, (n, _) in enumerate(named)}
 
     def _audio_stream(self):
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
-        return self._side_stream
+        # kept outside the module's attributes: a HIP stream can be neither pickled nor deep-copied
+        st = _SIDE_STREAMS.get(self)
+        if st is None:
+            st = _SIDE_STREAMS[self] = torch.cuda.Stream()
+        return st
 
     @torch.jit.ignore
     def no_weight_decay(self):

@@ -36,7 +36,17 @@ def torch_dtype(dt: int):
     return torch.float32 if dt == F32 else torch.bfloat16
 
 
+try:
+    _raw_stream, _cur_dev = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:          # CPU-only build of torch: ops raise before they get here
+    _raw_stream = _cur_dev = None
+
+
 def _stream():
+    """Raw hipStream_t of torch's current stream (torch.cuda.current_stream().cuda_stream costs ~4 us per call, and
+    there are ~1200 launches per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -162,7 +172,12 @@ def flush_deferred():
 # are queued and computed by csts_wgrad_grouped at the end, all layers in one launch per dY dtype.  A weight gradient on
 # its own needs a deep split-K to fill the chip; together they provide thousands of (tile, token-chunk) work items, so
 # chunks are long (WGRAD_CHUNK tokens) and most layers need no split-K partials at all.
-GROUP_WGRADS = os.environ.get("CSTS_GROUP_WGRADS", "1") != "0"
+# "capture" (default): only while the step is being captured into a HIP graph -- replayed, the grouped tail costs nothing
+# on the host and the graph's private pool makes the longer tensor lifetimes free.  In eager mode the end-of-backward
+# release of every queued operand at once fragments torch's caching allocator (hipMalloc stalls of ~20 ms in the next
+# forward were measured), so eager steps keep the in-line split-K weight gradients unless CSTS_GROUP_WGRADS=1 forces
+# grouping; CSTS_GROUP_WGRADS=0 switches it off everywhere.
+GROUP_WGRADS = {"0": "never", "1": "always"}.get(os.environ.get("CSTS_GROUP_WGRADS", ""), "capture")
 WGRAD_CHUNK = 8192
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 _wg_tables = {}
@@ -171,7 +186,9 @@ _wg_tables = {}
 def queue_wgrad(dY, X, tokens, N, K, want_bias):
     """Queue dW[N,K] = dY[tokens,N]^T X[tokens,K] (+ db[N]) for the grouped launch; returns (dW, db) to hand to autograd
     now (complete when backward returns), or None when the problem has to run in line."""
-    if not (GROUP_WGRADS and DEFER_REDUCTIONS and X.dtype == torch.bfloat16 and dY.dtype in (torch.float32, torch.bfloat16)
+    if GROUP_WGRADS == "never" or (GROUP_WGRADS == "capture" and not torch.cuda.is_current_stream_capturing()):
+        return None
+    if not (DEFER_REDUCTIONS and X.dtype == torch.bfloat16 and dY.dtype in (torch.float32, torch.bfloat16)
             and N % 8 == 0 and K % 8 == 0 and dY.is_contiguous() and X.is_contiguous() and tokens >= 256):
         return None
     if not _can_defer():

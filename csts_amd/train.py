@@ -167,17 +167,26 @@ class GraphedTrainStep:
         assert not isinstance(model, GradAllReduce), "graph capture is single-GPU; multi-GPU runs eagerly"
         self.cfg, self.model, self.opt = cfg, model, optimizer
         self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._step()
-        torch.cuda.synchronize()
+        from . import ops
+        mode = ops.GROUP_WGRADS
+        if mode == "capture":
+            # the warm-up steps must take the same (grouped) path as the capture: its lazily built host tables and
+            # pinned buffers may not be allocated while a capture is open
+            ops.GROUP_WGRADS = "always"
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._step()
+            torch.cuda.synchronize()
+        finally:
+            ops.GROUP_WGRADS = mode
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)

@@ -271,12 +271,14 @@ def test_backward_is_bitwise_reproducible():
     m, cfg = make_model("bf16")
     batch = T.synthetic_batch(2, 8, 256, 77, DEV)
     runs = []
+    old_mode, ops.GROUP_WGRADS = ops.GROUP_WGRADS, "always"      # the grouped end-of-backward tail included
     for _ in range(2):
         for p in m.parameters():
             p.grad = None
         T.train_step(cfg, m, batch)
         torch.cuda.synchronize()
         runs.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    ops.GROUP_WGRADS = old_mode
     bad = [n for n in runs[0] if not torch.equal(runs[0][n], runs[1][n])]
     assert not bad, bad[:10]
 

@@ -358,7 +358,7 @@ def test_grouped_weight_gradients_match_inline():
 
     def run(grouped):
         old = ops.GROUP_WGRADS
-        ops.GROUP_WGRADS = grouped
+        ops.GROUP_WGRADS = "always" if grouped else "never"
         try:
             ps = [t.clone().requires_grad_() for t in (W1, b1, W2, b2)]
             y = ops.mlp(x, ps[0], ps[1], ps[2], ps[3], residual=res, act_dt=L.BF16, out_dt=L.F32, compute=L.BF16)
