@@ -244,6 +244,52 @@ __device__ __forceinline__ void tile_loop(typename El<F32>::T* smem, const void*
   }
 }
 
+// Row-per-lane operands (the 128 query rows of a workgroup, one per lane) are moved through LDS: the tile is loaded /
+// stored by the whole workgroup in 16-byte chunks that run along each 2*HD-byte row (consecutive lanes -> consecutive
+// chunks), and only the LDS side is accessed row-per-lane.  A direct row-per-lane global access makes every wave
+// instruction a 64-row gather / scatter (64 different 128-byte lines per instruction).
+template <int HD>
+__device__ __forceinline__ void stage_rows_in(bf16* S, const void* src, int64_t base, int64_t ts, int row0, int nrows_valid,
+                                              int tid) {
+  constexpr int CPR = HD / 8, LDS_LD = HD + 8;
+#pragma unroll 2
+  for (int c = tid; c < 128 * CPR; c += 256) {
+    const int row = c / CPR, col = (c - row * CPR) * 8;
+    const int r = min(row0 + row, nrows_valid - 1);
+    *reinterpret_cast<uint4*>(S + row * LDS_LD + col) =
+        *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(src) + base + (int64_t)r * ts + col);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void frag_from_lds(RowFrag<HD, false>& f, const bf16* S, int row, int h) {
+  constexpr int LDS_LD = HD + 8;
+#pragma unroll
+  for (int s = 0; s < HD / 16; ++s) f.b[s] = *reinterpret_cast<const bf16x8*>(S + row * LDS_LD + 16 * s + 8 * h);
+}
+// accumulator rows (lane = row) -> LDS [128][HD+8] bf16 -> coalesced 16-byte global stores
+template <int HD>
+__device__ __forceinline__ void stage_rows_out(bf16* S, void* dst, int64_t base, int64_t ts, int row0, int nrows_valid,
+                                               const f32x16 (&acc)[HD / 32], float mul, int row_in_tile, int h, int tid) {
+  constexpr int CPR = HD / 8, LDS_LD = HD + 8;
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      bf16x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (bf16)(acc[d][4 * rq + j] * mul);
+      *reinterpret_cast<bf16x4*>(S + row_in_tile * LDS_LD + d * 32 + 8 * rq + 4 * h) = v;
+    }
+  __syncthreads();
+#pragma unroll 2
+  for (int c = tid; c < 128 * CPR; c += 256) {
+    const int row = c / CPR, col = (c - row * CPR) * 8;
+    if (row0 + row < nrows_valid)
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(dst) + base + (int64_t)(row0 + row) * ts + col) =
+          *reinterpret_cast<const uint4*>(S + row * LDS_LD + col);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- forward
 template <int HD, bool F32>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
@@ -259,7 +305,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   const int qi = qvalid ? qraw : p.Nq - 1;
 
   RowFrag<HD, F32> qf;
-  qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
+  if constexpr (F32) {
+    qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
+  } else {
+    stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+    __syncthreads();
+    frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
+    __syncthreads();          // the K/V tile loop reuses this LDS
+  }
   f32x16 O[HD / 32];
 #pragma unroll
   for (int d = 0; d < HD / 32; ++d)
@@ -328,10 +381,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     for (int kt = 0; kt < KT; ++kt) pv<HD, C::LD_TR, F32>(O, Vs + kt * 32 * C::LD_TR, S[kt], lane);
   });
   lsum += __shfl_xor(lsum, 32, 64);
-  if (qvalid) {
-    store_rows<HD>(p.O, p.dt, (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)head * p.o_hs, O, 1.f / lsum, h);
-    if (h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
+  if constexpr (F32) {
+    if (qvalid) store_rows<HD>(p.O, p.dt, (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)head * p.o_hs, O, 1.f / lsum, h);
+  } else {
+    stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, O, 1.f / lsum,
+                       w * 32 + (lane & 31), h, tid);
   }
+  if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
 }
 
 // ---------------------------------------------------------------------------------------------- dQ
@@ -349,8 +405,19 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
   const int qi = qvalid ? qraw : p.Nq - 1;
 
   RowFrag<HD, F32> qf, dof;
-  qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
-  dof.load(p.dO, (int64_t)b * p.do_bs + (int64_t)qi * p.do_ts + (int64_t)head * p.do_hs, h);
+  if constexpr (F32) {
+    qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
+    dof.load(p.dO, (int64_t)b * p.do_bs + (int64_t)qi * p.do_ts + (int64_t)head * p.do_hs, h);
+  } else {
+    stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+    __syncthreads();
+    frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
+    __syncthreads();
+    stage_rows_in<HD>(smem, p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, blockIdx.x * 128, p.Nq, tid);
+    __syncthreads();
+    frag_from_lds<HD>(dof, smem, w * 32 + (lane & 31), h);
+    __syncthreads();
+  }
   const float L = p.LSE[((int64_t)b * p.H + head) * p.Nq + qi];
   const float dl = p.delta[((int64_t)b * p.H + head) * p.Nq + qi];
   const float negL = -L;
@@ -389,8 +456,13 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
       pv<HD, C::LD_ROW, F32>(acc, Ks + kt * 32 * C::LD_ROW, S, lane);
     }
   });
-  if (qvalid)
-    store_rows<HD>(p.dQ, p.dt, (int64_t)b * p.dq_bs + (int64_t)qi * p.dq_ts + (int64_t)head * p.dq_hs, acc, p.scale, h);
+  if constexpr (F32) {
+    if (qvalid)
+      store_rows<HD>(p.dQ, p.dt, (int64_t)b * p.dq_bs + (int64_t)qi * p.dq_ts + (int64_t)head * p.dq_hs, acc, p.scale, h);
+  } else {
+    stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, blockIdx.x * 128, p.Nq, acc, p.scale,
+                       w * 32 + (lane & 31), h, tid);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
