@@ -221,9 +221,9 @@ def _wg_plan(sig):
     device addresses, which change from step to step.  Cached: building ~7000 items in Python costs ~15 ms.
 
     Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2: the tiles of one
-    tile-row (same dY panel) go to ONE XCD, rows are spread over the XCDs by load (long chunks first), and XCD x's list is
-    laid out at positions x, x + 8, x + 16, ... (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles of a row
-    landed on different XCDs).  Padding slots keep A == NULL (the kernel skips them)."""
+    (layer, token chunk) go to ONE XCD, these groups are spread over the XCDs by load (long chunks first), and XCD x's list
+    is laid out at positions x, x + 8, x + 16, ... (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles landed
+    on different XCDs).  Padding slots keep A == NULL (the kernel skips them)."""
     import numpy as np
     plan = _wg_plans.get(sig)
     if plan is not None:
@@ -233,8 +233,10 @@ def _wg_plan(sig):
         nch = -(-tokens // WGRAD_CHUNK)
         for c in range(nch):
             kb, ke = c * WGRAD_CHUNK, min(tokens, (c + 1) * WGRAD_CHUNK)
-            for m0 in range(0, N, 128):
-                groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for n0 in range(0, K, 128)])
+            # one group = ALL tiles of this (layer, token chunk): they run together on one XCD and stream the same
+            # token range in near lockstep, so its L2 serves every dY / X panel slice to all the tiles that share it
+            # (grouping by tile-row only reused the dY panel: rocprofv3 still counted 18.6 GB per launch)
+            groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, 128) for n0 in range(0, K, 128)])
     groups.sort(key=lambda g_: -g_[0][0] * len(g_))
     lists, load = [[] for _ in range(8)], [0] * 8
     for g_ in groups:
