@@ -81,9 +81,11 @@ def train(cfg):
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     dev = torch.device("cuda", torch.cuda.current_device())
     steps = cfg.CSTS_AMD.STEPS_PER_EPOCH
+    from . import checkpoint as ck
+    start_epoch = ck.load_train_checkpoint(cfg, model, optimizer)          # train_avgaze_net.py:280
     model.train()
     graphed = None        # single GPU: the iteration is captured into a HIP graph (the step is launch-bound from Python)
-    for epoch in range(cfg.SOLVER.MAX_EPOCH):
+    for epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCH):
         t0 = time.time()
         for it in range(steps):
             batch = T.synthetic_batch(b, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, 1000 + rank + 7919 * (epoch * steps + it), dev)
@@ -103,6 +105,8 @@ def train(cfg):
                       "kldiv_loss": float(vals[1]), "nce_loss": float(vals[2]) if nce is not None else None})
         torch.cuda.synchronize()
         _log({"_type": "train_epoch", "epoch": epoch + 1, "clips_per_s": steps * b * world / (time.time() - t0)})
+        if getattr(cfg.CSTS_AMD, "SAVE_CHECKPOINTS", False) and (epoch + 1) % cfg.TRAIN.CHECKPOINT_PERIOD == 0:
+            ck.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, epoch, cfg)  # train_avgaze_net.py:345 (0.75 GB + moments)
 
 
 @torch.no_grad()

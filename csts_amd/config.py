@@ -111,6 +111,7 @@ def get_cfg() -> CfgNode:
                        STEPS_PER_EPOCH=50,
                        GRAD_BUCKET_MB=64,
                        TWO_STREAMS=True,             # audio trunk on a second HIP stream, concurrent with the video trunk
+                       SAVE_CHECKPOINTS=False,       # write checkpoints/checkpoint_epoch_XXXXX.pyth (reference wire format) every CHECKPOINT_PERIOD
                        HIP_GRAPH=True,               # single GPU: capture the whole iteration once, replay it (train.GraphedTrainStep)
                        FUSION_KERNEL_FROM_GRID=False)  # True: (1,S/32,S/32) fusion kernels -> 224^2 works (parity unpinned)
     return c

@@ -138,13 +138,33 @@ class FusedAdamW:
         self.state_t.zero_()
 
     def state_dict(self):
-        return {"state": {"step": self.state_t[0:1].clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()},
-                "param_groups": [{"lr": float(self._lr), "weight_decay": g["weight_decay"], "betas": self.betas, "eps": self.eps}
-                                 for g in self.param_groups]}
+        """torch.optim.AdamW's layout (what the reference stores as "optimizer_state", checkpoint.py:131): per-parameter
+        step / exp_avg / exp_avg_sq keyed by the parameter's index over the param groups, plus the groups' hyper-parameters."""
+        step = self.state_t[0:1].detach().clone().reshape(())
+        state = {i: {"step": step.clone(), "exp_avg": self._m[i].detach().clone().view_as(p),
+                     "exp_avg_sq": self._v[i].detach().clone().view_as(p)} for i, p in enumerate(self.params)}
+        groups, off = [], 0
+        for g in self.param_groups:
+            n = len(g["params"])
+            groups.append({"lr": float(self._lr), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": g["weight_decay"],
+                           "amsgrad": False, "params": list(range(off, off + n))})
+            off += n
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        st = sd["state"]
-        self.state_t[0:1].copy_(st["step"])
-        self.exp_avg.copy_(st["exp_avg"])
-        self.exp_avg_sq.copy_(st["exp_avg_sq"])
-        self._lr.fill_(float(sd["param_groups"][0]["lr"]))
+        state = sd["state"]
+        if len(state) not in (0, len(self.params)):
+            raise ValueError("optimizer state has a different number of parameters")
+        steps = set()
+        for i, p in enumerate(self.params):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            self._m[i].copy_(st["exp_avg"].reshape(-1))
+            self._v[i].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(float(st["step"]))
+        if steps:
+            # one step counter for the whole set (every parameter of this path receives a gradient on every iteration)
+            self.state_t[0:1].fill_(max(steps))
+        if sd.get("param_groups"):
+            self._lr.fill_(float(sd["param_groups"][0]["lr"]))

@@ -74,6 +74,15 @@ def install_stubs():
         def clone(self):
             return copy.deepcopy(self)
 
+        def dump(self):          # yacs CfgNode.dump(): the config as a YAML string
+            def plain(x):
+                if isinstance(x, dict):
+                    return {k: plain(v) for k, v in x.items()}
+                if isinstance(x, (list, tuple)):
+                    return [plain(v) for v in x]
+                return x
+            return yaml.safe_dump(plain(self))
+
         def _merge(self, d):
             for k, v in d.items():
                 if isinstance(v, dict):
@@ -378,6 +387,54 @@ def gen_metrics():
     save("metrics_f1.npz", logits=t2n(logits).astype(np.float32), labels=t2n(labels), **out)
 
 
+def gen_checkpoint():
+    """A .pyth checkpoint written by the reference's own save_checkpoint (slowfast/utils/checkpoint.py:110-143) for a
+    small stand-in module with CSTS-style names (incl. a pos_embed_temporal of a different length) and a torch AdamW
+    state -- the wire format csts_amd.checkpoint must read -- plus what the reference's load_checkpoint makes of it."""
+    import tempfile, shutil
+    from slowfast.utils import checkpoint as ref_ckpt
+
+    class PM:          # the iopath stub lacks mkdirs
+        def mkdirs(self, p): os.makedirs(p, exist_ok=True)
+        def open(self, *a, **k): return open(*a, **k)
+        def exists(self, p): return os.path.exists(p)
+        def ls(self, p): return os.listdir(p)
+    ref_ckpt.pathmgr = PM()
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, T):
+            super().__init__()
+            self.pos_embed_spatial = torch.nn.Parameter(torch.zeros(1, 16, 8))
+            self.pos_embed_temporal = torch.nn.Parameter(torch.zeros(1, T, 8))
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(2)])
+            self.head = torch.nn.Linear(8, 3)
+
+    torch.manual_seed(11)
+    src = Tiny(4)
+    for p_ in src.parameters():
+        torch.nn.init.normal_(p_, std=0.5)
+    opt = torch.optim.AdamW(src.parameters(), lr=1e-3, eps=1e-8, weight_decay=0.05)
+    src.head(src.blocks[1](src.blocks[0](src.pos_embed_spatial + src.pos_embed_temporal.mean(1, keepdim=True)))).sum().backward()
+    opt.step()
+    cfg = make_cfg(8)
+    tmp = tempfile.mkdtemp()
+    path = ref_ckpt.save_checkpoint(tmp + "/", src, opt, 6, cfg)
+    assert path.endswith("checkpoint_epoch_00007.pyth"), path
+    shutil.copy(path, os.path.join(OUT, "ref_checkpoint_epoch_00007.pyth"))
+    # the reference loading it into a model whose temporal pos-embed is longer and whose head has another shape
+    dst = Tiny(8)
+    dst.head = torch.nn.Linear(8, 5)
+    torch.manual_seed(12)
+    for p_ in dst.parameters():
+        torch.nn.init.normal_(p_, std=0.1)
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    epoch = ref_ckpt.load_checkpoint(path, dst, data_parallel=False, optimizer=None, epoch_reset=True)
+    after = dst.state_dict()
+    save("ref_checkpoint_loaded.npz", epoch=np.array(epoch), **{k.replace(".", "__"): t2n(v) for k, v in after.items()},
+         **{"before__" + k.replace(".", "__"): t2n(v) for k, v in before.items()})
+    shutil.rmtree(tmp)
+
+
 def gen_lr():
     from slowfast.utils import lr_policy
     cfg = make_cfg(8)
@@ -395,6 +452,8 @@ if __name__ == "__main__":
         gen_lr()
     if "metrics" in what or "blocks" in what:
         gen_metrics()
+    if "checkpoint" in what or "blocks" in what:
+        gen_checkpoint()
     if "model" in what:
         gen_model()
     if "model" in what or "t32" in what:

@@ -196,3 +196,46 @@ def test_two_rank_gloo_data_parallel_logic():
         assert r[1], "all_gather_with_grad backward != single-process gradient"
         assert r[2], "bucketed gradient all-reduce != mean of per-rank gradients"
         assert r[3], "scalar all-reduce / gather"
+
+
+def test_checkpoint_wire_format_reads_reference_written_pyth(tmp_path):
+    """csts_amd.checkpoint against a .pyth written by the REFERENCE's save_checkpoint (fixture from oracle/gen_golden.py):
+    name + shape matching, bilinear pos-embed resize, epoch / optimizer-state handling == the reference's load_checkpoint
+    (slowfast/utils/checkpoint.py:185-354), and our own save_checkpoint round-trips through the same format."""
+    import numpy as np
+    from csts_amd import checkpoint as ck
+    from csts_amd.config import load_yaml
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, T, nout):
+            super().__init__()
+            self.pos_embed_spatial = torch.nn.Parameter(torch.zeros(1, 16, 8))
+            self.pos_embed_temporal = torch.nn.Parameter(torch.zeros(1, T, 8))
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(2)])
+            self.head = torch.nn.Linear(8, nout)
+
+    ref_file = os.path.join(GOLDEN, "ref_checkpoint_epoch_00007.pyth")
+    g = np.load(os.path.join(GOLDEN, "ref_checkpoint_loaded.npz"))
+    dst = Tiny(8, 5)
+    dst.load_state_dict({k: torch.from_numpy(g["before__" + k.replace(".", "__")]) for k in dst.state_dict()})
+    epoch, not_loaded = ck.load_checkpoint(ref_file, dst, epoch_reset=True)
+    assert epoch == int(g["epoch"]) == -1
+    assert sorted(not_loaded) == ["head.bias", "head.weight"]          # shape mismatch: left untouched, like the reference
+    for k, v in dst.state_dict().items():
+        assert torch.allclose(v, torch.from_numpy(g[k.replace(".", "__")]), atol=1e-7), k
+    # resume semantics: epoch and the torch AdamW state come back
+    src = Tiny(4, 3)
+    opt = torch.optim.AdamW(src.parameters(), lr=5e-4, eps=1e-8, weight_decay=0.05)
+    epoch, not_loaded = ck.load_checkpoint(ref_file, src, optimizer=opt)
+    assert epoch == 6 and not not_loaded
+    assert len(opt.state_dict()["state"]) == 8 and abs(opt.param_groups[0]["lr"] - 1e-3) < 1e-12
+    # our writer -> same layout (keys, file name), readable by our reader
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0])
+    path = ck.save_checkpoint(str(tmp_path), src, opt, 2, cfg)
+    assert path.endswith(os.path.join("checkpoints", "checkpoint_epoch_00003.pyth")) and ck.has_checkpoint(str(tmp_path))
+    assert ck.get_last_checkpoint(str(tmp_path)) == path
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(blob) == ["cfg", "epoch", "model_state", "optimizer_state"] and isinstance(blob["cfg"], str)
+    again = Tiny(4, 3)
+    assert ck.load_checkpoint(path, again)[0] == 2
+    assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), src.state_dict().values()))

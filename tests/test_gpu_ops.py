@@ -440,3 +440,35 @@ def test_adaptive_f1_on_device():
         assert abs(f1b - ref[0]) < 2e-6
     with pytest.raises(NotImplementedError):
         M.adaptive_f1(preds, hm, labels, "kinetics")
+
+
+def test_fused_adamw_state_dict_is_torch_adamw_format():
+    """FusedAdamW.state_dict() / load_state_dict() speak torch.optim.AdamW's layout (what a reference .pyth stores as
+    "optimizer_state"): moments move both ways and the next step agrees."""
+    from csts_amd.optim import FusedAdamW
+    shapes = [(64, 40), (96,), (3, 5, 7)]
+    pa = [rnd(*s_, seed=20 + i, scale=0.5).requires_grad_() for i, s_ in enumerate(shapes)]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    ref = torch.optim.AdamW([{"params": [pb[0], pb[2]], "weight_decay": 0.05}, {"params": [pb[1]], "weight_decay": 0.0}],
+                            lr=2e-3, eps=1e-8)
+    fused = FusedAdamW([{"params": [pa[0], pa[2]], "weight_decay": 0.05}, {"params": [pa[1]], "weight_decay": 0.0}],
+                       lr=1e-5, eps=1e-8, max_grad_norm=0.0)
+    for step in range(2):                      # give the torch optimizer some history
+        for i, b in enumerate(pb):
+            b.grad = rnd(*shapes[i], seed=300 + 10 * step + i)
+        ref.step()
+    for a, b in zip(pa, pb):
+        a.data.copy_(b.data)
+    fused.load_state_dict(ref.state_dict())    # torch -> fused
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        g = rnd(*shapes[i], seed=900 + i)
+        a.grad, b.grad = g.clone(), g.clone()
+    ref.step(); fused.step()
+    for a, b in zip(pa, pb):
+        assert rel_l2(a.detach(), b.detach()) < 2e-6
+    ref2 = torch.optim.AdamW([{"params": [pb[0], pb[2]], "weight_decay": 0.05}, {"params": [pb[1]], "weight_decay": 0.0}],
+                             lr=1.0, eps=1e-8)
+    ref2.load_state_dict(fused.state_dict())   # fused -> torch
+    assert abs(ref2.param_groups[0]["lr"] - 2e-3) < 1e-9
+    assert rel_l2(ref2.state[pb[2]]["exp_avg"], ref.state[pb[2]]["exp_avg"]) < 1e-6
+    assert float(ref2.state[pb[0]]["step"]) == 3.0
