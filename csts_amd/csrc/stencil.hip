@@ -723,11 +723,10 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void
 }
 
 int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 8); }
-// kernels that stage the 27 x HD weight table per workgroup: fewer, fatter workgroups amortise the staging
-int grid_for_staged(int64_t total) {
-  static const int cap = getenv("CSTS_STENCIL_GRID_CAP") ? atoi(getenv("CSTS_STENCIL_GRID_CAP")) : 256 * 8;
-  return (int)std::min<int64_t>(cdiv(total, 256), cap);
-}
+// kernels that stage the 27 x HD weight table per workgroup.  Measured on MI355X (tools/dwconv_bench.py, whole step):
+// caps of 256 / 512 / 1024 / 2048 workgroups give 28.28 / 27.88 / 27.75 / 27.90 ms per step -- the staging is not what
+// bounds these kernels, so the cap stays at 8 workgroups per CU.
+int grid_for_staged(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 8); }
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
