@@ -87,11 +87,20 @@ class GradAllReduce(nn.Module):
         self.module = module
         self.world = dist.get_world_size() if is_dist() else 1
         self.bucket_bytes = int(bucket_mb) * (1 << 20)
+        self._late = []
+        late_ids = set()
         if self.world > 1 or _FORCE:
-            # bucket hooks read gradients in the middle of backward, on whichever stream autograd is replaying: the
-            # deferred (end-of-backward) second-stage reductions of ops.py would not have run yet -> keep them in line
-            _ops.DEFER_REDUCTIONS = False
-        self._params = [p for p in module.parameters() if p.requires_grad]
+            # Bucket hooks read gradients in the middle of backward.  Linear weight gradients therefore run in line (no
+            # grouped end-of-backward launch).  The LayerNorm / pooling-stencil parameters, whose second-stage
+            # reductions ARE deferred to the end of backward (ops.flush_deferred), are kept out of the hook-driven
+            # buckets and reduced in one small bucket by finish() (they total ~0.1 % of the gradient bytes).
+            _ops.GROUP_WGRADS = "never"
+            for name, p in module.named_parameters():
+                if p.requires_grad and any(t in name for t in (".norm1.", ".norm2.", ".norm_q.", ".norm_k.", ".norm_v.",
+                                                               ".pool_q.", ".pool_k.", ".pool_v.", ".upsample_q.")):
+                    self._late.append(p)
+                    late_ids.add(id(p))
+        self._params = [p for p in module.parameters() if p.requires_grad and id(p) not in late_ids]
         self._assign(list(reversed(self._params)))
         self._ready_order: List[torch.nn.Parameter] = []
         self._observed = False
@@ -169,6 +178,19 @@ class GradAllReduce(nn.Module):
     def finish(self):
         """Wait for the outstanding buckets and hand the averaged gradients back (call after backward): every p.grad
         becomes a VIEW of its bucket's flat buffer -- no copy back."""
+        if self._late and (self.world > 1 or _FORCE):
+            # complete by now: the deferred reductions ran in the autograd final callback, on this stream
+            ps = [p for p in self._late if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+            if self._avg_op is not None:
+                dist.all_reduce(flat, op=self._avg_op)
+            else:
+                flat /= self.world
+                dist.all_reduce(flat)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
         for work, flat, ps, views in self._pending:
             work.wait()
             if flat.is_cuda:

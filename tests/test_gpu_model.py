@@ -311,6 +311,7 @@ def test_rccl_single_rank_collective_paths():
         assert abs(float(r[1]) - 2 * float(loss)) < 1e-6
     finally:
         du._FORCE = False
+        ops.GROUP_WGRADS, ops.DEFER_REDUCTIONS = "capture", True     # GradAllReduce switches the grouped tail off process-wide
         dist.destroy_process_group()
         _MODELS.clear()
 
