@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--rehearse-dist", action="store_true",
                    help="run the N>1 code path (RCCL process group, GradAllReduce buckets, eager step) with ONE rank")
+    p.add_argument("--ddp-graph", action="store_true",
+                   help="EXPERIMENTAL: capture the data-parallel step (RCCL collectives included) into a HIP graph")
     p.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph (single GPU only)")
     p.add_argument("--op-breakdown", default=None, help="write per-C-ABI-entry device time of one eager step to this file")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
@@ -220,11 +222,11 @@ def main():
     if dist_path and not isinstance(model, GradAllReduce):
         model = GradAllReduce(model, bucket_mb=cfg.CSTS_AMD.GRAD_BUCKET_MB)
     model.train()
-    use_graph = not dist_path and not args.no_graph
+    use_graph = (not dist_path or args.ddp_graph) and not args.no_graph
     opt = T.construct_optimizer(model, cfg, capturable=use_graph)
     batch = T.synthetic_batch(b, args.frames, 256, 1000 + rank, dev)      # resident in HBM before timing
     lr = T.get_lr_at_epoch(cfg, 0.0)
-    graphed = T.GraphedTrainStep(cfg, model, opt, batch) if use_graph else None
+    graphed = T.GraphedTrainStep(cfg, model, opt, batch, allow_collectives=args.ddp_graph) if use_graph else None
 
     def step():
         if graphed is not None:

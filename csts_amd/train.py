@@ -163,8 +163,12 @@ class GraphedTrainStep:
     into static buffers; the learning rate lives in a device tensor (set_lr) so the schedule still applies.
     Drop-path masks are drawn by torch's graph-safe Philox generator on every replay."""
 
-    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2):
-        assert not isinstance(model, GradAllReduce), "graph capture is single-GPU; multi-GPU runs eagerly"
+    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2, allow_collectives: bool = False):
+        # RCCL collectives can be captured too (torch's ProcessGroupNCCL supports it), but that path has only been run
+        # with ONE rank here (bench.py --rehearse-dist --ddp-graph): multi-GPU runs stay eager unless asked otherwise.
+        assert allow_collectives or not isinstance(model, GradAllReduce), "graph capture is single-GPU; multi-GPU runs eagerly"
+        if isinstance(model, GradAllReduce):
+            warmup = max(warmup, 3)          # bucket order and per-bucket streams are learnt in the first iterations
         self.cfg, self.model, self.opt = cfg, model, optimizer
         self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
         from . import ops
@@ -193,6 +197,8 @@ class GraphedTrainStep:
         loss, kld, nce, _ = compute_loss(self.cfg, self.model, self.static["video"], self.static["audio"],
                                          self.static["labels_hm"])
         loss.backward()
+        if isinstance(self.model, GradAllReduce):
+            self.model.finish()
         _clip_and_step(self.cfg, self.model, self.opt)
         return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
 
@@ -203,7 +209,8 @@ class GraphedTrainStep:
                     self.static[k].copy_(batch[k], non_blocking=True)
         if lr is not None:
             set_lr(self.opt, lr)
-        if hasattr(self.model, "_refresh_w16"):
-            self.model._refresh_w16()        # only acts after an out-of-band weight change (load_state_dict)
+        core = self.model.module if isinstance(self.model, GradAllReduce) else self.model
+        if hasattr(core, "_refresh_w16"):
+            core._refresh_w16()              # only acts after an out-of-band weight change (load_state_dict)
         self.graph.replay()
         return self.out
