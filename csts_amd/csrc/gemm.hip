@@ -597,7 +597,7 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
 // one partial slab per chunk, finished by csts_reduce_rows_batched).  Same tile machinery as gemm2_kernel (TN form).
 // =====================================================================================================
 template <bool A_F32, int MT>
-__global__ __launch_bounds__(256, (MT == 2) ? 3 : 4) void wgrad_grouped_kernel(const csts_wgrad_item* __restrict__ items) {
+__global__ __launch_bounds__(256, (MT == 4) ? 2 : ((MT == 2) ? 3 : 4)) void wgrad_grouped_kernel(const csts_wgrad_item* __restrict__ items) {
   constexpr int BM2 = 64 * MT, NTHR = 256;
   typedef Oper<false, A_F32, BM2, NTHR> OA;
   typedef Oper<false, false, 128, NTHR> OB;
@@ -879,9 +879,11 @@ extern "C" size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, in
 // tokens of dY[:, m] for the tile's rows (bias gradient), written by the n0 == 0 tiles.
 extern "C" int csts_wgrad_grouped(const csts_wgrad_item* device_items, int nitems, int a_f32, int tile_rows, hipStream_t stream) {
   CSTS_REQUIRE(device_items != nullptr && nitems > 0, "no items");
-  CSTS_REQUIRE(tile_rows == 64 || tile_rows == 128, "tile_rows must be 64 or 128");
+  CSTS_REQUIRE(tile_rows == 64 || tile_rows == 128 || (tile_rows == 256 && !a_f32), "tile_rows must be 64, 128 or (bf16 dY) 256");
   const dim3 grid((unsigned)nitems), block(256);
-  if (a_f32) {
+  if (tile_rows == 256) {
+    hipLaunchKernelGGL((wgrad_grouped_kernel<false, 4>), grid, block, 0, stream, device_items);
+  } else if (a_f32) {
     if (tile_rows == 128) hipLaunchKernelGGL((wgrad_grouped_kernel<true, 2>), grid, block, 0, stream, device_items);
     else hipLaunchKernelGGL((wgrad_grouped_kernel<true, 1>), grid, block, 0, stream, device_items);
   } else {

@@ -216,7 +216,7 @@ def _wg_dtype():
     return _WG_DTYPE
 
 
-def _wg_plan(sig):
+def _wg_plan(sig, rows=128):
     """Work-item layout of one grouped launch for the problem list `sig` = ((tokens, N, K), ...): everything except the
     device addresses, which change from step to step.  Cached: building ~7000 items in Python costs ~15 ms.
 
@@ -225,7 +225,7 @@ def _wg_plan(sig):
     is laid out at positions x, x + 8, x + 16, ... (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles landed
     on different XCDs).  Padding slots keep A == NULL (the kernel skips them)."""
     import numpy as np
-    plan = _wg_plans.get(sig)
+    plan = _wg_plans.get((sig, rows))
     if plan is not None:
         return plan
     groups = []
@@ -236,7 +236,7 @@ def _wg_plan(sig):
             # one group = ALL tiles of this (layer, token chunk): they run together on one XCD and stream the same
             # token range in near lockstep, so its L2 serves every dY / X panel slice to all the tiles that share it
             # (grouping by tile-row only reused the dY panel: rocprofv3 still counted 18.6 GB per launch)
-            groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, 128) for n0 in range(0, K, 128)])
+            groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, rows) for n0 in range(0, K, 128)])
     groups.sort(key=lambda g_: -g_[0][0] * len(g_))
     lists, load = [[] for _ in range(8)], [0] * 8
     for g_ in groups:
@@ -257,7 +257,7 @@ def _wg_plan(sig):
             tmpl[i] = (0, 0, 0, 0, N, K, K, kb, ke, N, K, m0, n0)
             pidx[i], chunk[i] = pi, c
     valid = pidx >= 0
-    plan = _wg_plans[sig] = (tmpl, valid, pidx[valid], chunk[valid], n_items)
+    plan = _wg_plans[(sig, rows)] = (tmpl, valid, pidx[valid], chunk[valid], n_items)
     return plan
 
 
@@ -272,11 +272,13 @@ def flush_wgrads():
     if tab is None:
         tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=3, captures=4)
     keep = []
-    for a_f32 in (False, True):
-        probs = [t for t in q if (t[0].dtype == torch.float32) == a_f32]
+    # 256 x 128 tiles where they divide the layer's output rows (bf16 dY): a quarter less operand traffic per FLOP
+    for a_f32, rows in ((False, 256), (False, 128), (True, 128)):
+        wants256 = lambda t: not a_f32 and t[5] % 256 == 0
+        probs = [t for t in q if (t[0].dtype == torch.float32) == a_f32 and (wants256(t) == (rows == 256))]
         if not probs:
             continue
-        tmpl, valid, pidx, chunk, n_items = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs))
+        tmpl, valid, pidx, chunk, n_items = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows)
         A = np.empty(len(probs), dtype=np.uint64); B = np.empty_like(A); Cb = np.empty_like(A); Cs = np.zeros_like(A)
         cstride = np.zeros(len(probs), dtype=np.uint64); sstride = np.zeros_like(cstride)
         for i, (dY, X, dW, db, tokens, N, K) in enumerate(probs):
@@ -301,7 +303,7 @@ def flush_wgrads():
         arr["C"][valid] = Cb[pidx] + ch * cstride[pidx]
         arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
         ptr = tab.upload(arr.tobytes())
-        L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, 128, _stream()), "csts_wgrad_grouped")
+        L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
     del q, keep
 
 

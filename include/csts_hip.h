@@ -67,7 +67,7 @@ int csts_gemm_v2_eligible(const csts_gemm_args* args);   /* 1 when the fast bf16
 /* Grouped weight gradients: every dW[M,N] = dY[tokens,M]^T X[tokens,N] of a backward pass (nn.Linear weight gradients of
  * attention.py:88-89, common.py:20-21 ...) as (tile, token-chunk) work items of ONE launch; items live in DEVICE memory.
  * A (dY) is bf16 or fp32 for the whole launch (a_f32), B (X) bf16, C fp32 (the gradient itself, or one chunk's partial slab
- * to be summed by csts_reduce_rows_batched); tile_rows (64 | 128) x 128 tiles, all of one height per launch.
+ * to be summed by csts_reduce_rows_batched); tile_rows (64 | 128, or 256 with bf16 dY) x 128 tiles, one height per launch.
  * colsum (optional): bias-gradient partial sum over the item's tokens for the tile's rows (written by n0 == 0 tiles). */
 typedef struct {
   const void* A; const void* B; float* C; float* colsum;
