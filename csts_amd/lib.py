@@ -149,6 +149,11 @@ SYMBOLS = {
     "csts_egonce_fwd": (_I, [vp, vp, vp, vp, _I, _F, vp]),
     "csts_egonce_bwd": (_I, [vp, vp, vp, vp, vp, _I, _F, vp]),
     "csts_adamw_step": (_I, [C.POINTER(OptArgs), vp]),
+    "csts_frames_normalize": (_I, [vp, vp, _I, i64, _I, C.c_float * 3, C.c_float * 3, vp]),
+    "csts_stft_frames": (_I, [_I, _I, _I]),
+    "csts_stft_logpower": (_I, [vp, vp, _I, _I, _I, _I, _I, _F, vp]),
+    "csts_audio_windows": (_I, [vp, vp, vp, _I, _I, _I, _I, _I, vp]),
+    "csts_gaze_heatmaps": (_I, [vp, _I, vp, i64, _I, _I, _I, vp]),
     "csts_adaptive_f1_workspace": (sz, [i64, _I]),
     "csts_adaptive_f1": (_I, [vp, vp, vp, vp, _I, i64, _I, _I, vp, vp, sz, vp]),
 }

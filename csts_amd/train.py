@@ -126,12 +126,26 @@ def _clip_and_step(cfg, model, optimizer):
     optimizer.step()
 
 
-def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device) -> Dict[str, torch.Tensor]:
+def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device, pipeline: str = "device") -> Dict[str, torch.Tensor]:
     """Synthetic clips generated ON DEVICE following the dataset contract (SURVEY.md 8(d);
     ego4d_avgaze_forecast.py:214-221,294-335): normalised uint8 video, log-power STFT windows of 24 kHz noise
-    (n_fft 511, hop 120, win 240: data/preprocess.py:276-290), 19x19-Gaussian gaze heatmaps."""
+    (n_fft 511, hop 120, win 240: data/preprocess.py:276-290), 19x19-Gaussian gaze heatmaps.
+    pipeline="device": raw uint8 frames / waveform / gaze points go through the HIP input pipeline (csts_amd.inputs);
+    pipeline="torch": the same quantities with torch ops (torch.stft), the cross-check."""
     g = torch.Generator(device=device).manual_seed(seed)
     T, S = num_frames, crop
+    if pipeline == "device" and torch.device(device).type == "cuda":
+        from . import inputs
+        frames = torch.randint(0, 256, (B, T, S, S, 3), generator=g, device=device, dtype=torch.uint8)
+        n = 24000 * 5
+        wav = 0.1 * torch.randn(B, n, generator=g, device=device) + 0.05 * torch.sin(
+            2 * math.pi * 440.0 * torch.arange(n, device=device) / 24000.0)[None]
+        xy = torch.rand(B, T, 2, generator=g, device=device)
+        labels = torch.cat([xy, torch.zeros(B, T, 1, device=device)], dim=-1)
+        frames_idx = (torch.arange(T, device=device, dtype=torch.float32) + 0.5)[None].expand(B, T)
+        batch = inputs.assemble_batch(frames, wav, frames_idx, float(T), labels)
+        batch["labels"] = labels.double()
+        return batch
     u = torch.randint(0, 256, (B, 3, T, S, S), generator=g, device=device).float()
     video = (u / 255.0 - 0.45) / 0.225
     n = 24000 * 5

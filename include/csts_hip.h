@@ -253,6 +253,23 @@ size_t csts_adaptive_f1_workspace(int64_t nframes, int nthr);
 int csts_adaptive_f1(const float* preds, const float* labels_hm, const uint8_t* tracked, const float* thresholds, int nthr,
                      int64_t nframes, int hw, int rescale, float* out, void* workspace, size_t ws_bytes, hipStream_t stream);
 
+/* ---- input pipeline on the device ("next" row): what the reference does on the CPU just before the
+ *      model is called.  frames_normalize: uint8 (B, T*H*W, C) -> fp32 (B, C, T*H*W), (x/255 - mean)/std
+ *      (slowfast/datasets/utils.py:290-307, ego4d_avgaze_forecast.py:294-296).  stft_logpower: fp32 waveform (B, n) ->
+ *      log(|STFT|^2 + eps) (B, n_fft/2+1, csts_stft_frames(n, n_fft, hop)), librosa.stft semantics (center, zero padding,
+ *      periodic Hann of win samples centred in n_fft; data/preprocess.py:276-290).  audio_windows: (B, 1, T, nbins, width)
+ *      windows of the spectrogram centred on centers[b][t] (ego4d_avgaze_forecast.py:214-219).  gaze_heatmaps: labels
+ *      (nframes, label_stride) with x, y in [0,1] -> (nframes, H, W) OpenCV-Gaussian maps normalised to sum 1
+ *      (ego4d_avgaze_forecast.py:318-326,404-422). */
+int csts_frames_normalize(const uint8_t* frames_thwc, float* out_cthw, int B, int64_t thw, int C, const float mean[3],
+                          const float std[3], hipStream_t stream);
+int csts_stft_frames(int n, int n_fft, int hop);
+int csts_stft_logpower(const float* wav, float* spec, int B, int n, int n_fft, int hop, int win, float eps, hipStream_t stream);
+int csts_audio_windows(const float* spec, const int* centers, float* out, int B, int T, int nbins, int cols, int width,
+                       hipStream_t stream);
+int csts_gaze_heatmaps(const float* labels, int label_stride, float* heatmaps, int64_t nframes, int H, int W, int ksize,
+                       hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -592,3 +592,68 @@ def adaptive_f1(preds, labels_hm, labels, dataset):
     f1 = (2 * recall * precision) / (recall + precision + 1e-6)        # :70
     i = int(torch.argmax(f1))
     return float(f1[i]), float(recall[i]), float(precision[i]), thresholds[i]
+
+
+# --------------------------------------------------------------------------------------- input pipeline
+# PARITY UNPINNED against the reference for this block: the reference computes these with librosa / OpenCV, which are
+# absent from the build image, so the functions below restate the PUBLISHED algorithms (librosa.stft with center=True,
+# pad_mode='constant', periodic Hann window padded to n_fft; cv2.getGaussianKernel's closed form) at the reference's call
+# sites; the STFT is cross-checked against torch.stft in tests/test_oracle_golden.py.
+def frames_normalize(frames_u8, mean=(0.45, 0.45, 0.45), std=(0.225, 0.225, 0.225)):
+    """uint8 (T, H, W, C) -> float (C, T, H, W): slowfast/datasets/utils.py:290-307 (tensor_normalize) + the permute of
+    ego4d_avgaze_forecast.py:296."""
+    x = frames_u8.float() / 255.0
+    x = (x - torch.tensor(mean)) / torch.tensor(std)
+    return x.permute(3, 0, 1, 2).contiguous()
+
+
+def stft_logpower(wav, n_fft=511, hop=120, win=240, eps=1e-6):
+    """data/preprocess.py:287-290: log(|librosa.stft(y, n_fft=511, window='hann', hop_length=120, win_length=240,
+    pad_mode='constant')|^2 + 1e-6) for 24 kHz audio (10 ms window, 5 ms step) -> (n_fft//2 + 1, 1 + len(y)//hop)."""
+    import numpy as np
+    y = np.asarray(wav, dtype=np.float64)
+    k = np.arange(win)
+    w = 0.5 - 0.5 * np.cos(2.0 * np.pi * k / win)                      # scipy get_window('hann', win, fftbins=True)
+    lpad = (n_fft - win) // 2
+    wfull = np.zeros(n_fft)
+    wfull[lpad:lpad + win] = w                                          # librosa.util.pad_center
+    ypad = np.pad(y, n_fft // 2, mode="constant")                       # center=True
+    nfr = 1 + (len(ypad) - n_fft) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(nfr)[:, None]
+    S = np.fft.rfft(ypad[idx] * wfull[None, :], n=n_fft, axis=1).T      # (bins, frames)
+    return np.log((S * np.conj(S)).real + eps).astype(np.float32)
+
+
+def audio_windows(spec, frames_idx, frame_length):
+    """ego4d_avgaze_forecast.py:214-219: T windows of 256 spectrogram columns centred on the sampled video frames."""
+    import numpy as np
+    cols = spec.shape[1]
+    idx = np.round(np.asarray(frames_idx, dtype=np.float64) / frame_length * cols).astype(np.int64)   # torch.round: half to even
+    idx = np.clip(idx, 128, cols - 1 - 128)
+    return np.stack([spec[:, i - 128:i + 128] for i in idx], axis=0)[None], idx
+
+
+def gaze_heatmaps(labels_xy, T, H=64, W=64, ksize=19):
+    """ego4d_avgaze_forecast.py:318-326 + _get_gaussian_map (:404-422): a ksize x ksize OpenCV Gaussian
+    (sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8) pasted at round(x*W), round(y*H), clipped at the border, renormalised to sum 1
+    (uniform 1/(H*W) when the gaze falls outside)."""
+    import numpy as np
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    i = np.arange(ksize) - (ksize - 1) / 2
+    k1 = np.exp(-(i * i) / (2 * sigma * sigma))
+    k1 = (k1 / k1.sum()).astype(np.float32)                              # ktype CV_32F
+    k2 = np.outer(k1, k1)
+    out = np.zeros((T, H, W), dtype=np.float64)
+    r = (ksize - 1) // 2
+    for t in range(T):
+        mu_x, mu_y = round(float(labels_xy[t][0]) * W), round(float(labels_xy[t][1]) * H)   # Python round: half to even
+        left, right = max(mu_x - r, 0), min(mu_x + r, W - 1)
+        top, bottom = max(mu_y - r, 0), min(mu_y + r, H - 1)
+        if not (left >= right or top >= bottom):
+            out[t, top:bottom + 1, left:right + 1] = k2[r - mu_y + top:r + bottom - mu_y + 1, r - mu_x + left:r + right - mu_x + 1]
+        s = out[t].sum()
+        if s == 0:
+            out[t] += 1.0 / (H * W)
+        elif s != 1:
+            out[t] /= s
+    return out.astype(np.float32)

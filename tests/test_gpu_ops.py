@@ -472,3 +472,41 @@ def test_fused_adamw_state_dict_is_torch_adamw_format():
     assert abs(ref2.param_groups[0]["lr"] - 2e-3) < 1e-9
     assert rel_l2(ref2.state[pb[2]]["exp_avg"], ref.state[pb[2]]["exp_avg"]) < 1e-6
     assert float(ref2.state[pb[0]]["step"]) == 3.0
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline
+def test_input_pipeline_on_device():
+    """csts_frames_normalize / csts_stft_logpower / csts_audio_windows / csts_gaze_heatmaps against the oracle's
+    restatement of the dataset code (slowfast/datasets/utils.py:290-307, data/preprocess.py:276-290,
+    ego4d_avgaze_forecast.py:214-219,318-326,404-422) and, for the STFT, against torch.stft."""
+    import numpy as np
+    from csts_amd import inputs as I
+    g = torch.Generator().manual_seed(5)
+    B, T = 2, 8
+    fr = torch.randint(0, 256, (B, T, 32, 48, 3), generator=g, dtype=torch.uint8)
+    out = I.normalize_frames(fr.to(DEV))
+    for b in range(B):
+        assert torch.allclose(out[b].cpu(), O.frames_normalize(fr[b]), atol=1e-6)
+    wav = 0.1 * torch.randn(B, 24000 * 2 + 37, generator=g) + 0.05 * torch.sin(torch.arange(24000 * 2 + 37) * 0.11)[None]
+    spec = I.stft_logpower(wav.to(DEV)).cpu()
+    for b in range(B):
+        ref = torch.from_numpy(O.stft_logpower(wav[b].numpy()))
+        assert spec[b].shape == ref.shape
+        assert (spec[b] - ref).abs().max() < 2e-3             # log domain; tiny powers amplify fp32 rounding
+        tref = torch.stft(wav[b], n_fft=511, hop_length=120, win_length=240, window=torch.hann_window(240), center=True,
+                          pad_mode="constant", return_complex=True)
+        assert (spec[b] - torch.log(tref.abs() ** 2 + 1e-6)).abs().max() < 2e-3
+    idx = torch.tensor([[3.0, 10.5, 22.0, 40.0, 57.5, 70.0, 88.0, 89.9]] * B)
+    win = I.audio_windows(spec.to(DEV), idx.to(DEV), 90.0).cpu()
+    for b in range(B):
+        ref, _ = O.audio_windows(spec[b].numpy(), idx[b].numpy(), 90.0)
+        assert np.array_equal(win[b].numpy(), ref)
+    labels = torch.tensor([[[0.5, 0.5, 0], [0.0, 0.98, 0], [1.5, 0.5, 0], [0.03, 0.01, 1], [0.999, 0.999, 0], [0.25, 0.75, 0],
+                            [0.5078125, 0.4921875, 0], [-0.2, 0.3, 0]]] * B)
+    hm = I.gaze_heatmaps(labels.to(DEV)).cpu()
+    for b in range(B):
+        ref = torch.from_numpy(O.gaze_heatmaps(labels[b].numpy(), T))
+        assert torch.allclose(hm[b], ref, atol=1e-7, rtol=1e-4)
+    assert torch.allclose(hm.sum(dim=(-1, -2)), torch.ones(B, T), atol=1e-5)
+    batch = I.assemble_batch(fr.to(DEV), wav.to(DEV), idx.to(DEV), 90.0, labels.to(DEV))
+    assert batch["video"].shape == (B, 3, T, 32, 48) and batch["audio"].shape == (B, 1, T, 256, 256)

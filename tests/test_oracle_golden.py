@@ -235,3 +235,17 @@ def test_adaptive_f1_metric():
         f1, rec, prec, thr = O.adaptive_f1(preds, hm, labels, ds)
         ref = g[ds]
         assert abs(f1 - ref[0]) < 1e-6 and abs(rec - ref[1]) < 1e-6 and abs(prec - ref[2]) < 1e-6 and abs(thr - ref[3]) < 1e-12, (ds, f1, ref)
+
+
+def test_input_pipeline_oracle_cross_checks():
+    """The input-pipeline restatement is NOT pinned by the reference (librosa / OpenCV are absent): the STFT is cross-checked
+    against torch.stft, the heat maps against their defining properties."""
+    wav = 0.1 * torch.randn(24000, generator=torch.Generator().manual_seed(3))
+    s = torch.from_numpy(O.stft_logpower(wav.numpy()))
+    t = torch.stft(wav, n_fft=511, hop_length=120, win_length=240, window=torch.hann_window(240), center=True,
+                   pad_mode="constant", return_complex=True)
+    assert s.shape == (256, 200) == tuple(t.shape) and (s - torch.log(t.abs() ** 2 + 1e-6)).abs().max() < 1e-3
+    hm = O.gaze_heatmaps([(0.5, 0.5), (0.0, 0.98), (1.5, 0.5)], 3)
+    assert np.allclose(hm.sum(axis=(1, 2)), 1.0, atol=1e-6)
+    assert hm[0].argmax() == 32 * 64 + 32 and abs(hm[2].max() - 1 / 4096) < 1e-9       # centre ; outside the image -> uniform
+    assert (hm[0] > 0).sum() == 19 * 19
