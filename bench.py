@@ -77,7 +77,9 @@ class GemmTimer:
                 rc = fn(argsref, stream)
                 e1.record()
                 tf = lambda b: "true" if b else "false"
-                if v2.value:
+                if v2.value >= 30:
+                    name = f"gemm3_kernel<{tr.value // 64}, {v2.value - 30}>"
+                elif v2.value:
                     name = (f"gemm2_kernel<{tf(a.layout != 2)}, {tf(a.layout == 0)}, {tf(a.a_dt == 0)}, {tf(a.b_dt == 0)}, "
                             f"{tr.value // 64}, 2>")
                 else:

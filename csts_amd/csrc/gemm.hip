@@ -11,6 +11,7 @@
 // Operands whose reduction dim is NOT the contiguous one are kept [k][out] in LDS and fed to the MFMA through
 // ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32), so staging is always a straight 16-byte copy.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -32,6 +33,8 @@ struct Params {
   int64_t lda, ldb, ldc, ldaux, ldr;
   int64_t M, N, K, res_row_mod, rows_per_scale, k_chunk;
   int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
+  int64_t ntiles;   // gemm3 (persistent): output tiles of the whole problem
+  unsigned long long* stamps;   // gemm3 built with -DCSTS_GEMM3_STAMPS: cycle stamps of two workgroups (diagnostics)
 };
 
 // load 8 consecutive source elements (guarded) as floats
@@ -589,6 +592,306 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
 }
 
 // =====================================================================================================
+// gemm3: PERSISTENT NT kernel (activations x bf16 shadow weights, both k-contiguous) with an LDS-DMA staging ring.
+// The model's activation GEMMs have short K (96..3072): a one-tile-per-workgroup launch spends most of its life in the
+// fill (first operand round trip), the epilogue (C through LDS, stores) and the drain, with every workgroup of the
+// single resident wave in the same phase at the same time (all load, then all multiply, then all store).  Here a
+// workgroup owns a LIST of output tiles and runs ONE flattened stream of k-tiles over them:
+//   * operand tiles go L2/HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass) into a ring of S
+//     stages; S-1 k-tiles stay in flight across the ONE raw s_barrier of a k-step (counted s_waitcnt vmcnt(N)), and the
+//     prefetch runs ACROSS tile boundaries, so the next tile's first operands land while this tile's epilogue runs;
+//   * the epilogue stages C through the ring stage that was consumed last (32 rows at a time), its global stores are
+//     fire-and-forget, and the 2-3 workgroups that share a CU drift out of phase, so stores, loads and MFMAs overlap;
+//   * tiles are dealt so that an XCD works on a contiguous range of tiles (shared A/B panels stay in its L2).
+// The LDS image is lane-linear per wave-instruction (8 rows x 128 B); ds_read_b128 bank conflicts are removed by an
+// XOR swizzle applied to the per-lane SOURCE address and, identically, to the fragment read: chunk slot s of row r
+// holds k-chunk s ^ ((r >> 1) & 7), which puts the 16 rows a 16-lane group reads on 16 distinct 16-byte slots.
+// Preconditions (host-checked): bf16 A and B, 16-byte aligned rows, K % 16 == 0, split_k == 1, gridDim.x % 8 == 0.
+// =====================================================================================================
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it leaves LDS-DMA loads in flight
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 4 consecutive elements -> 4 floats
+__device__ __forceinline__ f32x4 ld4_as_f32(const void* p, int dt, int64_t i) {
+  if (dt == CSTS_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i);
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + i);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+// Store a lane's four 4-column runs o[q] (columns c0 + 8 q .. + 3 of one row; c0 already includes this half-wave's
+// +4 * hi) at element offset `at` (= row * ld + c0).  fp32: one 16-byte store per run.  bf16: lanes l and l + 32 hold
+// adjacent runs of the same row, so v_permlane32_swap pairs them into 8 contiguous columns per lane -> one 16-byte
+// store per two runs (lower half-wave: columns 16 p .. + 7, upper: 16 p + 8 .. + 15, relative to the unit's first column).
+// Must be called with all lanes active (the swap is a cross-lane exchange); `rowok` / N only mask the stores.
+__device__ __forceinline__ void st4x4(void* base, int dt, int64_t at, const f32x4 (&o)[4], bool rowok, int64_t c0, int64_t N, int hi) {
+  if (dt == CSTS_F32) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (rowok && c0 + 8 * q < N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + at + 8 * q) = o[q];
+  } else {
+    uint2 pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16x4 b = {(bf16)o[q][0], (bf16)o[q][1], (bf16)o[q][2], (bf16)o[q][3]};
+      pk[q] = __builtin_bit_cast(uint2, b);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      uint2 a = pk[2 * pr], b = pk[2 * pr + 1];
+      const auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+      const auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+      a.x = rx[0]; b.x = rx[1]; a.y = ry[0]; b.y = ry[1];
+      // lower half-wave now holds columns 16 pr .. 16 pr + 7 of the unit, the upper half-wave 16 pr + 8 .. 16 pr + 15
+      const int64_t cfirst = c0 - 4 * hi + 16 * pr + 8 * hi;
+      if (rowok && cfirst < N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(base) + at - 4 * hi + 16 * pr + 8 * hi) = make_uint4(a.x, a.y, b.x, b.y);
+    }
+  }
+}
+
+#ifdef CSTS_GEMM3_STAMPS
+#define G3_STAMP() do { if (stamp_on && nstamp < 500) stamp_buf[nstamp++] = (unsigned long long)clock64(); } while (0)
+#else
+#define G3_STAMP() do { } while (0)
+#endif
+
+template <int MT, int S>
+__global__ __launch_bounds__(256, (MT == 4) ? 1 : (MT == 2 ? 2 : 3)) void gemm3_kernel(Params p) {
+#ifdef CSTS_GEMM3_STAMPS
+  const bool stamp_on = p.stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 137);
+  unsigned long long* stamp_buf = p.stamps + (blockIdx.x == 0 ? 0 : 512);
+  int nstamp = 1;
+#endif
+  constexpr int BM3 = 64 * MT;                       // tile rows; waves 2 x 2, each (32*MT) x 64
+  constexpr int A_BYTES = BM3 * 128, B_BYTES = 128 * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int NA = BM3 / 32, NB = 4, LPT = NA + NB;   // LDS-DMA instructions per thread per k-tile
+  static_assert(32 * CS_LD * 4 <= STAGE_BYTES, "C staging (32 rows) must fit one ring stage");
+  __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (int)((p.K + BK2 - 1) / BK2), nk_full = (int)(p.K / BK2), k_tail = (int)((p.K % BK2) >> 4);
+
+  // this workgroup's tiles: XCD x (= blockIdx.x % 8: workgroups are dealt round-robin over the XCDs) owns a contiguous
+  // range of tiles; its workgroups walk the range with stride = workgroups on the XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  const int64_t tq = p.ntiles >> 3, tr = p.ntiles & 7;
+  const int64_t t_beg = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq), t_end = t_beg + tq + (xcd < tr ? 1 : 0);
+  const int64_t t_first = t_beg + slot;
+  const int my_tiles = t_first < t_end ? (int)((t_end - t_first + stride - 1) / stride) : 0;
+  const int total_k = my_tiles * nk;
+
+  // ---- producer side: per-lane source rows of the pieces this wave stages (8 rows x 128 B per wave-instruction)
+  const bf16* asrc[NA];
+  const bf16* bsrc[NB];
+  int ach[NA], bch[NB];                              // swizzled k-chunk (x8 elements) this lane fetches
+#pragma unroll
+  for (int i = 0; i < NA; ++i) ach[i] = ((lane & 7) ^ ((((wave * NA + i) * 8 + (lane >> 3)) >> 1) & 7)) * 8;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) bch[i] = ((lane & 7) ^ ((((wave * NB + i) * 8 + (lane >> 3)) >> 1) & 7)) * 8;
+  auto set_tile = [&](int64_t t) {
+    const int64_t m0 = (t / p.ntiles_n) * BM3, n0 = (t % p.ntiles_n) * 128;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      asrc[i] = reinterpret_cast<const bf16*>(p.A) + min(m0 + (wave * NA + i) * 8 + (lane >> 3), p.M - 1) * p.lda;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      bsrc[i] = reinterpret_cast<const bf16*>(p.B) + min(n0 + (wave * NB + i) * 8 + (lane >> 3), p.N - 1) * p.ldb;
+  };
+  int64_t pt = t_first;                              // producer position: tile, k-tile inside it, flattened index
+  int pk = 0, pidx = 0, pstage = 0;
+  auto produce = [&]() {
+    if (pidx >= total_k) return;
+    char* st = smem_raw + pstage * STAGE_BYTES;
+    const int64_t k0 = (int64_t)pk * BK2;
+    const bool full = k0 + BK2 <= p.K;               // wave-uniform; chunks past K are fetched from chunk 0 (never used)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int64_t k = (full || k0 + ach[i] < p.K) ? k0 + ach[i] : k0;
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k), (lptr_t)(st + (wave * NA + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int64_t k = (full || k0 + bch[i] < p.K) ? k0 + bch[i] : k0;
+      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + k), (lptr_t)(st + A_BYTES + (wave * NB + i) * 1024), 16, 0, 0);
+    }
+    ++pidx;
+    pstage = (pstage + 1 == S) ? 0 : pstage + 1;
+    if (++pk == nk) {
+      pk = 0;
+      pt += stride;
+      if (pidx < total_k) set_tile(pt);
+    }
+  };
+  G3_STAMP();
+  if (my_tiles > 0) set_tile(pt);
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) produce();
+  G3_STAMP();
+
+  // ---- consumer side.  Fragment row = obase + (lane & 31) with obase % 32 == 0: the swizzle key is a per-lane constant
+  const int key = (lane >> 1) & 7, hi = lane >> 5;
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = (lane & 31) * 128 + (((ks * 2 + hi) ^ key) << 4);
+  int cidx = 0, cstage = 0;
+
+  for (int64_t t = t_first; t < t_end; t += stride) {
+    // The MFMA operands are SWAPPED (weights as the row operand): acc[mi][ni][r] is C[m][n] with m = the lane's row
+    // (lane & 31) of 32-row unit mi and n = 32 * ni + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3) -- every lane owns runs of
+    // 4 consecutive columns of ONE output row, so the epilogue needs no LDS transpose and no barrier.
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int64_t m0 = (t / p.ntiles_n) * BM3 + wm * 32 * MT + (lane & 31), n0 = (t % p.ntiles_n) * 128 + wn * 64 + 4 * hi;
+    f32x4 bias4[2][4];                               // loaded ahead of the k-loop: its wait is long over by the epilogue
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t c = n0 + ni * 32 + 8 * q;
+        bias4[ni][q] = (p.bias != nullptr && c < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+
+    // one k-step: wait for k-tile cidx, barrier, then NKS 16-deep sub-steps; the LDS-DMA instructions that refill the
+    // stage consumed one step ago are spread over the sub-steps so that their issue runs under the MFMAs
+    auto kstep = [&](auto nks_tag) {
+      constexpr int NKS = decltype(nks_tag)::value;
+      // k-tile cidx has landed once at most `ahead` younger k-tiles (LPT instructions each) are outstanding; epilogue
+      // stores issued meanwhile are younger still, so the count only ever over-waits
+      const int ahead = min(S - 2, total_k - 1 - cidx);
+      if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
+      else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
+      else wait_vm<0>();
+      G3_STAMP();
+      __builtin_amdgcn_s_barrier();                  // every wave's share landed; everyone is done with the previous stage
+      G3_STAMP();
+      const char* As = smem_raw + cstage * STAGE_BYTES;
+      const char* Bs = As + A_BYTES;
+      cstage = (cstage + 1 == S) ? 0 : cstage + 1;
+      ++cidx;
+      const bool refill = pidx < total_k;            // wave-uniform
+      char* st = smem_raw + pstage * STAGE_BYTES;
+      const int64_t k0 = (int64_t)pk * BK2;
+      const bool full = k0 + BK2 <= p.K;             // chunks past K are fetched from chunk 0 (never used)
+      bf16x8 fa[2][MT], fb[2][2];
+      auto frags = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          fa[buf][i] = *reinterpret_cast<const bf16x8*>(As + (wm * 32 * MT + i * 32) * 128 + foff[ks]);
+        fb[buf][0] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64) * 128 + foff[ks]);
+        fb[buf][1] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 64 + 32) * 128 + foff[ks]);
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) frags(ks + 1, (ks + 1) & 1);
+        if (refill) {
+#pragma unroll
+          for (int i = 0; i < LPT; ++i) {
+            const bool mine = (NKS == 4) ? (i * 4 / LPT == ks) : (ks == 0);
+            if (!mine) continue;
+            if (i < NA) {
+              const int64_t k = (full || k0 + ach[i] < p.K) ? k0 + ach[i] : k0;
+              __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k), (lptr_t)(st + (wave * NA + i) * 1024), 16, 0, 0);
+            } else {
+              const int b = i - NA;
+              const int64_t k = (full || k0 + bch[b] < p.K) ? k0 + bch[b] : k0;
+              __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[b] + k), (lptr_t)(st + A_BYTES + (wave * NB + b) * 1024), 16, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][0], fa[ks & 1][i], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][1], fa[ks & 1][i], acc[i][1], 0, 0, 0);
+        }
+      }
+      if (refill) {                                  // advance the producer
+        ++pidx;
+        pstage = (pstage + 1 == S) ? 0 : pstage + 1;
+        if (++pk == nk) {
+          pk = 0;
+          pt += stride;
+          if (pidx < total_k) set_tile(pt);
+        }
+      }
+      G3_STAMP();
+    };
+    for (int kt = 0; kt < nk_full; ++kt) kstep(std::integral_constant<int, 4>());
+    if (k_tail == 1) kstep(std::integral_constant<int, 1>());        // K % 64 = 16, 32 or 48 (K % 16 == 0)
+    else if (k_tail == 2) kstep(std::integral_constant<int, 2>());
+    else if (k_tail == 3) kstep(std::integral_constant<int, 3>());
+
+    // ---------------- epilogue straight from the accumulators (same arithmetic order as gemm2_kernel)
+    G3_STAMP();
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int64_t m = m0 + mi * 32;
+      const bool mok = m < p.M;
+      float rsc = 1.f;
+      if (p.row_scale != nullptr && mok) rsc = p.row_scale[m / p.rows_per_scale];
+      const int64_t rm = (p.residual != nullptr && p.res_row_mod > 0) ? (m % p.res_row_mod) : m;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        f32x4 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t c = n0 + ni * 32 + 8 * q;
+          const bool ok = mok && c < p.N;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][4 * q + j] + bias4[ni][q][j];
+          if (p.epilogue == CSTS_EPI_DGELU) {
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+            if (ok) h = ld4_as_f32(p.aux, p.aux_dt, m * p.ldaux + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= (p.aux_dt == CSTS_BF16) ? dgelu_fast(h[j]) : dgelu_f(h[j]);
+          }
+          o[q] = v;
+        }
+        if (p.epilogue == CSTS_EPI_GELU) {
+          if (p.aux != nullptr) st4x4(p.aux, p.aux_dt, m * p.ldaux + n0 + ni * 32, o, mok, n0 + ni * 32, p.N, hi);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[q][j] = (p.aux_dt == CSTS_BF16) ? gelu_fast(o[q][j]) : gelu_f(o[q][j]);
+        }
+        if (p.row_scale != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] *= rsc;
+        }
+        if (p.residual != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t c = n0 + ni * 32 + 8 * q;
+            if (mok && c < p.N) o[q] += ld4_as_f32(p.residual, p.r_dt, rm * p.ldr + c);
+          }
+        }
+        st4x4(p.C, p.c_dt, m * p.ldc + n0 + ni * 32, o, mok, n0 + ni * 32, p.N, hi);
+      }
+    }
+    G3_STAMP();
+  }
+  wait_vm<0>();
+  G3_STAMP();
+#ifdef CSTS_GEMM3_STAMPS
+  if (stamp_on) stamp_buf[0] = (unsigned long long)nstamp;
+#endif
+}
+
+// =====================================================================================================
 // Grouped weight gradients: MANY independent dW = dY^T X problems (every Linear of the model) in ONE launch.
 // A lone weight gradient of this model has 9..36 output tiles and a reduction over 2 k..262 k tokens, so by itself it
 // needs a deep split-K (slabs + finishing pass) just to occupy the chip.  Queued up for a whole backward pass there are
@@ -757,6 +1060,44 @@ int pick_tile_rows(const csts_gemm_args* a, int64_t per) {
   return mt;
 }
 
+// gemm3 (LDS-DMA ring, NT bf16 x bf16): usable when every 16-byte chunk is whole and K has only whole MFMA sub-steps
+bool v3_ok(const csts_gemm_args* a, int split) {
+  return v2_ok(a) && a->layout == CSTS_GEMM_NT && a->a_dt == CSTS_BF16 && a->b_dt == CSTS_BF16 && a->K % 16 == 0 &&
+         split == 1 && a->colsum == nullptr;
+}
+// Library heuristic for the persistent LDS-DMA kernel (64-row tiles, 3-stage ring, 2 workgroups per CU).
+bool pick3(const csts_gemm_args* a, int split, int* mt, int* stages) {
+  if (a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->M < 256) return false;
+  // Measured inside the train step (profiles/r1_v7_gemm_shapes.txt vs r1_v6): the ring wins where a workgroup's k-loop is
+  // long and the grid is small (< 2 128-row tiles per CU, K >= 768: fc2 / qkv of the 384- and 768-channel stages,
+  // 20-40 % faster); on the large-M short-K shapes the register-staged kernel at 3-4 workgroups per CU stays ahead.
+  if (cdiv(a->M, 128) * cdiv(a->N, BN) >= 512 || a->K < 768) return false;
+  *mt = 1;
+  *stages = 3;
+  return true;
+}
+
+template <int MT>
+void launch3_mt(const Params& p, int stages, dim3 grid, hipStream_t s) {
+  if (stages == 2) hipLaunchKernelGGL((gemm3_kernel<MT, 2>), grid, dim3(256), 0, s, p);
+  else if (stages == 4 && MT < 4) hipLaunchKernelGGL((gemm3_kernel<MT, (MT < 4 ? 4 : 3)>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm3_kernel<MT, 3>), grid, dim3(256), 0, s, p);
+}
+// persistent launch: min(tiles, 256 CUs x workgroups that fit a CU's 160 KiB of LDS) workgroups, a multiple of 8
+void launch3(Params p, const csts_gemm_args* a, int mt, int stages, int wpc, hipStream_t s) {
+  const int64_t ntiles = cdiv(a->M, 64 * mt) * p.ntiles_n;
+  p.ntiles = ntiles;
+  p.stamps = (a->split_k <= 1 && a->workspace != nullptr && a->ws_bytes >= 8192) ? reinterpret_cast<unsigned long long*>(a->workspace) : nullptr;
+  const int stage_bytes = (64 * mt + 128) * 128;
+  const int fit = std::max(1, (160 * 1024) / (stages * stage_bytes));
+  if (wpc <= 0 || wpc > fit) wpc = fit;
+  int64_t g = std::min<int64_t>(cdiv(ntiles, 8) * 8, (int64_t)256 * wpc);
+  dim3 grid((unsigned)g, 1, 1);
+  if (mt == 1) launch3_mt<1>(p, stages, grid, s);
+  else if (mt == 2) launch3_mt<2>(p, stages, grid, s);
+  else launch3_mt<4>(p, stages, grid, s);
+}
+
 template <bool A_KC, bool B_KC>
 void launch(const Params& p, int compute, dim3 grid, hipStream_t s) {
   if (compute == CSTS_F32) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true>), grid, dim3(NT_), 0, s, p);
@@ -811,6 +1152,22 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   p.ntiles_n = (int)cdiv(a->N, BN);
   int64_t mtiles = cdiv(a->M, BM);
   CSTS_REQUIRE(mtiles * p.ntiles_n < (int64_t)1 << 31, "grid too large");
+  if (a->algo % 1000 >= 300 && a->algo % 1000 < 400) {   // forced: 1000 * workgroups-per-CU (0 = as many as LDS allows) + 300 + 10 * (tile_rows / 64) + stages
+    CSTS_REQUIRE(v3_ok(a, split), "algo 3xx (persistent LDS-DMA NT kernel) not applicable to this problem");
+    const int code = a->algo % 1000 - 300, mt = code / 10, st = code % 10;
+    CSTS_REQUIRE((mt == 1 || mt == 2 || mt == 4) && st >= 2 && st <= 4 && !(mt == 4 && st == 4), "bad algo 3xx code");
+    launch3(p, a, mt, st, a->algo / 1000, stream);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
+  {
+    int mt3, st3;
+    if (pick3(a, split, &mt3, &st3)) {
+      launch3(p, a, mt3, st3, 0, stream);
+      CSTS_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (use_v2) {
     int mt = pick_tile_rows(a, p.ntiles_n * nsplit);
     mtiles = cdiv(a->M, mt);
@@ -852,7 +1209,8 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
 extern "C" int csts_gemm_v2_eligible(const csts_gemm_args* a) { return a != nullptr && v2_ok(a) ? 1 : 0; }
 
 // Which kernel csts_gemm would launch for these arguments (host-only; used by bench.py to name the kernel a timed call
-// ran, exactly as rocprofv3 prints it): v2 = 1 -> gemm2_kernel<A_KC, B_KC, A_F32, B_F32, tile_rows / 64, 2>, else gemm_kernel.
+// ran, exactly as rocprofv3 prints it): v2 = 1 -> gemm2_kernel<A_KC, B_KC, A_F32, B_F32, tile_rows / 64, 2>; v2 = 30 + stages ->
+// gemm3_kernel<tile_rows / 64, stages>; 0 -> gemm_kernel.
 extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, int* nsplit) {
   CSTS_REQUIRE(a != nullptr && v2 && tile_rows && nsplit, "null pointer");
   const int split = a->split_k > 1 ? a->split_k : 1;
@@ -860,6 +1218,13 @@ extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, 
   const int bk = use_v2 ? BK2 : BK;
   const int64_t k_chunk = cdiv(cdiv(a->K, bk), split) * bk;
   const int64_t ns = cdiv(a->K, k_chunk);
+  int mt3, st3;
+  if (pick3(a, split, &mt3, &st3)) {   // gemm3_kernel<tile_rows / 64, stages>
+    *v2 = 30 + st3;
+    *nsplit = 1;
+    *tile_rows = 64 * mt3;
+    return 0;
+  }
   *v2 = use_v2 ? 1 : 0;
   *nsplit = (int)ns;
   *tile_rows = use_v2 ? pick_tile_rows(a, cdiv(a->N, BN) * ns) : BM;

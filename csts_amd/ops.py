@@ -310,7 +310,7 @@ def flush_wgrads():
 # ----------------------------------------------------------------------------------------- raw wrappers
 def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
          residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True, tile_rows=0,
-         want_colsum=False):
+         want_colsum=False, algo=0, debug_ws=None):
     a = L.GemmArgs()
     a.layout = layout
     a.A, a.a_dt, a.lda = _p(A, a_off), _dt(A), lda
@@ -325,7 +325,10 @@ def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bia
     a.row_scale, a.rows_per_scale = _p(row_scale), rows_per_scale
     a.compute, a.split_k = compute, split_k
     a.tile_rows = tile_rows
+    a.algo = algo
     ws = None
+    if debug_ws is not None:   # diagnostics builds only (gemm3 cycle stamps)
+        a.workspace, a.ws_bytes = _p(debug_ws), debug_ws.numel() * debug_ws.element_size()
     if split_k > 1 and deterministic:
         nb = _lib().csts_gemm_splitk_workspace(M, N, K, split_k)
         if nb <= SPLITK_WS_LIMIT:

@@ -58,6 +58,7 @@ typedef struct {
   void* workspace; size_t ws_bytes;   /* optional: makes split_k deterministic (partial slabs + finishing pass) */
   float* colsum;   /* optional, TN + bf16 v2 kernel only: colsum[m] = sum_k A[k,m] (the bias gradient of a Linear) */
   int tile_rows;   /* 0 = library heuristic; 64 / 128 / 256 force the bf16 kernel's row tile (tuning sweeps) */
+  int algo;        /* 0 = library heuristic; 2 = register-staged kernel; 1000 * wg_per_cu + 300 + 10 * (tile_rows / 64) + stages = persistent LDS-DMA NT kernel (tuning sweeps) */
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
 size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);

@@ -80,6 +80,38 @@ def test_gemm_epilogues(compute):
     assert rel_l2(out32, (A.float() @ Wn) * hf.grad) < TOL[compute]
 
 
+@pytest.mark.parametrize("algo", [0, 2, 312, 313, 314, 322, 323, 324, 1322, 342, 343])
+@pytest.mark.parametrize("M,N,K", [(520, 384, 96), (2080, 160, 448), (777, 288, 160), (4096, 1536, 384), (300, 96, 1040),
+                                   (33000, 192, 64)])
+def test_gemm_nt_persistent_kernel(algo, M, N, K):
+    """gemm3 (persistent LDS-DMA NT kernel, every forced tile/stage variant and the library heuristic) against fp32 torch:
+    ragged M, N % 128 != 0, K % 64 in {0, 16, 32}, all epilogues, bf16 and fp32 outputs (reference nn.Linear + GELU +
+    drop-path + residual: attention.py:130,159,238-248; common.py:26-34)."""
+    dt = torch.bfloat16
+    A, W, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.2).to(dt), rnd(N, seed=3)
+    pre = A.float() @ W.float().t() + b
+    out = torch.full((M + 1, N), 7.0, device=DEV, dtype=dt)   # a guard row behind the output
+    aux = torch.full((M + 1, N), 7.0, device=DEV, dtype=dt)
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out, N, M, N, K, compute=L.BF16, bias=b, epilogue=L.EPI_GELU, aux=aux, algo=algo)
+    assert rel_l2(aux[:M].float(), pre) < 6e-3 and rel_l2(out[:M].float(), F.gelu(pre)) < 6e-3
+    assert (out[M] == 7).all() and (aux[M] == 7).all()
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out, N, M, N, K, compute=L.BF16, algo=algo)            # no bias, bf16 out
+    assert rel_l2(out[:M].float(), pre - b) < 6e-3
+    per = (M + 1) // 2
+    res = rnd(per, N, seed=4)
+    rs = torch.tensor([0.0, 1.25], device=DEV)
+    out32 = torch.full((M + 1, N), 7.0, device=DEV)
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out32, N, M, N, K, compute=L.BF16, bias=b, residual=res, ldr=N, res_row_mod=per,
+             row_scale=rs, rows_per_scale=per, algo=algo)
+    ref = pre * rs.repeat_interleave(per)[:M, None] + res.repeat(2, 1)[:M]
+    assert rel_l2(out32[:M], ref) < 1e-4 and (out32[M] == 7).all()
+    h = rnd(M, N, seed=7).to(dt)                                                                    # DGELU, fp32 out
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out32, N, M, N, K, compute=L.BF16, epilogue=L.EPI_DGELU, aux=h, algo=algo)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).sum().backward()
+    assert rel_l2(out32[:M], (pre - b) * hf.grad) < 1e-3
+
+
 @pytest.mark.parametrize("compute", [L.F32, L.BF16])
 def test_linear_and_mlp_autograd(compute):
     dt = tdt(compute)
