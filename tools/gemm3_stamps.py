@@ -1,6 +1,6 @@
 """Cycle stamps of the persistent NT kernel (diagnostics build: gemm.hip compiled with -DCSTS_GEMM3_STAMPS and linked as
-tools/diag/libcsts_hip_stamps.so).  Prints, for two workgroups, the cycles between the stamp points of every k-step:
-wait (vmcnt) | barrier | issue of the next LDS-DMA tile | fragment reads + MFMAs; and the epilogue.
+tools/diag/libcsts_hip_stamps.so by `make -C csts_amd/csrc stamps`).  Prints, for two workgroups, the cycles between the stamp points of every k-step:
+wait (vmcnt) | barrier | fragment reads + MFMAs with the interleaved LDS-DMA refill; and the epilogue.
 usage: gemm3_stamps.py M N K algo"""
 import os, sys
 import torch
@@ -25,14 +25,14 @@ for w in range(2):
     print(f"workgroup {w}: {n - 1} stamps, total {t[-1] - t[0]} cycles; prologue issue {t[1] - t[0]}")
     i = 2
     tile = 0
-    while i + 4 * nk + 2 <= len(t):
+    while i + 3 * nk + 2 <= len(t):
         rows = []
         for kt in range(nk):
-            a, b, c, d = t[i:i + 4]
+            a, b, c = t[i:i + 3]
             prev = t[i - 1]
-            rows.append((a - prev, b - a, c - b, d - c))
-            i += 4
+            rows.append((a - prev, b - a, c - b))
+            i += 3
         epi0, epi1 = t[i], t[i + 1]
         i += 2
-        print(f"  tile {tile}: k-steps (wait,barrier,issue,mfma): " + " ".join(f"{r[0]}/{r[1]}/{r[2]}/{r[3]}" for r in rows) + f" | epilogue {epi1 - epi0}")
+        print(f"  tile {tile}: k-steps (wait,barrier,mfma+refill): " + " ".join(f"{r[0]}/{r[1]}/{r[2]}" for r in rows) + f" | epilogue {epi1 - epi0}")
         tile += 1
