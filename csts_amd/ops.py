@@ -308,9 +308,26 @@ def flush_wgrads():
 
 
 # ----------------------------------------------------------------------------------------- raw wrappers
+AUTO_SPLIT_SMALL_M = True
+
+
+def _auto_split(layout, M, N, K, compute):
+    """Deterministic split-K for activation GEMMs with a handful of rows (embedding projections and similarity matrices
+    of the EgoNCE loss: M = batch; the temporal-fusion block: M = B*2T'): one or two row tiles leave 1..24 workgroups
+    walking the whole K serially (55-100 us per call measured); slabs + the finishing pass spread K over the chip."""
+    if layout == L.GEMM_TN or M > 128:
+        return 1
+    ksteps = -(-K // (64 if compute == BF16 else 32))
+    tiles = -(-M // 64) * -(-N // 128)
+    split = min(ksteps // (4 if compute == BF16 else 2), -(-192 // tiles))
+    return split if split >= 2 else 1
+
+
 def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
          residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True, tile_rows=0,
          want_colsum=False, algo=0, debug_ws=None):
+    if split_k == 1 and AUTO_SPLIT_SMALL_M and not want_colsum and algo == 0 and tile_rows == 0:
+        split_k = _auto_split(layout, M, N, K, compute)
     a = L.GemmArgs()
     a.layout = layout
     a.A, a.a_dt, a.lda = _p(A, a_off), _dt(A), lda
