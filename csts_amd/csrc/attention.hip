@@ -555,6 +555,157 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- dQ, dK, dV in ONE pass
+// Short key sequences (N_k <= 128: the decoder blocks, whose K/V are pooled down to 128 tokens while the queries are the
+// 32 k .. 64 k upsampled tokens).  The two-kernel form streams Q and dO from HBM twice (once per kernel) for a handful
+// of MFMAs per byte; here K and V live in LDS for the whole workgroup, every 128-query tile of Q / dO is staged ONCE and
+// used for both products:
+//   part A (= attn_dkv_kernel's body): wave w owns keys 32 w .. 32 w + 31 as row fragments and walks the tile's four
+//           32-query units: S, dP with the queries in the accumulator registers -> dV += P^T dO, dK += dS^T Q;
+//   part B (= attn_dq_kernel's body):  wave w owns queries 32 w .. 32 w + 31 of the tile as row fragments (read back
+//           from the staged tile) and walks the four 32-key units of K / V in LDS -> dQ = dS K, staged out through the
+//           Q tile's LDS buffer as coalesced 16-byte stores.  The O tile is staged beside dO, so delta = rowsum(dO * O)
+//           is a dot product of two row fragments here (no separate delta launch, no second read of dO); LSE and
+//           delta of the tile sit in LDS for part A.
+// S / dP are computed in both orientations (MFMA time is free here: the kernel is bound by the Q / dO / dQ streams).
+// dK / dV partials of the query splits go to the same workspace layout attn_dkv_reduce_kernel sums.  bf16, no mask.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
+  typedef Cfg<HD, false> C;
+  constexpr int LD = C::LD_ROW, TILE = 128 * LD;
+  __shared__ __attribute__((aligned(16))) bf16 smem[5 * TILE + 512];
+  bf16* Ks = smem;
+  bf16* Vs = smem + TILE;
+  bf16* Qs = smem + 2 * TILE;
+  bf16* dOs = smem + 3 * TILE;
+  bf16* Os = smem + 4 * TILE;
+  float* Ls = reinterpret_cast<float*>(smem + 5 * TILE);   // LSE and delta of the tile's 128 queries
+  float* Ds = Ls + 128;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.y / p.H, head = blockIdx.y % p.H;
+  const int split = blockIdx.x;
+  const int qbeg = split * p.q_chunk, qend = min(p.Nq, qbeg + p.q_chunk);
+  const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs, vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+  const int64_t qbase = (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, dobase = (int64_t)b * p.do_bs + (int64_t)head * p.do_hs;
+  const int64_t obase = (int64_t)b * p.o_bs + (int64_t)head * p.o_hs;
+  load_tile<HD, 128, LD, false>(Ks, p.K, kbase, p.k_ts, 0, p.Nk, tid);      // rows >= Nk are zero
+  load_tile<HD, 128, LD, false>(Vs, p.V, vbase, p.v_ts, 0, p.Nk, tid);
+
+  const int kraw = w * 32 + (lane & 31);
+  const bool kvalid = kraw < p.Nk;
+  const int ki = kvalid ? kraw : p.Nk - 1;
+  RowFrag<HD, false> kf, vf;
+  kf.load(p.K, kbase + (int64_t)ki * p.k_ts, h);
+  vf.load(p.V, vbase + (int64_t)ki * p.v_ts, h);
+  f32x16 dK[HD / 32], dV[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dK[d][r] = 0.f; dV[d][r] = 0.f; }
+  const float* Lrow = p.LSE + ((int64_t)b * p.H + head) * p.Nq;
+
+  TileStage<HD, 128> sq, sdo, so;
+  float lnext = 0.f;
+  sq.gload(p.Q, qbase, p.q_ts, qbeg, qend, tid);
+  sdo.gload(p.dO, dobase, p.do_ts, qbeg, qend, tid);
+  so.gload(p.O, obase, p.o_ts, qbeg, qend, tid);
+  if (tid < 128) lnext = Lrow[min(qbeg + tid, qend - 1)];
+  for (int q0 = qbeg; q0 < qend; q0 += 128) {
+    __syncthreads();                       // the previous tile's dQ has left the Q buffer; everyone is done with dO / stats
+    sq.lstore(Qs, LD, tid);
+    sdo.lstore(dOs, LD, tid);
+    so.lstore(Os, LD, tid);
+    if (tid < 128) Ls[tid] = lnext;
+    if (q0 + 128 < qend) {                 // the next tile's HBM round trip runs under this tile's MFMAs
+      sq.gload(p.Q, qbase, p.q_ts, q0 + 128, qend, tid);
+      sdo.gload(p.dO, dobase, p.do_ts, q0 + 128, qend, tid);
+      so.gload(p.O, obase, p.o_ts, q0 + 128, qend, tid);
+      if (tid < 128) lnext = Lrow[min(q0 + 128 + tid, qend - 1)];
+    }
+    __syncthreads();
+    // ---- part B: this wave's 32 queries (row fragments) against all keys -> dQ; delta = rowsum(dO * O) on the way
+    f32x16 acc[HD / 32];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    {
+      const int qrow = w * 32 + (lane & 31);
+      RowFrag<HD, false> qf, dof;
+      frag_from_lds<HD>(qf, Qs, qrow, h);
+      frag_from_lds<HD>(dof, dOs, qrow, h);
+      float dl = 0.f;
+      {
+        RowFrag<HD, false> of;
+        frag_from_lds<HD>(of, Os, qrow, h);
+#pragma unroll
+        for (int s2 = 0; s2 < HD / 16; ++s2)
+#pragma unroll
+          for (int j2 = 0; j2 < 8; ++j2) dl += (float)dof.b[s2][j2] * (float)of.b[s2][j2];
+      }
+      dl += __shfl_xor(dl, 32, 64);          // the two half-waves hold the two halves of every 16-wide chunk of the row
+      if (h == 0) Ds[qrow] = dl;
+      const float negL = -Ls[qrow];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        if (kt * 32 >= p.Nk) break;          // wave-uniform
+        f32x16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+        score<HD, LD, false>(S, Ks + kt * 32 * LD, qf, lane);
+        score<HD, LD, false>(dP, Vs + kt * 32 * LD, dof, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], p.scale_log2, negL));
+          const float pr = (kt * 32 + rowoff(r, h) >= p.Nk) ? 0.f : e;
+          S[r] = pr * (dP[r] - dl);
+        }
+        pv<HD, LD, false>(acc, Ks + kt * 32 * LD, S, lane);
+      }
+    }
+    __syncthreads();                       // every wave's delta is in LDS
+    // ---- part A: this wave's 32 keys (row fragments) against the tile's 128 queries -> dK, dV
+    const bool ragged = q0 + 128 > qend;   // wave-uniform
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x16 S, dP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+      score<HD, LD, false>(S, Qs + qt * 32 * LD, kf, lane);
+      score<HD, LD, false>(dP, dOs + qt * 32 * LD, vf, lane);
+      // the 4 registers of a quad are 4 consecutive queries: one 16-byte LDS read of LSE / delta each
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qo = qt * 32 + 8 * j + 4 * h;
+        const float4 L4 = *reinterpret_cast<const float4*>(Ls + qo), D4 = *reinterpret_cast<const float4*>(Ds + qo);
+        const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * j + i], p.scale_log2, -l[i]));
+          const float pr = (ragged && q0 + qo + i >= qend) ? 0.f : e;
+          S[4 * j + i] = pr;
+          dP[4 * j + i] = pr * (dP[4 * j + i] - dd[i]);
+        }
+      }
+      pv<HD, LD, false>(dV, dOs + qt * 32 * LD, S, lane);
+      pv<HD, LD, false>(dK, Qs + qt * 32 * LD, dP, lane);
+    }
+    __syncthreads();                       // every wave is done with the Q tile: it becomes the dQ staging buffer
+    stage_rows_out<HD>(Qs, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, q0, qend, acc, p.scale,
+                       w * 32 + (lane & 31), h, tid);
+  }
+  if (!kvalid) return;
+  if (p.nsplit == 1) {
+    store_rows<HD>(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)ki * p.dk_ts + (int64_t)head * p.dk_hs, dK, p.scale, h);
+    store_rows<HD>(p.dV, p.dt, (int64_t)b * p.dv_bs + (int64_t)ki * p.dv_ts + (int64_t)head * p.dv_hs, dV, 1.f, h);
+  } else {
+    const int64_t per = (int64_t)p.B * p.H * p.Nk * HD;
+    const int64_t off = (((int64_t)split * p.B + b) * p.H + head) * (int64_t)p.Nk * HD + (int64_t)ki * HD;
+    store_rows<HD>(p.ws, CSTS_F32, off, dK, p.scale, h);
+    store_rows<HD>(p.ws, CSTS_F32, (int64_t)p.nsplit * per + off, dV, 1.f, h);
+  }
+}
+
 // second pass: dK/dV[b, k, head, :] = sum_split ws[...]
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnP p, int HD) {
   const int64_t per = (int64_t)p.B * p.H * p.Nk * HD;
@@ -655,7 +806,18 @@ bool strides_ok(const int64_t* s, int dt) {
   return s[0] % a == 0 && s[1] % a == 0 && s[2] % a == 0;
 }
 
+// one-pass backward (attn_bwd_fused_kernel): bf16, head_dim 96, all keys in one LDS tile, no mask, enough queries to split
+bool fused_bwd_ok(const csts_attn_args* a) {
+  return a->dtype == CSTS_BF16 && a->head_dim == 96 && a->Nk <= 128 && a->mask_mode == 0 && a->Nq >= 1024;
+}
+
 void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
+  if (fused_bwd_ok(a)) {      // one workgroup per CU (its LDS holds K, V and the Q / dO tile): aim at two rounds of the chip
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(512 / ((int64_t)a->B * a->H), cdiv(a->Nq, 256)));
+    q_chunk = (int)(cdiv(cdiv(a->Nq, want), 128) * 128);
+    nsplit = (int)cdiv(a->Nq, q_chunk);
+    return;
+  }
   const int qblk = a->head_dim == 96 ? 64 : 32;
   const int64_t base = cdiv(a->Nk, 128) * a->B * a->H;
   int64_t want = std::max<int64_t>(1, 512 / base);
@@ -730,6 +892,22 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
                    strides_ok(a->dk_strides, a->dtype) && strides_ok(a->dv_strides, a->dtype) &&
                    strides_ok(a->o_strides, a->dtype), "strides must keep 16-byte row alignment");
   AttnP p; fill(a, p);
+  if (fused_bwd_ok(a)) {   // delta, dQ, dK, dV in one pass over Q / dO / O
+    dkv_plan(a, p.nsplit, p.q_chunk);
+    if (p.nsplit > 1) {
+      CSTS_REQUIRE(workspace != nullptr && ws_bytes >= csts_attn_bwd_workspace(a), "workspace too small");
+      p.ws = reinterpret_cast<float*>(workspace);
+    }
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<96>), dim3((unsigned)p.nsplit, (unsigned)(a->B * a->H)), dim3(256), 0, stream, p);
+    CSTS_LAUNCH_CHECK();
+    if (p.nsplit > 1) {
+      const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim;
+      hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
+                         stream, p, a->head_dim);
+      CSTS_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   // 1. delta = rowsum(dO * O)
   {
     const int64_t rows = (int64_t)a->B * a->H * a->Nq;

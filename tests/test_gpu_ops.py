@@ -247,6 +247,50 @@ def test_attention_spatial_mask_and_probs(compute):
     assert rel_l2(probs, attn) < (1e-4 if compute == L.F32 else 3e-2)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 2, 1024, 128), (1, 2, 1500, 100), (1, 1, 4000, 32), (2, 1, 2304, 128), (1, 4, 1100, 8)])
+def test_attention_backward_one_pass_short_kv(B, H, Nq, Nk):
+    """csts_attn_bwd with N_k <= 128, head_dim 96, bf16 takes the one-pass kernel (dQ, dK, dV from one sweep over Q / dO;
+    decoder blocks, attention.py:365-392): ragged query tiles, ragged / tiny key counts, q read in place inside a qkv
+    buffer (token stride 3C), several query splits -> against fp32 torch autograd of softmax(q k^T / sqrt(hd)) v."""
+    import ctypes as C
+    hd = 96
+    Cc = H * hd
+    qkv = rnd(B, Nq, 3 * Cc, seed=1).to(torch.bfloat16)
+    k, v = rnd(B, Nk, Cc, seed=2).to(torch.bfloat16), rnd(B, Nk, Cc, seed=3).to(torch.bfloat16)
+    do = rnd(B, Nq, Cc, seed=4).to(torch.bfloat16)
+    o = torch.empty(B, Nq, Cc, device=DEV, dtype=torch.bfloat16)
+    lse, delta = torch.empty(B, H, Nq, device=DEV), torch.empty(B, H, Nq, device=DEV)
+    dqkv = torch.full((B, Nq + 1, 3 * Cc), 7.0, device=DEV, dtype=torch.bfloat16)     # dq written in place, guard row behind
+    dk, dv = torch.empty_like(k), torch.empty_like(v)
+    a = L.AttnArgs()
+    a.Q, a.K, a.V, a.O, a.LSE = qkv.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    a.dO, a.delta, a.dQ, a.dK, a.dV = do.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.dtype, a.B, a.H, a.Nq, a.Nk, a.head_dim = L.BF16, B, H, Nq, Nk, hd
+    a.q_strides = (C.c_int64 * 3)(Nq * 3 * Cc, 3 * Cc, hd)
+    a.dq_strides = (C.c_int64 * 3)((Nq + 1) * 3 * Cc, 3 * Cc, hd)
+    so, sk = (C.c_int64 * 3)(Nq * Cc, Cc, hd), (C.c_int64 * 3)(Nk * Cc, Cc, hd)
+    a.o_strides = so; a.do_strides = so
+    a.k_strides = sk; a.v_strides = sk; a.dk_strides = sk; a.dv_strides = sk
+    a.scale = hd ** -0.5
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.csts_attn_fwd(C.byref(a), st), "fwd")
+    ws = torch.empty(max(16, lib.csts_attn_bwd_workspace(C.byref(a))), dtype=torch.uint8, device=DEV)
+    L.check(lib.csts_attn_bwd(C.byref(a), ws.data_ptr(), ws.numel(), st), "bwd")
+    torch.cuda.synchronize()
+    qf = qkv[:, :, :Cc].float().reshape(B, Nq, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    kf = k.float().reshape(B, Nk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    vf = v.float().reshape(B, Nk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    of = torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf
+    of.backward(do.float().reshape(B, Nq, H, hd).transpose(1, 2))
+    back = lambda t, n: t.transpose(1, 2).reshape(B, n, Cc)
+    assert rel_l2(o.float(), back(of, Nq)) < 1e-2
+    assert rel_l2(dqkv[:, :Nq, :Cc].float(), back(qf.grad, Nq)) < 1.5e-2, "dq"
+    assert rel_l2(dk.float(), back(kf.grad, Nk)) < 1.5e-2, "dk"
+    assert rel_l2(dv.float(), back(vf.grad, Nk)) < 1.5e-2, "dv"
+    assert (dqkv[:, Nq] == 7).all() and (dqkv[:, :Nq, Cc:] == 7).all()      # nothing outside the dq slot was touched
+
+
 def test_attention_long_kv_online_softmax():
     """N_kv = 1000 (not a multiple of the 64-key tile), large score range: exercises the online-softmax rescale."""
     B, N, Cc, H = 1, 1000, 96, 1
