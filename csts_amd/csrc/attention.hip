@@ -19,7 +19,7 @@ namespace {
 
 struct AttnP {
   const void* Q; const void* K; const void* V; void* O; float* LSE;
-  const void* dO; const float* delta; void* dQ; void* dK; void* dV; float* ws;
+  const void* dO; float* delta; void* dQ; void* dK; void* dV; float* ws;
   int dt, B, H, Nq, Nk;
   int64_t q_bs, q_ts, q_hs, k_bs, k_ts, k_hs, v_bs, v_ts, v_hs, o_bs, o_ts, o_hs;
   int64_t do_bs, do_ts, do_hs, dq_bs, dq_ts, dq_hs, dk_bs, dk_ts, dk_hs, dv_bs, dv_ts, dv_hs;
@@ -419,7 +419,28 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
     __syncthreads();
   }
   const float L = p.LSE[((int64_t)b * p.H + head) * p.Nq + qi];
-  const float dl = p.delta[((int64_t)b * p.H + head) * p.Nq + qi];
+  // delta = rowsum(dO * O): a dot product of two row fragments of this lane's query (the half-waves hold alternate
+  // pieces of the row); kept for the dK/dV kernel, which runs after this one
+  float dl = 0.f;
+  {
+    RowFrag<HD, F32> of;
+    if constexpr (F32) {
+      of.load(p.O, (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)head * p.o_hs, h);
+#pragma unroll
+      for (int s2 = 0; s2 < HD / 2; ++s2) dl += dof.f[s2] * of.f[s2];
+    } else {
+      stage_rows_in<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+      __syncthreads();
+      frag_from_lds<HD>(of, smem, w * 32 + (lane & 31), h);
+      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < HD / 16; ++s2)
+#pragma unroll
+        for (int j2 = 0; j2 < 8; ++j2) dl += (float)dof.b[s2][j2] * (float)of.b[s2][j2];
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (h == 0 && qvalid) p.delta[((int64_t)b * p.H + head) * p.Nq + qi] = dl;
+  }
   const float negL = -L;
   const int fq = frame_of(p, qi);
   f32x16 acc[HD / 32];
@@ -724,37 +745,6 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnP p, int HD) {
   }
 }
 
-// delta[b,h,q] = sum_d dO * O   (32 lanes per row)
-// delta[b,h,q] = sum_d O * dO : a group of GL lanes per row, 8 elements (one 16-byte load of O and of dO) per lane,
-// HD/8 lanes active; rows are walked token-major (heads innermost) so a wave reads contiguous memory
-template <int GL>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p, int HD) {
-  const int sub = threadIdx.x % GL;
-  const bool active = sub * 8 < HD;
-  const int c8 = min(sub * 8, HD - 8);
-  const int64_t rows = (int64_t)p.B * p.Nq * p.H;
-  const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
-  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) / GL;
-  for (int64_t row = row0; row < rows; row += stride) {
-    const int head = (int)(row % p.H);
-    const int64_t bq = row / p.H;
-    const int q = (int)(bq % p.Nq), b = (int)(bq / p.Nq);
-    const int64_t oo = (int64_t)b * p.o_bs + (int64_t)q * p.o_ts + (int64_t)head * p.o_hs + c8;
-    const int64_t od = (int64_t)b * p.do_bs + (int64_t)q * p.do_ts + (int64_t)head * p.do_hs + c8;
-    float o8[8], d8[8];
-    ld8_as_f32(p.O, p.dt, oo, o8);
-    ld8_as_f32(p.dO, p.dt, od, d8);
-    float s = 0.f;
-    if (active) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += o8[j] * d8[j];
-    }
-#pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (sub == 0) const_cast<float*>(p.delta)[((int64_t)b * p.H + head) * p.Nq + q] = s;
-  }
-}
-
 __global__ __launch_bounds__(256) void attn_probs_kernel(AttnP p, int HD, float* probs) {
   const int64_t total = (int64_t)p.B * p.H * p.Nq * p.Nk;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -908,18 +898,7 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
     }
     return 0;
   }
-  // 1. delta = rowsum(dO * O)
-  {
-    const int64_t rows = (int64_t)a->B * a->H * a->Nq;
-    if (a->head_dim <= 128)
-      hipLaunchKernelGGL(attn_delta_kernel<16>, dim3((unsigned)std::min<int64_t>(cdiv(rows * 16, 256), 8192)), dim3(256), 0,
-                         stream, p, a->head_dim);
-    else
-      hipLaunchKernelGGL(attn_delta_kernel<32>, dim3((unsigned)std::min<int64_t>(cdiv(rows * 32, 256), 8192)), dim3(256), 0,
-                         stream, p, a->head_dim);
-    CSTS_LAUNCH_CHECK();
-  }
-  // 2. dQ
+  // 1 + 2. delta = rowsum(dO * O) and dQ (the dQ kernel computes delta from its staged O rows and leaves it for step 3)
   {
     dim3 grid((unsigned)cdiv(a->Nq, 128), a->H, a->B);
     attn_dispatch(K_DQ, a, p, grid, stream);
