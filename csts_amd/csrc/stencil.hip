@@ -125,81 +125,6 @@ template <bool F32> __device__ __forceinline__ void* bptr(void* p, int64_t off) 
   else return reinterpret_cast<bf16*>(p) + off;
 }
 
-// weights staged as wl[28][HD] fp32: 27 taps + one all-zero row (index 27) that invalid taps point to
-__device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, float* wl, int HD) {
-  const int nthr = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
-  for (int i = tid; i < HD * 27; i += nthr) {   // coalesced global reads; the (conflicting) transposition is paid in LDS
-    const int c = i / 27, k = i - c * 27;
-    wl[k * HD + c] = w[i];
-  }
-  for (int i = tid; i < HD; i += nthr) wl[27 * HD + i] = 0.f;
-  __syncthreads();
-}
-
-// coarse[b,o,c] = sum_k fine[b, o*s-1+k, c] * w[c%HD][k]          (4 channels per thread)
-template <bool FF32, bool CF32>
-__global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const void* __restrict__ fine,
-                                                             const float* __restrict__ w, void* __restrict__ coarse) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  const Geom& g = rg.g;
-  stage_weights_z(w, wl, g.HD);
-  const int CQ = g.C / VEC;
-  const int ntok = g.Tc * g.Hc * g.Wc;
-  const int total = g.B * ntok * CQ;
-  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int bt = idx / CQ;
-    const int c = (idx - bt * CQ) * VEC, cw = c % g.HD;
-    int b, ot, oh, ow;
-    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
-    int tof[3], hof[3], xof[3];
-    bool tv[3], hv[3], xv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
-      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
-      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
-      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
-    }
-    const void* fb = bptr<FF32>(fine, (int64_t)b * g.f_bs);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      Raw4<FF32> raw[9];
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw4_load<FF32>(fb, tof[kt] + hof[kh] + xof[kw]);
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tap = (tv[kt] && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
-          const float4 ww = *reinterpret_cast<const float4*>(&wl[tap * g.HD + cw]);
-          float v[4];
-          raw4_cvt<FF32>(raw[kh * 3 + kw], v);
-          acc[0] += v[0] * ww.x; acc[1] += v[1] * ww.y; acc[2] += v[2] * ww.z; acc[3] += v[3] * ww.w;
-        }
-    }
-    st4t<CF32>(bptr<CF32>(coarse, (int64_t)b * g.c_bs), (bt - b * ntok) * cts + c, acc);
-  }
-}
-
-// Fused pooling: depthwise conv (as dwconv_strided) + LayerNorm(hd) of the result, for up to two tensors that share the
-// geometry (k and v of one attention: attention.py:104-116 -> pool_k + norm_k, pool_v + norm_v), in ONE launch.
-// A group of GL lanes owns one (batch, out-token, head, slot) item, 8 channels per lane (HD/8 lanes active), so the
-// LayerNorm statistics are a shuffle reduction inside the group and the pooled row never leaves registers before it is
-// normalised.  Writes the pre-LN row (saved for backward), the normalised row, mean and rstd.
-struct PoolLnSlots {
-  const void* fine[2];
-  const float* w[2];
-  const float* gamma[2];
-  const float* beta[2];
-  void* conv[2];
-  void* y[2];
-  float* mean[2];
-  float* rstd[2];
-};
 template <bool F32> struct Raw8;
 template <> struct Raw8<true> { float4 a, b; };
 template <> struct Raw8<false> { uint4 a; };
@@ -236,6 +161,109 @@ template <bool F32> __device__ __forceinline__ void st8t(void* base, int64_t i, 
   }
 }
 
+// V consecutive channels per thread: 4 (fp32 tensors: 16-byte accesses) or 8 (bf16 tensors: 16-byte accesses; the 8-byte
+// bf16x4 form kept the vector-memory path at about half rate -- 18..27 tap loads per output make these kernels bound by
+// the L1/TA path, not by HBM)
+template <int V, bool F32> struct RawV { typedef Raw4<F32> T; };
+template <bool F32> struct RawV<8, F32> { typedef Raw8<F32> T; };
+template <int V, bool F32> __device__ __forceinline__ typename RawV<V, F32>::T rawv_load(const void* base, int i) {
+  if constexpr (V == 8) return raw8_load<F32>(base, i);
+  else return raw4_load<F32>(base, i);
+}
+template <int V, bool F32> __device__ __forceinline__ void rawv_cvt(const typename RawV<V, F32>::T& r, float (&o)[V]) {
+  if constexpr (V == 8) raw8_cvt<F32>(r, o);
+  else raw4_cvt<F32>(r, o);
+}
+template <int V, bool F32> __device__ __forceinline__ void stvt(void* base, int i, const float (&o)[V]) {
+  if constexpr (V == 8) st8t<F32>(base, i, o);
+  else st4t<F32>(base, i, o);
+}
+// acc[j] += v[j] * wl[j]  for V channels (wl: 16-byte aligned row of the staged weights)
+template <int V> __device__ __forceinline__ void fmav(float (&acc)[V], const float (&v)[V], const float* wrow) {
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    const float4 ww = *reinterpret_cast<const float4*>(wrow + 4 * q);
+    acc[4 * q] += v[4 * q] * ww.x; acc[4 * q + 1] += v[4 * q + 1] * ww.y;
+    acc[4 * q + 2] += v[4 * q + 2] * ww.z; acc[4 * q + 3] += v[4 * q + 3] * ww.w;
+  }
+}
+
+// weights staged as wl[28][HD] fp32: 27 taps + one all-zero row (index 27) that invalid taps point to
+__device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, float* wl, int HD) {
+  const int nthr = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
+  for (int i = tid; i < HD * 27; i += nthr) {   // coalesced global reads; the (conflicting) transposition is paid in LDS
+    const int c = i / 27, k = i - c * 27;
+    wl[k * HD + c] = w[i];
+  }
+  for (int i = tid; i < HD; i += nthr) wl[27 * HD + i] = 0.f;
+  __syncthreads();
+}
+
+// coarse[b,o,c] = sum_k fine[b, o*s-1+k, c] * w[c%HD][k]          (V channels per thread)
+template <bool FF32, bool CF32, int V>
+__global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const void* __restrict__ fine,
+                                                             const float* __restrict__ w, void* __restrict__ coarse) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const Geom& g = rg.g;
+  stage_weights_z(w, wl, g.HD);
+  const int CQ = g.C / V;
+  const int ntok = g.Tc * g.Hc * g.Wc;
+  const int total = g.B * ntok * CQ;
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int bt = idx / CQ;
+    const int c = (idx - bt * CQ) * V, cw = c % g.HD;
+    int b, ot, oh, ow;
+    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+    int tof[3], hof[3], xof[3];
+    bool tv[3], hv[3], xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
+      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
+    }
+    const void* fb = bptr<FF32>(fine, (int64_t)b * g.f_bs);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      typename RawV<V, FF32>::T raw[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = rawv_load<V, FF32>(fb, tof[kt] + hof[kh] + xof[kw]);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (tv[kt] && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
+          float v[V];
+          rawv_cvt<V, FF32>(raw[kh * 3 + kw], v);
+          fmav<V>(acc, v, &wl[tap * g.HD + cw]);
+        }
+    }
+    stvt<V, CF32>(bptr<CF32>(coarse, (int64_t)b * g.c_bs), (bt - b * ntok) * cts + c, acc);
+  }
+}
+
+// Fused pooling: depthwise conv (as dwconv_strided) + LayerNorm(hd) of the result, for up to two tensors that share the
+// geometry (k and v of one attention: attention.py:104-116 -> pool_k + norm_k, pool_v + norm_v), in ONE launch.
+// A group of GL lanes owns one (batch, out-token, head, slot) item, 8 channels per lane (HD/8 lanes active), so the
+// LayerNorm statistics are a shuffle reduction inside the group and the pooled row never leaves registers before it is
+// normalised.  Writes the pre-LN row (saved for backward), the normalised row, mean and rstd.
+struct PoolLnSlots {
+  const void* fine[2];
+  const float* w[2];
+  const float* gamma[2];
+  const float* beta[2];
+  void* conv[2];
+  void* y[2];
+  float* mean[2];
+  float* rstd[2];
+};
 template <int GL, bool F32>
 __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlots sl, int nslots, float eps) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [nslots][28][HD]
@@ -370,7 +398,7 @@ struct Slots2 {
   const float* w[2];
 };
 
-template <int NT, int NH, int NW, bool CF32, bool FF32>
+template <int NT, int NH, int NW, bool CF32, bool FF32, int V>
 __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slots2 sl) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const void* __restrict__ coarse = sl.src[blockIdx.y];
@@ -378,13 +406,13 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slot
   void* __restrict__ fine = sl.dst[blockIdx.y];
   const Geom& g = rg.g;
   stage_weights_z(w, wl, g.HD);
-  const int CQ = g.C / VEC;
+  const int CQ = g.C / V;
   const int ntok = g.Tf * g.Hf * g.Wf;
   const int total = g.B * ntok * CQ;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int bt = idx / CQ;
-    const int c = (idx - bt * CQ) * VEC, cw = c % g.HD;
+    const int c = (idx - bt * CQ) * V, cw = c % g.HD;
     int b, ft, fh, fw;
     decomp(bt, ntok, g.Hf, g.Wf, b, ft, fh, fw);
     int kt[NT], ot[NT], kh[NH], oh[NH], kw[NW], ow[NW];
@@ -399,26 +427,27 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slot
 #pragma unroll
     for (int i = 0; i < NW; ++i) ow[i] = ow[i] * cts + c;
     const void* cb = bptr<CF32>(coarse, (int64_t)b * g.c_bs);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      Raw4<CF32> raw[NH * NW];
+      typename RawV<V, CF32>::T raw[NH * NW];
 #pragma unroll
       for (int e = 0; e < NH; ++e)
 #pragma unroll
-        for (int f = 0; f < NW; ++f) raw[e * NW + f] = raw4_load<CF32>(cb, ot[a] + oh[e] + ow[f]);
+        for (int f = 0; f < NW; ++f) raw[e * NW + f] = rawv_load<V, CF32>(cb, ot[a] + oh[e] + ow[f]);
 #pragma unroll
       for (int e = 0; e < NH; ++e)
 #pragma unroll
         for (int f = 0; f < NW; ++f) {
           const int tap = (vt[a] && vh[e] && vw[f]) ? kt[a] * 9 + kh[e] * 3 + kw[f] : 27;
-          const float4 ww = *reinterpret_cast<const float4*>(&wl[tap * g.HD + cw]);
-          float v[4];
-          raw4_cvt<CF32>(raw[e * NW + f], v);
-          acc[0] += v[0] * ww.x; acc[1] += v[1] * ww.y; acc[2] += v[2] * ww.z; acc[3] += v[3] * ww.w;
+          float v[V];
+          rawv_cvt<V, CF32>(raw[e * NW + f], v);
+          fmav<V>(acc, v, &wl[tap * g.HD + cw]);
         }
     }
-    st4t<FF32>(bptr<FF32>(fine, (int64_t)b * g.f_bs), (bt - b * ntok) * fts + c, acc);
+    stvt<V, FF32>(bptr<FF32>(fine, (int64_t)b * g.f_bs), (bt - b * ntok) * fts + c, acc);
   }
 }
 
@@ -766,14 +795,15 @@ extern "C" int csts_dwconv_strided(const csts_dwconv_geom* a, const void* fine, 
   CSTS_REQUIRE(fine && weight && coarse, "null pointer");
   CSTS_REQUIRE(((uintptr_t)fine & 15) == 0 && ((uintptr_t)coarse & 15) == 0, "tensors must be 16-byte aligned");
   RowGeom rg; fill_geom(a, rg);
-  const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc * (a->C / VEC);
+  const bool ff = fine_dt == CSTS_F32, cf = coarse_dt == CSTS_F32;
+  const int vec = (!ff && !cf) ? 8 : VEC;     // bf16 on both sides: 8 channels (16 bytes) per thread
+  const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc * (a->C / vec);
   const dim3 grid(grid_for_staged(total)), block(256);
   const size_t sm = (size_t)a->HD * 28 * 4;
-  const bool ff = fine_dt == CSTS_F32, cf = coarse_dt == CSTS_F32;
-  if (ff && cf) hipLaunchKernelGGL((dwconv_strided_kernel<true, true>), grid, block, sm, stream, rg, fine, weight, coarse);
-  else if (!ff && !cf) hipLaunchKernelGGL((dwconv_strided_kernel<false, false>), grid, block, sm, stream, rg, fine, weight, coarse);
-  else if (ff) hipLaunchKernelGGL((dwconv_strided_kernel<true, false>), grid, block, sm, stream, rg, fine, weight, coarse);
-  else hipLaunchKernelGGL((dwconv_strided_kernel<false, true>), grid, block, sm, stream, rg, fine, weight, coarse);
+  if (ff && cf) hipLaunchKernelGGL((dwconv_strided_kernel<true, true, 4>), grid, block, sm, stream, rg, fine, weight, coarse);
+  else if (!ff && !cf) hipLaunchKernelGGL((dwconv_strided_kernel<false, false, 8>), grid, block, sm, stream, rg, fine, weight, coarse);
+  else if (ff) hipLaunchKernelGGL((dwconv_strided_kernel<true, false, 4>), grid, block, sm, stream, rg, fine, weight, coarse);
+  else hipLaunchKernelGGL((dwconv_strided_kernel<false, true, 4>), grid, block, sm, stream, rg, fine, weight, coarse);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
@@ -789,17 +819,17 @@ static int transposed_launch(const csts_dwconv_geom* a, int nslots, const void* 
     sl.src[i] = coarse[i]; sl.dst[i] = fine[i]; sl.w[i] = weight[i];
   }
   RowGeom rg; fill_geom(a, rg);
-  const int64_t total = (int64_t)a->B * a->Tf * a->Hf * a->Wf * (a->C / VEC);
-  const dim3 grid(grid_for_staged(total), nslots), block(256);
-  const size_t sm = (size_t)a->HD * 28 * 4;
   CSTS_REQUIRE(coarse_dt == fine_dt, "transposed stencil: both tensors must have the same dtype");
   const bool f32 = fine_dt == CSTS_F32;
+  const int64_t total = (int64_t)a->B * a->Tf * a->Hf * a->Wf * (a->C / (f32 ? VEC : 8));   // bf16: 8 channels per thread
+  const dim3 grid(grid_for_staged(total), nslots), block(256);
+  const size_t sm = (size_t)a->HD * 28 * 4;
   auto nc = [](int st) { return st == 1 ? 3 : (st == 2 ? 2 : 1); };
   const int key = nc(a->st) * 100 + nc(a->sh) * 10 + nc(a->sw);
 #define TR_CASE(NT, NH, NW)                                                                                          \
   case NT * 100 + NH * 10 + NW:                                                                                      \
-    if (f32) hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, true, true>), grid, block, sm, stream, rg, sl); \
-    else hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, false, false>), grid, block, sm, stream, rg, sl);   \
+    if (f32) hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, true, true, 4>), grid, block, sm, stream, rg, sl); \
+    else hipLaunchKernelGGL((dwconv_transposed_kernel<NT, NH, NW, false, false, 8>), grid, block, sm, stream, rg, sl);   \
     break;
   switch (key) {
     TR_CASE(3, 3, 3) TR_CASE(3, 3, 2) TR_CASE(3, 3, 1) TR_CASE(3, 2, 3) TR_CASE(3, 2, 2) TR_CASE(3, 2, 1)
