@@ -539,13 +539,20 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
           }
     }
   }
-  for (int l = 0; l < (int)blockDim.y; ++l) {   // fold the token lanes in a fixed order
-    if (ty == l) {
+  // fold the token lanes in a fixed order (lane 0 stores, lanes 1.. add in turn, as straight-line read / add / write batches:
+  // a per-element "first lane?" test inside the unrolled loops compiled to one branch per element)
+  if (ty == 0) {
 #pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        if (l == 0) { red[cl * 27 + k] = a0[k]; red[(cl + 1) * 27 + k] = a1[k]; }
-        else { red[cl * 27 + k] += a0[k]; red[(cl + 1) * 27 + k] += a1[k]; }
-      }
+    for (int k = 0; k < 27; ++k) { red[cl * 27 + k] = a0[k]; red[(cl + 1) * 27 + k] = a1[k]; }
+  }
+  __syncthreads();
+  for (int l = 1; l < (int)blockDim.y; ++l) {
+    if (ty == l) {
+      float t0[27], t1[27];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) { t0[k] = red[cl * 27 + k]; t1[k] = red[(cl + 1) * 27 + k]; }
+#pragma unroll
+      for (int k = 0; k < 27; ++k) { red[cl * 27 + k] = t0[k] + a0[k]; red[(cl + 1) * 27 + k] = t1[k] + a1[k]; }
     }
     __syncthreads();
   }
@@ -890,9 +897,11 @@ static int wgrad_launch(const csts_dwconv_geom* a, int nslots, const void* const
     sl.fine[i] = fine[i]; sl.coarse[i] = coarse[i];
     sl.ws[i] = reinterpret_cast<float*>(workspace) + per_slot * i;
   }
-  const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 512 / (slab / 2)), chunk / 2));
   CSTS_REQUIRE(coarse_dt == fine_dt, "stencil wgrad: both tensors must have the same dtype");
+  const int lanes = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 512 / (slab / 2)), chunk / 2));
   const dim3 wg(nslab, (unsigned)nchunk, nslots), wb(slab / 2, lanes);
+  // (a 4-channel-per-thread form with 8-byte loads was measured slower: 230 VGPRs halve the resident waves and the tap
+  // loads of this kernel are latency-bound)
   if (fine_dt == CSTS_F32) hipLaunchKernelGGL((dwconv_wgrad_kernel<true, true>), wg, wb, (size_t)slab * 27 * 4, stream, rg, sl, slab, (int)chunk);
   else hipLaunchKernelGGL((dwconv_wgrad_kernel<false, false>), wg, wb, (size_t)slab * 27 * 4, stream, rg, sl, slab, (int)chunk);
   CSTS_LAUNCH_CHECK();
