@@ -412,7 +412,9 @@ template <bool KC, bool F32S, int EXT, int NTHR> struct Oper {
 };
 
 // LDS-lean schedule: ONE LDS stage (A+B <= 40 KiB) + the next k-tile prefetched in registers, and the epilogue staged
-// 64 rows at a time (33 KiB) -> 4 workgroups per CU.  Counters on MI355X (rocprofv3 PMC, NT 8192x1536x384): with the
+// 64 rows at a time (33 KiB) -> 4 workgroups per CU.  (gemm3's register epilogue -- swapped MFMA operands, 16-byte stores of
+// 32-byte row segments -- was tried here too: correct, but 8 % slower over the step's GEMMs: at 3-4 workgroups per CU the
+// staged epilogue's full-line stores matter more than its barriers.)  Counters on MI355X (rocprofv3 PMC, NT 8192x1536x384): with the
 // previous double-buffered 74 KiB layout only 2 workgroups fit per CU and waves sat 47 % in s_waitcnt / barriers with
 // the MFMA pipe 12 % busy; residency, not per-workgroup pipelining, is what hides the L2/HBM round trips here.
 // Wave grid WM x 2, each wave (32*MT) x 64: tiles 64x128 (MT 1), 128x128 (MT 2), 256x128 (MT 4: 128x64 per wave, 2 wg/CU).
@@ -662,8 +664,14 @@ __device__ __forceinline__ void st4x4(void* base, int dt, int64_t at, const f32x
 #define G3_STAMP() do { } while (0)
 #endif
 
+// workgroups per CU that the ring's LDS allows (160 KiB), capped at 3: the register budget is set for exactly that many
+template <int MT, int S> struct G3Occ {
+  static constexpr int FIT = (160 * 1024) / (S * (64 * MT + 128) * 128);
+  static constexpr int WG = FIT < 1 ? 1 : (FIT > 3 ? 3 : FIT);
+};
+
 template <int MT, int S>
-__global__ __launch_bounds__(256, (MT == 4) ? 1 : (MT == 2 ? 2 : 3)) void gemm3_kernel(Params p) {
+__global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p) {
 #ifdef CSTS_GEMM3_STAMPS
   const bool stamp_on = p.stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 137);
   unsigned long long* stamp_buf = p.stamps + (blockIdx.x == 0 ? 0 : 512);
