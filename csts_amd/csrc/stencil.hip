@@ -451,6 +451,78 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slot
   }
 }
 
+// Transposed convolution with stride 2 along H and W (the (1,2,2) pools of the 384 / 768-channel stages and the decoder's
+// upsampling), bf16, fine H and W even: one thread produces the 2 x 2 block of fine positions (2 mh + {0,1}, 2 mw + {0,1})
+// for 8 channels.  With kernel 3 / padding 1 an even fine index 2m has the single tap (o = m, k = 1) per axis and an odd
+// index 2m + 1 the taps (o = m, k = 2) and (o = m + 1, k = 0): the whole block reads the 2 x 2 coarse neighbourhood
+// {mh, mh+1} x {mw, mw+1} once per temporal tap -- 4 loads per 4 outputs where the generic kernel issues 4 per output
+// (two of them on average for taps that do not exist at that parity).  The tap loads are what bounds these kernels.
+template <int NT>
+__global__ __launch_bounds__(256) void dwconv_transposed_s22_kernel(RowGeom rg, Slots2 sl) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const bf16* __restrict__ coarse = reinterpret_cast<const bf16*>(sl.src[blockIdx.y]);
+  bf16* __restrict__ fine = reinterpret_cast<bf16*>(sl.dst[blockIdx.y]);
+  const Geom& g = rg.g;
+  stage_weights_z(sl.w[blockIdx.y], wl, g.HD);
+  const int CQ = g.C / 8;
+  const int H2 = g.Hf >> 1, W2 = g.Wf >> 1;
+  const int nblk = g.Tf * H2 * W2;
+  const int total = g.B * nblk * CQ;
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int bt = idx / CQ;
+    const int c = (idx - bt * CQ) * 8, cw = c % g.HD;
+    int b, ft, mh, mw;
+    decomp(bt, nblk, H2, W2, b, ft, mh, mw);
+    int kt[NT], ot[NT];
+    bool vt[NT];
+    axis_cand<NT>(ft, g.st, rg.lt, g.Tc, kt, ot, vt);
+    const bool vh1 = mh + 1 < g.Hc, vw1 = mw + 1 < g.Wc;
+    const int oh0 = mh * g.Wc * cts, oh1 = min(mh + 1, g.Hc - 1) * g.Wc * cts;
+    const int ow0 = mw * cts + c, ow1 = min(mw + 1, g.Wc - 1) * cts + c;
+    const bf16* cb = coarse + (int64_t)b * g.c_bs;
+    float o00[8], o01[8], o10[8], o11[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o00[j] = 0.f; o01[j] = 0.f; o10[j] = 0.f; o11[j] = 0.f; }
+    Raw8<false> raw[NT][4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int tb = ot[a] * g.Hc * g.Wc * cts;
+      raw[a][0] = raw8_load<false>(cb, tb + oh0 + ow0);
+      raw[a][1] = raw8_load<false>(cb, tb + oh0 + ow1);
+      raw[a][2] = raw8_load<false>(cb, tb + oh1 + ow0);
+      raw[a][3] = raw8_load<false>(cb, tb + oh1 + ow1);
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      float i00[8], i01[8], i10[8], i11[8];
+      raw8_cvt<false>(raw[a][0], i00);
+      raw8_cvt<false>(raw[a][1], i01);
+      raw8_cvt<false>(raw[a][2], i10);
+      raw8_cvt<false>(raw[a][3], i11);
+      // weight row of tap (kt, kh, kw); taps that do not exist read the all-zero row 27
+      const int t9 = kt[a] * 9;
+      auto wrow = [&](bool ok, int kh, int kw) { return &wl[(ok ? t9 + kh * 3 + kw : 27) * g.HD + cw]; };
+      const bool v = vt[a];
+      fmav<8>(o00, i00, wrow(v, 1, 1));
+      fmav<8>(o01, i00, wrow(v, 1, 2));
+      fmav<8>(o01, i01, wrow(v && vw1, 1, 0));
+      fmav<8>(o10, i00, wrow(v, 2, 1));
+      fmav<8>(o10, i10, wrow(v && vh1, 0, 1));
+      fmav<8>(o11, i00, wrow(v, 2, 2));
+      fmav<8>(o11, i01, wrow(v && vw1, 2, 0));
+      fmav<8>(o11, i10, wrow(v && vh1, 0, 2));
+      fmav<8>(o11, i11, wrow(v && vh1 && vw1, 0, 0));
+    }
+    bf16* fb = fine + (int64_t)b * g.f_bs;
+    const int f00 = ((ft * g.Hf + 2 * mh) * g.Wf + 2 * mw) * fts + c;
+    st8t<false>(fb, f00, o00);
+    st8t<false>(fb, f00 + fts, o01);
+    st8t<false>(fb, f00 + g.Wf * fts, o10);
+    st8t<false>(fb, f00 + g.Wf * fts + fts, o11);
+  }
+}
+
 // partial dW: block = (slab/2 channel pairs) x (token lanes), chunk of coarse tokens -> ws[part][HD*27]
 // token lanes and heads of a slab are folded in LDS in a fixed order (bitwise reproducible).
 struct WgSlots2 {
@@ -832,6 +904,15 @@ static int transposed_launch(const csts_dwconv_geom* a, int nslots, const void* 
   const dim3 grid(grid_for_staged(total), nslots), block(256);
   const size_t sm = (size_t)a->HD * 28 * 4;
   auto nc = [](int st) { return st == 1 ? 3 : (st == 2 ? 2 : 1); };
+  if (!f32 && a->sh == 2 && a->sw == 2 && a->Hf % 2 == 0 && a->Wf % 2 == 0) {   // 2 x 2 output blocks (see the kernel)
+    const int64_t items = (int64_t)a->B * a->Tf * (a->Hf / 2) * (a->Wf / 2) * (a->C / 8);
+    const dim3 grid2(grid_for_staged(items), nslots);
+    if (nc(a->st) == 3) hipLaunchKernelGGL((dwconv_transposed_s22_kernel<3>), grid2, block, sm, stream, rg, sl);
+    else if (nc(a->st) == 2) hipLaunchKernelGGL((dwconv_transposed_s22_kernel<2>), grid2, block, sm, stream, rg, sl);
+    else hipLaunchKernelGGL((dwconv_transposed_s22_kernel<1>), grid2, block, sm, stream, rg, sl);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   const int key = nc(a->st) * 100 + nc(a->sh) * 10 + nc(a->sw);
 #define TR_CASE(NT, NH, NW)                                                                                          \
   case NT * 100 + NH * 10 + NW:                                                                                      \

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsts_hip.so")
+LIB_PATH = os.environ.get("CSTS_HIP_LIB") or os.path.join(_HERE, "libcsts_hip.so")   # override: A/B runs of two builds on one box
 
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

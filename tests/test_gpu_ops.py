@@ -291,6 +291,37 @@ def test_attention_backward_one_pass_short_kv(B, H, Nq, Nk):
     assert (dqkv[:, Nq] == 7).all() and (dqkv[:, :Nq, Cc:] == 7).all()      # nothing outside the dq slot was touched
 
 
+@pytest.mark.parametrize("fthw,st", [((3, 8, 12), (1, 2, 2)), ((4, 6, 4), (2, 2, 2)), ((2, 16, 16), (4, 2, 2)), ((3, 7, 5), (1, 2, 2))])
+def test_transposed_stencil_stride2_blocks(fthw, st):
+    """bf16 transposed depthwise convolution with stride 2 along H and W (2 x 2 output blocks per thread; odd grids fall back
+    to the generic kernel) against torch.conv_transpose3d semantics of attention_upsample / the pool backward
+    (attention.py:251-289, :11-49): fine grid = the given one, coarse = floor((fine-1)/stride)+1, coarse read in place
+    inside a 3C-wide buffer."""
+    import ctypes as C
+    B, Cc, HD = 2, 192, 96
+    cthw = [(f - 1) // s_ + 1 for f, s_ in zip(fthw, st)]
+    Nf, Nc = fthw[0] * fthw[1] * fthw[2], cthw[0] * cthw[1] * cthw[2]
+    coarse = rnd(B, Nc, 3 * Cc, seed=1).to(torch.bfloat16)
+    w = rnd(HD, 27, seed=2, scale=0.3)
+    fine = torch.full((B, Nf + 1, Cc), 7.0, device=DEV, dtype=torch.bfloat16)
+    g = L.DwconvGeom()
+    g.B, g.C, g.HD = B, Cc, HD
+    g.Tf, g.Hf, g.Wf = fthw; g.Tc, g.Hc, g.Wc = cthw; g.st, g.sh, g.sw = st
+    g.fine_batch_stride, g.fine_token_stride = (Nf + 1) * Cc, Cc
+    g.coarse_batch_stride, g.coarse_token_stride = Nc * 3 * Cc, 3 * Cc
+    lib = L.load()
+    L.check(lib.csts_dwconv_transposed(C.byref(g), coarse.data_ptr() + 2 * Cc, L.BF16, w.data_ptr(), fine.data_ptr(), L.BF16,
+                                       torch.cuda.current_stream().cuda_stream), "transposed")     # the middle (k) slot
+    torch.cuda.synchronize()
+    x = coarse[:, :, Cc:2 * Cc].float().reshape(B, *cthw, Cc).permute(0, 4, 1, 2, 3)
+    wt = w.reshape(HD, 1, 3, 3, 3).repeat(Cc // HD, 1, 1, 1, 1)
+    op = [f - ((c - 1) * s_ - 2 + 3) for f, c, s_ in zip(fthw, cthw, st)]     # output_padding that restores the fine grid
+    ref = F.conv_transpose3d(x, wt, stride=st, padding=1, output_padding=op, groups=Cc)
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(B, Nf, Cc)
+    assert rel_l2(fine[:, :Nf].float(), ref) < 6e-3
+    assert (fine[:, Nf] == 7).all()
+
+
 def test_attention_long_kv_online_softmax():
     """N_kv = 1000 (not a multiple of the 64-key tile), large score range: exercises the online-softmax rescale."""
     B, N, Cc, H = 1, 1000, 96, 1
