@@ -291,8 +291,10 @@ __device__ __forceinline__ void stage_rows_out(bf16* S, void* dst, int64_t base,
 }
 
 // ---------------------------------------------------------------------------------------------- forward
+// hd 96 / bf16: a 256-register budget = two workgroups (2 waves per SIMD) per CU; unconstrained the compiler took 272
+// registers and the kernel ran one wave per SIMD (63 -> 44 us on the 32 k-query x 512-key block, 108 -> 64 us on the decoder)
 template <int HD, bool F32>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_kernel(AttnP p) {
   typedef typename El<F32>::T T;
   typedef Cfg<HD, F32> C;
   constexpr int KT = C::KVBLK / 32;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 
 // ---------------------------------------------------------------------------------------------- dQ
 template <int HD, bool F32>
-__global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_kernel(AttnP p) {
   typedef typename El<F32>::T T;
   typedef Cfg<HD, F32> C;
   constexpr int KT = C::KVBLK / 32;
@@ -487,6 +489,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
+// (a 256-register budget for two workgroups per CU, as attn_fwd / attn_dq have, was measured 2-4 % slower here: this
+// kernel carries dK, dV, the key fragments and the score tiles and spills)
 template <int HD, bool F32>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   typedef typename El<F32>::T T;
@@ -522,6 +526,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
     const bool slow = (q0 + QBLK > qend) || p.mask_mode != 0;   // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+
       f32x16 S, dP;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
@@ -541,16 +546,11 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
         }
       } else {
         // the 4 registers of a quad are 4 consecutive queries: one 16-byte load of LSE / delta each
-        float4 L4[4], D4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int q = q0 + qt * 32 + 8 * j + 4 * h;
-          L4[j] = *reinterpret_cast<const float4*>(Lrow + q);
-          D4[j] = *reinterpret_cast<const float4*>(Drow + q);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float l[4] = {L4[j].x, L4[j].y, L4[j].z, L4[j].w}, dd[4] = {D4[j].x, D4[j].y, D4[j].z, D4[j].w};
+          const float4 L4 = *reinterpret_cast<const float4*>(Lrow + q), D4 = *reinterpret_cast<const float4*>(Drow + q);
+          const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * j + i], p.scale_log2, -l[i]));
