@@ -191,6 +191,11 @@ def cpu_baseline(frames):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): native libraries print there too (RCCL writes a five-line version banner
+    # to stdout when its first communicator comes up), so fd 1 points at stderr until the result is printed
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -362,7 +367,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.frames)
             except Exception as e:  # keep the line valid even if the host runs out of memory
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        sys.stdout.flush()
+        os.dup2(_stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)       # teardown chatter of native libraries stays off stdout as well
     if dist_path:
         torch.distributed.destroy_process_group()
 
