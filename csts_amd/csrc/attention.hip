@@ -803,7 +803,7 @@ bool fused_bwd_ok(const csts_attn_args* a) {
 
 void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
   if (fused_bwd_ok(a)) {      // one workgroup per CU (its LDS holds K, V and the Q / dO tile): aim at two rounds of the chip
-    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(512 / ((int64_t)a->B * a->H), cdiv(a->Nq, 256)));
+    const int64_t want = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)a->B * a->H), cdiv(a->Nq, 256)));
     q_chunk = (int)(cdiv(cdiv(a->Nq, want), 128) * 128);
     nsplit = (int)cdiv(a->Nq, q_chunk);
     return;
