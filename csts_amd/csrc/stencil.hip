@@ -949,7 +949,9 @@ static void wgrad_plan(const csts_dwconv_geom* a, int& slab, int& nslab, int64_t
   slab = a->HD * k;
   nslab = a->C / slab;
   const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc;
-  nchunk = std::max<int64_t>(1, std::min<int64_t>(2048 / nslab, cdiv(total, 16)));
+  // <= 512 workgroups per tensor (2 per CU), >= 16 coarse tokens each.  Sweep on MI355X (tools/dwconv_bench.py, wgrad calls of
+  // one step): caps of 2048 / 1024 / 512 / 256 / 128 -> 1.39 / 1.34 / 1.31 / 1.40 / 2.3 ms; 32 / 64 tokens minimum: worse.
+  nchunk = std::max<int64_t>(1, std::min<int64_t>(512 / nslab, cdiv(total, 16)));
   chunk = cdiv(total, nchunk);
   nchunk = cdiv(total, chunk);
 }
