@@ -830,11 +830,11 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void
   }
 }
 
-int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 8); }
-// kernels that stage the 27 x HD weight table per workgroup.  Measured on MI355X (tools/dwconv_bench.py, whole step):
-// caps of 256 / 512 / 1024 / 2048 workgroups give 28.28 / 27.88 / 27.75 / 27.90 ms per step -- the staging is not what
-// bounds these kernels, so the cap stays at 8 workgroups per CU.
-int grid_for_staged(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 8); }
+int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 32); }
+// kernels that stage the 27 x HD weight table per workgroup.  Whole-step sweeps on MI355X, same box (elementwise cap /
+// staged cap -> ms per step): 2048 / 2048 -> 25.04, 2048 / 1024 -> 24.97, 8192 / 1024 -> 24.82..24.96, 8192 / 768 -> 24.85,
+// 2048 / 4096 -> 25.27, 1024 / 2048 -> 25.27: 4 staged workgroups per CU, the element-wise kernels effectively uncapped.
+int grid_for_staged(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 4); }
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
