@@ -524,6 +524,19 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
                                                  [&](const T* Qs, const T* dOs, int q0) {
     const bool slow = (q0 + QBLK > qend) || p.mask_mode != 0;   // wave-uniform
+    // statistics of the whole tile first: the kernel runs one wave per SIMD, so these L2 round trips would otherwise be
+    // exposed once per 32-query unit
+    float4 L4a[QT][4], D4a[QT][4];
+    if (!(slow || !stats_vec)) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = q0 + qt * 32 + 8 * j + 4 * h;
+          L4a[qt][j] = *reinterpret_cast<const float4*>(Lrow + q);
+          D4a[qt][j] = *reinterpret_cast<const float4*>(Drow + q);
+        }
+    }
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
 
@@ -548,8 +561,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
         // the 4 registers of a quad are 4 consecutive queries: one 16-byte load of LSE / delta each
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int q = q0 + qt * 32 + 8 * j + 4 * h;
-          const float4 L4 = *reinterpret_cast<const float4*>(Lrow + q), D4 = *reinterpret_cast<const float4*>(Drow + q);
+          const float4 L4 = L4a[qt][j], D4 = D4a[qt][j];
           const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
