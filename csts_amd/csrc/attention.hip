@@ -407,9 +407,29 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
   const int qi = qvalid ? qraw : p.Nq - 1;
 
   RowFrag<HD, F32> qf, dof;
+  [[maybe_unused]] RowFrag<HD, F32> of_pre;       // hd 96 / bf16: O row fragments, staged together with Q and dO
+  constexpr bool PRE3 = !F32 && HD == 96;          // two 128-row staging regions fit the kernel's LDS only at hd 96
   if constexpr (F32) {
     qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
     dof.load(p.dO, (int64_t)b * p.do_bs + (int64_t)qi * p.do_ts + (int64_t)head * p.do_hs, h);
+  } else if constexpr (PRE3) {
+    // all three row tiles are requested at once (ONE memory round trip instead of three in a row), then pass through the
+    // two LDS staging regions
+    constexpr int LDS_LD = HD + 8;
+    TileStage<HD, 128> tq, tdo, to;
+    tq.gload(p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+    tdo.gload(p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, blockIdx.x * 128, p.Nq, tid);
+    to.gload(p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+    tq.lstore(smem, LDS_LD, tid);
+    tdo.lstore(smem + 128 * LDS_LD, LDS_LD, tid);
+    __syncthreads();
+    frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
+    frag_from_lds<HD>(dof, smem + 128 * LDS_LD, w * 32 + (lane & 31), h);
+    __syncthreads();
+    to.lstore(smem, LDS_LD, tid);
+    __syncthreads();
+    frag_from_lds<HD>(of_pre, smem, w * 32 + (lane & 31), h);
+    __syncthreads();
   } else {
     stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
     __syncthreads();
@@ -431,10 +451,14 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
 #pragma unroll
       for (int s2 = 0; s2 < HD / 2; ++s2) dl += dof.f[s2] * of.f[s2];
     } else {
-      stage_rows_in<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
-      __syncthreads();
-      frag_from_lds<HD>(of, smem, w * 32 + (lane & 31), h);
-      __syncthreads();
+      if constexpr (PRE3) {
+        of = of_pre;
+      } else {
+        stage_rows_in<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+        __syncthreads();
+        frag_from_lds<HD>(of, smem, w * 32 + (lane & 31), h);
+        __syncthreads();
+      }
 #pragma unroll
       for (int s2 = 0; s2 < HD / 16; ++s2)
 #pragma unroll
