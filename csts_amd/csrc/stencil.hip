@@ -311,13 +311,15 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlot
     const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
     const float* wls = wl + slot * 28 * HD + c8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Raw8<F32> raw[27];                      // all 27 taps in flight at once (one memory round trip per item, not three)
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      Raw8<F32> raw[9];
+    for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw8_load<F32>(fb, tof[kt] + hof[kh] + xof[kw]);
+        for (int kw = 0; kw < 3; ++kw) raw[kt * 9 + kh * 3 + kw] = raw8_load<F32>(fb, tof[kt] + hof[kh] + xof[kw]);
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlot
           const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * HD]);
           const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * HD + 4]);
           float v[8];
-          raw8_cvt<F32>(raw[kh * 3 + kw], v);
+          raw8_cvt<F32>(raw[kt * 9 + kh * 3 + kw], v);
           acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;
           acc[4] += v[4] * w1.x; acc[5] += v[5] * w1.y; acc[6] += v[6] * w1.z; acc[7] += v[7] * w1.w;
         }
