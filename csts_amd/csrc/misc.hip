@@ -347,6 +347,151 @@ __global__ __launch_bounds__(256) void rowdot_dx_kernel(const float* __restrict_
     st_from_f32(dx, dx_dt, idx, dout[idx / C] * w[idx % C]);
 }
 
+// c[m] = sum_n a[m,n] * b[m,n]   (gradient of a per-row weight: d w[m] = <dy[m,:], x[m,:]>); 32 lanes per row
+__global__ __launch_bounds__(256) void rowdot2_kernel(const void* __restrict__ a, int a_dt, const void* __restrict__ b, int b_dt,
+                                                      float* __restrict__ out, int64_t M, int C) {
+  const int sub = threadIdx.x & 31;
+  const int64_t row0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
+  for (int64_t m = row0; m < M; m += stride) {
+    float s = 0.f;
+    for (int c = sub; c < C; c += 32) s += ld_as_f32(a, a_dt, m * C + c) * ld_as_f32(b, b_dt, m * C + c);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) out[m] = s;
+  }
+}
+
+// ---- audio -> pixel attention map of the spatial fusion block (av_attention.py:356-370).
+// Tokens of the block: T*HW video tokens (t-major) followed by T audio tokens; audio token t attends to the HW video
+// tokens of frame t and to itself (the -1e8 mask of av_attention.py:336-346 leaves exactly these: exp underflows to 0
+// for every other key).  Per head: p = softmax(scale * q_a . k_j) over those HW + 1 keys; the map is p restricted to
+// the HW video keys, min-max rescaled: r = (p - min) / (max - min + 1e-8); custom_multimodal_builder.py:438 then
+// averages r over the heads.  One 256-thread workgroup per (clip, frame); everything in fp32.
+// block-wide reductions (all 256 threads call; `red` = 8 floats of LDS scratch)
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+// probabilities of head h for (b, t) into p[0 .. HW] (p[HW] = the audio token itself); q (hd floats) is left in LDS
+__device__ __forceinline__ void audio_attn_probs(const void* __restrict__ qkv, int dt, int64_t tok0, int t, int T, int HW, int C,
+                                                 int h, int hd, float scale, float* q, float* p, float* red) {
+  const int tid = threadIdx.x;
+  const int64_t ld = 3 * (int64_t)C, arow = tok0 + (int64_t)T * HW + t;
+  __syncthreads();                                         // previous head is done with q / p
+  for (int d = tid; d < hd; d += 256) q[d] = ld_as_f32(qkv, dt, arow * ld + h * hd + d);
+  __syncthreads();
+  for (int j = tid; j <= HW; j += 256) {
+    const int64_t row = j < HW ? tok0 + (int64_t)t * HW + j : arow;
+    float acc = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+      float kk[8];
+      ld8_as_f32(qkv, dt, row * ld + C + h * hd + d, kk);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += q[d + e] * kk[e];
+    }
+    p[j] = acc * scale;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = tid; j <= HW; j += 256) m = fmaxf(m, p[j]);
+  m = block_max256(m, red);
+  float s = 0.f;
+  for (int j = tid; j <= HW; j += 256) { const float e = __expf(p[j] - m); p[j] = e; s += e; }
+  s = block_sum256(s, red);
+  const float inv = 1.f / s;
+  for (int j = tid; j <= HW; j += 256) p[j] *= inv;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void audio_attn_fwd_kernel(const void* __restrict__ qkv, int dt, float* __restrict__ aa,
+                                                             float* __restrict__ wmap, int T, int HW, int C, int H, float scale) {
+  extern __shared__ float sm[];
+  const int hd = C / H, tid = threadIdx.x;
+  float* q = sm; float* p = q + hd; float* acc = p + HW + 1; float* red = acc + HW;
+  const int b = blockIdx.x / T, t = blockIdx.x % T;
+  const int64_t tok0 = (int64_t)b * (T * HW + T);
+  for (int j = tid; j < HW; j += 256) acc[j] = 0.f;
+  for (int h = 0; h < H; ++h) {
+    audio_attn_probs(qkv, dt, tok0, t, T, HW, C, h, hd, scale, q, p, red);
+    float mx = -INFINITY, mn = INFINITY;
+    for (int j = tid; j < HW; j += 256) { mx = fmaxf(mx, p[j]); mn = fminf(mn, p[j]); }
+    mx = block_max256(mx, red);
+    mn = -block_max256(-mn, red);
+    const float invd = 1.f / (mx - mn + 1e-8f);
+    for (int j = tid; j < HW; j += 256) {
+      const float r = (p[j] - mn) * invd;
+      if (aa != nullptr) aa[(((int64_t)b * H + h) * T + t) * HW + j] = r;
+      acc[j] += r;
+    }
+  }
+  for (int j = tid; j < HW; j += 256) wmap[((int64_t)b * T + t) * HW + j] = acc[j] / (float)H;
+}
+
+// backward: d(wmap) -> d(q of audio token t), d(k of the HW video tokens of frame t and of the audio token), written into
+// a zero-initialised buffer shaped like qkv (no other workgroup touches these rows / slots).
+__global__ __launch_bounds__(256) void audio_attn_bwd_kernel(const void* __restrict__ qkv, int dt, const float* __restrict__ dwmap,
+                                                             void* __restrict__ dqkv, int T, int HW, int C, int H, float scale) {
+  extern __shared__ float sm[];
+  const int hd = C / H, tid = threadIdx.x;
+  float* q = sm; float* p = q + hd; float* dl = p + HW + 1; float* red = dl + HW + 1;
+  const int b = blockIdx.x / T, t = blockIdx.x % T;
+  const int64_t tok0 = (int64_t)b * (T * HW + T), ld = 3 * (int64_t)C, arow = tok0 + (int64_t)T * HW + t;
+  for (int h = 0; h < H; ++h) {
+    audio_attn_probs(qkv, dt, tok0, t, T, HW, C, h, hd, scale, q, p, red);
+    float mx = -INFINITY, mn = INFINITY;
+    for (int j = tid; j < HW; j += 256) { mx = fmaxf(mx, p[j]); mn = fminf(mn, p[j]); }
+    mx = block_max256(mx, red);
+    mn = -block_max256(-mn, red);
+    // first index that attains the extremum (torch.max / torch.min route the gradient to one index)
+    float imx = 3.0e38f, imn = 3.0e38f;
+    for (int j = tid; j < HW; j += 256) { if (p[j] == mx) imx = fminf(imx, (float)j); if (p[j] == mn) imn = fminf(imn, (float)j); }
+    const int jmx = (int)(-block_max256(-imx, red)), jmn = (int)(-block_max256(-imn, red));
+    const float invd = 1.f / (mx - mn + 1e-8f);
+    float sg = 0.f, sgr = 0.f;
+    for (int j = tid; j < HW; j += 256) {
+      const float g = dwmap[((int64_t)b * T + t) * HW + j] / (float)H;
+      sg += g; sgr += g * (p[j] - mn) * invd;
+    }
+    sg = block_sum256(sg, red);
+    sgr = block_sum256(sgr, red);
+    float dot = 0.f;                                        // sum_j p_j dp_j over the video keys (dp of the self key is 0)
+    for (int j = tid; j < HW; j += 256) {
+      float dp = dwmap[((int64_t)b * T + t) * HW + j] / (float)H * invd;
+      if (j == jmn) dp += (sgr - sg) * invd;
+      if (j == jmx) dp -= sgr * invd;
+      dl[j] = dp;
+      dot += p[j] * dp;
+    }
+    dot = block_sum256(dot, red);
+    for (int j = tid; j <= HW; j += 256) dl[j] = p[j] * ((j < HW ? dl[j] : 0.f) - dot) * scale;   // d logits * scale
+    __syncthreads();
+    for (int d = tid; d < hd; d += 256) {                   // dq = sum_j dl_j k_j
+      float acc = 0.f;
+      for (int j = 0; j <= HW; ++j) {
+        const int64_t row = j < HW ? tok0 + (int64_t)t * HW + j : arow;
+        acc += dl[j] * ld_as_f32(qkv, dt, row * ld + C + h * hd + d);
+      }
+      st_from_f32(dqkv, dt, arow * ld + h * hd + d, acc);
+    }
+    for (int idx = tid; idx < (HW + 1) * hd; idx += 256) {  // dk_j = dl_j q
+      const int j = idx / hd, d = idx - j * hd;
+      const int64_t row = j < HW ? tok0 + (int64_t)t * HW + j : arow;
+      st_from_f32(dqkv, dt, row * ld + C + h * hd + d, dl[j] * q[d]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int csts_im2col(const csts_im2col_geom* g, const void* x, int x_dt, void* col, int col_dt, hipStream_t stream) {
@@ -537,6 +682,31 @@ extern "C" int csts_rowdot_fwd(const void* x, int x_dt, const float* w, const fl
 extern "C" int csts_rowdot_dx(const float* dout, const float* w, void* dx, int dx_dt, int64_t M, int C, hipStream_t stream) {
   CSTS_REQUIRE(dout && w && dx && M > 0 && C > 0, "bad args");
   hipLaunchKernelGGL(rowdot_dx_kernel, dim3(grid_for(M * C)), dim3(256), 0, stream, dout, w, dx, dx_dt, M * C, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int csts_rowdot2(const void* a, int a_dt, const void* b, int b_dt, float* out, int64_t M, int C, hipStream_t stream) {
+  CSTS_REQUIRE(a && b && out && M > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(rowdot2_kernel, dim3(grid_for(M * 32)), dim3(256), 0, stream, a, a_dt, b, b_dt, out, M, C);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_audio_attn_fwd(const void* qkv, int dt, float* audio_attn, float* wmap, int B, int T, int HW, int C, int H,
+                                   float scale, hipStream_t stream) {
+  CSTS_REQUIRE(qkv && wmap && B > 0 && T > 0 && HW > 0 && H > 0 && C % H == 0 && (C / H) % 8 == 0, "bad args");
+  const size_t smem = ((size_t)(C / H) + 2 * (HW + 1) + 8) * sizeof(float);
+  CSTS_REQUIRE(smem <= 64 * 1024, "frame too large for the audio-attention kernel");
+  hipLaunchKernelGGL(audio_attn_fwd_kernel, dim3(B * T), dim3(256), smem, stream, qkv, dt, audio_attn, wmap, T, HW, C, H, scale);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_audio_attn_bwd(const void* qkv, int dt, const float* d_wmap, void* dqkv, int B, int T, int HW, int C, int H,
+                                   float scale, hipStream_t stream) {
+  CSTS_REQUIRE(qkv && d_wmap && dqkv && B > 0 && T > 0 && HW > 0 && H > 0 && C % H == 0 && (C / H) % 8 == 0, "bad args");
+  const size_t smem = ((size_t)(C / H) + 2 * (HW + 1) + 8) * sizeof(float);
+  CSTS_REQUIRE(smem <= 64 * 1024, "frame too large for the audio-attention kernel");
+  hipLaunchKernelGGL(audio_attn_bwd_kernel, dim3(B * T), dim3(256), smem, stream, qkv, dt, d_wmap, dqkv, T, HW, C, H, scale);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

@@ -166,16 +166,13 @@ class Block(nn.Module):
                       row_scale=s_mlp, rows_per_scale=Nq, act_dt=rt.act_dt, out_dt=L.F32, compute=rt.compute,
                       w16_1=w16(self.mlp.fc1), w16_2=w16(self.mlp.fc2))
         extra = None
-        if want_attn or spatial_audio_attn:
+        if spatial_audio_attn:       # av_attention.py:360-370: (per-head rescaled audio->pixel map, its head mean per token)
+            T, HW = thw[0], thw[1] * thw[2]
+            wmap, aa = ops.audio_attn(qkv, T, HW, Cc, H)     # differentiable w.r.t. qkv (train mode back-propagates through it)
+            extra = (aa.reshape(B, H, T, thw[1], thw[2]), wmap)
+        elif want_attn:
             with torch.no_grad():
-                probs = ops.attention_probs(qkv.detach(), B, N, Cc, H, lse, mask_mode, mT, mHW)
-            if spatial_audio_attn:   # av_attention.py:360-370 (min-max rescaled audio->pixel attention)
-                T, HW = thw[0], thw[1] * thw[2]
-                aa = torch.stack([probs[:, :, T * HW + t, HW * t:HW * (t + 1)] for t in range(T)], dim=2)
-                amax, amin = aa.max(dim=-1, keepdim=True)[0], aa.min(dim=-1, keepdim=True)[0]
-                extra = ((aa - amin) / (amax - amin + 1e-8)).reshape(B, H, T, thw[1], thw[2])
-            else:
-                extra = probs
+                extra = ops.attention_probs(qkv.detach(), B, N, Cc, H, lse, mask_mode, mT, mHW)
         return out, q_thw, extra
 
 
@@ -408,9 +405,8 @@ class CSTS(nn.Module):
         x_spatial = av_sp[:, :Nv, :]
         # ---- temporal fusion (:435-451)
         x_t = xt
-        if self.spatial_audio_attn:
-            wmap = sp_extra.mean(dim=1).reshape(B, Nv, 1)       # (B, T, H, W) -> per-token weight
-            x_t = xt * wmap
+        if self.spatial_audio_attn:                             # :438-440
+            x_t = ops.row_weight(xt, sp_extra[1])
         x_tmp = ops.fusion_conv(x_t, self.vision_pool.weight, self.vision_pool.bias, Tn, HW, rt.act_dt, rt.compute)
         y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute)
         av_t = torch.cat([x_tmp, y_tmp], dim=1)
@@ -434,8 +430,8 @@ class CSTS(nn.Module):
             return logits
         if not return_embed:
             out = [logits]
-            if return_spatial_attn:
-                out.append(sp_extra)
+            if return_spatial_attn:     # with SPATIAL_AUDIO_ATTN the block yields the audio->pixel map instead (the reference
+                out.append(sp_extra[0] if isinstance(sp_extra, tuple) else sp_extra)   # raises NameError there, :485-491)
             if return_temporal_attn:
                 out.append(t_extra)
             return out

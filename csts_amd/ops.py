@@ -108,36 +108,76 @@ class HostTable:
 # Second stages of the cross-workgroup reductions of backward (LayerNorm dgamma/dbeta, stencil dweight): ~190 tiny
 # launches per step when done in line.  Inside a backward pass they are deferred instead: the first-stage kernels leave
 # their partial rows in a workspace, and ONE csts_reduce_rows_batched launch finishes all of them from an autograd final
-# callback (which runs on the caller's stream after the engine has joined every stream backward used).  The gradient
-# tensors handed to autograd are therefore complete when loss.backward() returns -- not before.
+# callback (which runs on the caller's stream after the engine has joined every stream backward used).
+#
+# A deferred gradient is NOT handed to autograd (an unfilled buffer would be adopted by AccumulateGrad only while the
+# parameter has no .grad yet, and be ADDED, garbage and all, when it has one: gradient accumulation, a module applied twice).
+# The Function returns None for that input; the final callback launches the finishing kernels and then hands every
+# finished tensor to its leaf parameter itself: p.grad = g, or p.grad += g when a gradient is already there.  Strong
+# references to operands, partial rows and results are held until then.
+#
+# The queues belong to ONE backward pass, identified by autograd's graph-task id: final callbacks are dropped when
+# backward raises, so a pass that finds another pass's leftovers discards them (stale device addresses) and registers
+# its own callback.
 _deferred = []          # (ws tensor, out tensor, nrows, ncols)
-_deferred_cb = [False]
+_assign = []            # (leaf parameter, finished gradient tensor)
+_deferred_task = [-1]   # graph-task id the queues belong to (-1: none)
 _deferred_tables = {}   # device index -> HostTable
 DEFER_REDUCTIONS = os.environ.get("CSTS_DEFER_REDUCE", "1") != "0"
 
 
-def _can_defer() -> bool:
+def reset_deferred():
+    """Drop everything queued for an end-of-backward flush (used when a backward pass died before its final callback)."""
+    _deferred.clear()
+    _assign.clear()
+    _wgq.clear()
+    _deferred_task[0] = -1
+
+
+def _can_defer(*params) -> bool:
+    """True when the caller may leave its gradient for the end-of-backward flush: inside a backward pass, and every
+    given parameter is a leaf the flush can assign to (None entries are ignored)."""
     if not DEFER_REDUCTIONS:
         return False
-    if not _deferred_cb[0]:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
-        except RuntimeError:          # not inside a backward pass
+    for p_ in params:
+        if p_ is not None and not (p_.is_leaf and p_.requires_grad):
             return False
-        _deferred_cb[0] = True
+    tid = torch._C._current_graph_task_id()
+    if tid < 0:                        # not inside a backward pass
+        return False
+    if _deferred_task[0] != tid:
+        reset_deferred()               # leftovers of a pass that raised before its callback ran
+        torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+        _deferred_task[0] = tid
     return True
 
 
-def _defer(ws: torch.Tensor, out, nrows: int, ncols: int):
-    """out: the tensor to fill, or its raw device address (see queue_wgrad for why no reference may be held)."""
+def _defer(ws: torch.Tensor, out: torch.Tensor, nrows: int, ncols: int):
     _deferred.append((ws, out, int(nrows), int(ncols)))
 
 
+def _assign_later(param, grad):
+    if param is not None and grad is not None:
+        _assign.append((param, grad))
+
+
+def _hand_over():
+    """Give the finished gradients to their parameters (stream-ordered after the finishing kernels)."""
+    for p_, g_ in _assign:
+        if p_.grad is None:
+            p_.grad = g_ if g_.dtype == p_.dtype else g_.to(p_.dtype)
+        else:
+            p_.grad.add_(g_)
+    _assign.clear()
+
+
 def flush_deferred():
-    """Finish the queued weight gradients and every deferred reduction on the current stream (idempotent)."""
-    _deferred_cb[0] = False
+    """Finish the queued weight gradients and every deferred reduction on the current stream, then hand the results to
+    their parameters (idempotent)."""
+    _deferred_task[0] = -1
     flush_wgrads()
     if not _deferred:
+        _hand_over()
         return
     # wide & shallow (split-K slabs) after narrow & deep (LayerNorm / stencil partial rows): two kernels
     wide = lambda it: it[3] >= 8192 and it[3] % 4 == 0 and it[2] <= 64
@@ -150,7 +190,7 @@ def flush_deferred():
     # one launch per size class (the grid is sized by the widest reduction of the launch)
     descs = (L.ReduceDesc * len(items))()
     for i, (ws, out, nrows, ncols) in enumerate(items):
-        descs[i].ws, descs[i].out = ws.data_ptr(), (out if isinstance(out, int) else out.data_ptr())
+        descs[i].ws, descs[i].out = ws.data_ptr(), out.data_ptr()
         descs[i].nrows, descs[i].ncols, descs[i].scale = nrows, ncols, 1.0
     raw = bytes(descs)
     sz = C.sizeof(L.ReduceDesc)
@@ -166,6 +206,8 @@ def flush_deferred():
         fn = _lib().csts_reduce_rows_wide if w else _lib().csts_reduce_rows_batched
         L.check(fn(base + lo * sz, hi - lo, items[hi - 1][3], _stream()), "csts_reduce_rows_batched")
         lo = hi
+    del items
+    _hand_over()
 
 
 # Weight gradients of the Linear layers (dW = dY^T X) are off the critical path of backward: inside a backward pass they
@@ -183,23 +225,23 @@ _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 _wg_tables = {}
 
 
-def queue_wgrad(dY, X, tokens, N, K, want_bias):
-    """Queue dW[N,K] = dY[tokens,N]^T X[tokens,K] (+ db[N]) for the grouped launch; returns (dW, db) to hand to autograd
-    now (complete when backward returns), or None when the problem has to run in line."""
+def queue_wgrad(dY, X, tokens, N, K, Wp, bp):
+    """Queue dW[N,K] = dY[tokens,N]^T X[tokens,K] (+ db[N] when bp is given) for the grouped launch at the end of this
+    backward pass, which also hands the results to the leaf parameters Wp / bp (see the note on deferred gradients
+    above).  Returns False when the problem has to run in line."""
     if GROUP_WGRADS == "never" or (GROUP_WGRADS == "capture" and not torch.cuda.is_current_stream_capturing()):
-        return None
+        return False
     if not (DEFER_REDUCTIONS and X.dtype == torch.bfloat16 and dY.dtype in (torch.float32, torch.bfloat16)
             and N % 8 == 0 and K % 8 == 0 and dY.is_contiguous() and X.is_contiguous() and tokens >= 256):
-        return None
-    if not _can_defer():
-        return None
+        return False
+    if Wp is None or Wp.dtype != torch.float32 or tuple(Wp.shape) != (N, K) or not _can_defer(Wp, bp):
+        return False
     dW = torch.empty(N, K, dtype=torch.float32, device=dY.device)
-    db = torch.empty(N, dtype=torch.float32, device=dY.device) if want_bias else None
-    # Only the ADDRESSES of dW / db are kept: autograd's AccumulateGrad adopts a gradient tensor as p.grad without a copy
-    # only while nobody else references it (a second reference would make it clone the still-empty buffer now).  The
-    # memory stays alive as p.grad until the grouped launch at the end of this backward pass.
-    _wgq.append((dY, X, dW.data_ptr(), (db.data_ptr() if db is not None else 0), tokens, N, K))
-    return dW, db
+    db = torch.empty(N, dtype=torch.float32, device=dY.device) if bp is not None else None
+    _wgq.append((dY, X, dW, db, tokens, N, K))
+    _assign_later(Wp, dW)
+    _assign_later(bp, db)
+    return True
 
 
 _WG_DTYPE = None
@@ -285,13 +327,13 @@ def flush_wgrads():
             A[i], B[i] = dY.data_ptr(), X.data_ptr()
             nch = -(-tokens // WGRAD_CHUNK)
             if nch == 1:
-                Cb[i], Cs[i] = dW, db
+                Cb[i], Cs[i] = dW.data_ptr(), (db.data_ptr() if db is not None else 0)
             else:          # several token chunks: one partial slab per chunk, summed by the batched reducer
                 slab = torch.empty(nch, N, K, dtype=torch.float32, device=dev)
                 _defer(slab, dW, nch, N * K)
                 Cb[i], cstride[i] = slab.data_ptr(), N * K * 4
                 cs = None
-                if db:
+                if db is not None:
                     cs = torch.empty(nch, N, dtype=torch.float32, device=dev)
                     _defer(cs, db, nch, N)
                     Cs[i], sstride[i] = cs.data_ptr(), N * 4
@@ -384,15 +426,14 @@ def _wgrad_split(M_out: int, N_out: int, Kred: int) -> int:
 
 
 def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: int, want_bias: bool = False,
-           allow_queue: bool = True):
+           params=None):
     """dW[N,K] = dY[M,N]^T X[M,K] (fp32, split over M); with want_bias also db[N] = colsum(dY), fused into the same
-    kernel when the bf16 v2 GEMM applies.  Inside a backward pass the problem is queued for the grouped end-of-backward
-    launch (queue_wgrad): the returned tensors are then complete when backward returns, NOT before -- callers that
-    post-process dW themselves pass allow_queue=False."""
-    if compute == BF16 and allow_queue:
-        queued = queue_wgrad(dY, X, M, N, K, want_bias)
-        if queued is not None:
-            return queued if want_bias else queued[0]
+    kernel when the bf16 v2 GEMM applies.  params = (W, b) leaf parameters: inside a backward pass the problem may then be
+    queued for the grouped end-of-backward launch, which assigns the gradients itself -- the return value is None (or
+    (None, None)) in that case and the caller returns None to autograd for those inputs."""
+    if compute == BF16 and params is not None:
+        if queue_wgrad(dY, X, M, N, K, params[0], params[1] if want_bias else None):
+            return (None, None) if want_bias else None
     split = _wgrad_split(N, K, M)
     det = split > 1 and _lib().csts_gemm_splitk_workspace(N, K, M, split) <= SPLITK_WS_LIMIT
     dW = (torch.zeros if (split > 1 and not det) else torch.empty)(N, K, dtype=torch.float32, device=dY.device)
@@ -407,8 +448,9 @@ def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: i
 BF16_GRAD_COPY = os.environ.get("CSTS_BF16_GRAD_COPY", "1") != "0"
 
 
-def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False):
-    """dx (+ addend) and the [2*C] dgamma|dbeta buffer; the second stage is deferred inside a backward pass.
+def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False, params=None):
+    """dx (+ addend) and the [2*C] dgamma|dbeta buffer.  params = (gamma, beta) leaf parameters: inside a backward pass
+    the second stage is then deferred and the flush assigns the two halves itself -- the returned buffer is None.
     want16: also emit a bf16 copy of dx, attached as dx._csts_bf16, for the weight/data-gradient GEMMs that read it next
     (LinearFn / MlpFn backward pick it up; any other consumer simply ignores the attribute)."""
     dx = torch.empty_like(x)
@@ -416,12 +458,15 @@ def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False)
     dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
     nbytes = _lib().csts_layernorm_bwd_workspace(rows, Cc)
     ws = _ws(nbytes, x.device)
-    defer = _can_defer()
+    defer = params is not None and _can_defer(*params)
     L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
                                       _p(addend), _p(dx16), None if defer else _p(dgb), None if defer else _p(dgb, Cc), _p(ws),
                                       ws.numel(), rows, Cc, _stream()), what)
     if defer:
         _defer(ws, dgb, nbytes // (2 * Cc * 4), 2 * Cc)
+        _assign_later(params[0], dgb[:Cc])
+        _assign_later(params[1], dgb[Cc:])
+        dgb = None
     if dx16 is not None:
         dx._csts_bf16 = dx16
     return dx, dgb
@@ -458,6 +503,7 @@ class LayerNormFn(Function):
         L.check(_lib().csts_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), out_dt, _p(mean), _p(rstd), rows, Cc,
                                           eps, _stream()), "csts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.params = (gamma, beta)
         ctx.set_materialize_grads(False)
         if passthrough:
             return y, x
@@ -476,7 +522,9 @@ class LayerNormFn(Function):
             if dpass.dtype != x.dtype:
                 dpass = dpass.to(x.dtype)
         dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd",
-                               want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16))
+                               want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16), params=ctx.params)
+        if dgb is None:                     # finished and assigned by the end-of-backward flush
+            return dx, None, None, None, None, None
         return dx, dgb[:Cc], dgb[Cc:], None, None, None
 
 
@@ -506,6 +554,7 @@ class LinearFn(Function):
              row_scale=row_scale, rows_per_scale=rows_per_scale)
         ctx.save_for_backward(x, Wop, row_scale)
         ctx.wdtype = W.dtype
+        ctx.params = (W, b)
         ctx.meta = (M, N, K, rows_per_scale, compute, b is not None, residual is not None,
                     residual.dtype if residual is not None else None)
         return y
@@ -526,10 +575,11 @@ class LinearFn(Function):
             gemm(L.GEMM_NN, dys, 0, N, W, 0, K, dx, K, M, K, N, compute=compute)
         if ctx.needs_input_grad[1]:
             if has_b and ctx.needs_input_grad[2]:
-                dW, db = _wgrad(dys, x, M, N, K, compute, want_bias=True)
+                dW, db = _wgrad(dys, x, M, N, K, compute, want_bias=True, params=ctx.params)
             else:
-                dW = _wgrad(dys, x, M, N, K, compute)
-            dW = dW.to(ctx.wdtype)
+                dW = _wgrad(dys, x, M, N, K, compute, params=(ctx.params[0], None))
+            if dW is not None:
+                dW = dW.to(ctx.wdtype)
         elif has_b and ctx.needs_input_grad[2]:
             db = colsum(dys, 1, M, N)
         if has_res and ctx.needs_input_grad[3]:
@@ -549,6 +599,7 @@ class MlpFn(Function):
     def forward(ctx, x, W1, b1, W2, b2, residual, row_scale, rows_per_scale: int, act_dt: int, out_dt: int, compute: int,
                 w16_1, w16_2):
         _need_gpu(x, W1, W2)
+        ctx.params = (W1, b1, W2, b2)
         if compute == BF16 and w16_1 is not None and w16_2 is not None:   # bf16 shadows of the fp32 master weights
             W1, W2 = w16_1, w16_2
         x = x.contiguous()
@@ -578,10 +629,11 @@ class MlpFn(Function):
             dys = scale_rows(dy, row_scale, rps, M, N, out_dt=BF16 if (compute == BF16 and BF16_GRAD_COPY) else None)
         else:
             dys = d16 if d16 is not None else dy
-        dW2, db2 = _wgrad(dys, g, M, N, Hd, compute, want_bias=True)
+        P1, pb1, P2, pb2 = ctx.params
+        dW2, db2 = _wgrad(dys, g, M, N, Hd, compute, want_bias=True, params=(P2, pb2))
         dh = torch.empty_like(h)
         gemm(L.GEMM_NN, dys, 0, N, W2, 0, Hd, dh, Hd, M, Hd, N, compute=compute, epilogue=L.EPI_DGELU, aux=h)
-        dW1, db1 = _wgrad(dh, x, M, Hd, K, compute, want_bias=True)
+        dW1, db1 = _wgrad(dh, x, M, Hd, K, compute, want_bias=True, params=(P1, pb1))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -616,9 +668,11 @@ def _ln_rows_fwd(c, gamma, beta, HD, act_dt):
     return y, mean, rstd
 
 
-def _ln_rows_bwd(dy, c, gamma, mean, rstd, HD):
+def _ln_rows_bwd(dy, c, gamma, mean, rstd, HD, params=None):
     rows = c.numel() // HD
-    dc, dgb = _ln_bwd_call(dy, c, gamma, mean, rstd, None, rows, HD, "csts_layernorm_bwd(head)")
+    dc, dgb = _ln_bwd_call(dy, c, gamma, mean, rstd, None, rows, HD, "csts_layernorm_bwd(head)", params=params)
+    if dgb is None:
+        return dc, None, None
     return dc, dgb[:HD], dgb[HD:]
 
 
@@ -716,6 +770,7 @@ class AttnInnerFn(Function):
         ctx.saved_slots = saved
         ctx.descr = (qd, kd, vd, Nq, Nk)
         ctx.save_for_backward(qkv, o, lse, wq, gq, wk, gk, wv, gv)
+        ctx.params = (wq, gq, bq, wk, gk, bk, wv, gv, bv)
         ctx.mark_non_differentiable(lse)
         ctx.set_materialize_grads(False)     # no zero-filled d(lse) tensor per backward
         return o, lse
@@ -766,13 +821,16 @@ class AttnInnerFn(Function):
 
         grads = {}
 
+        P = ctx.params                      # leaf parameters (wq, gq, bq, wk, gk, bk, wv, gv, bv)
+
         def pooled_bwd(slot, dy, w, gamma, transposed):
             c, mean, rstd, g = saved[slot]
-            dc, dg, db = _ln_rows_bwd(dy, c, gamma, mean, rstd, HD)
+            pw, pg, pb = P[3 * slot], P[3 * slot + 1], P[3 * slot + 2]
+            dc, dg, db = _ln_rows_bwd(dy, c, gamma, mean, rstd, HD, params=(pg, pb))
             wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
             wws = _ws(wsz, dev)
             dw = torch.empty(HD * 27, dtype=torch.float32, device=dev)
-            defer = _can_defer()
+            defer = _can_defer(pw)
             dwp = None if defer else _p(dw)
             if transposed:   # fine = dc (output side), coarse = qkv slot
                 L.check(lib.csts_dwconv_strided(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
@@ -784,9 +842,12 @@ class AttnInnerFn(Function):
                         "csts_dwconv_transposed(bwd)")
                 L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(dc), _dt(dc), dwp, _p(wws),
                                               wws.numel(), s), "csts_dwconv_wgrad")
+            dwv = dw.view(HD, 1, 3, 3, 3)
             if defer:
                 _defer(wws, dw, wsz // (HD * 27 * 4), HD * 27)
-            grads[slot] = (dw.view(HD, 1, 3, 3, 3), dg, db)
+                _assign_later(pw, dwv)
+                dwv = None
+            grads[slot] = (dwv, dg, db)
 
         def pooled_bwd_kv():
             """LayerNorm backward, transposed conv (data gradient) and stencil weight gradient of the k AND v pools,
@@ -797,7 +858,7 @@ class AttnInnerFn(Function):
             dgb = torch.empty(2, 2 * HD, dtype=torch.float32, device=dev)
             nbytes = lib.csts_layernorm_bwd_workspace(rows, HD)
             lws = _ws(2 * nbytes, dev)
-            defer = _can_defer()
+            defer = _can_defer(P[3], P[4], P[5], P[6], P[7], P[8])
             L.check(lib.csts_layernorm_bwd2(_p(dkv), _dt(dkv), _p(c2), _dt(c2), _p(gk), _p(gv), _p(mean2), _p(rstd2), _p(dc2),
                                             _dt(dc2), None if defer else _p(dgb[0]), None if defer else _p(dgb[1]), _p(lws),
                                             lws.numel(), rows, HD, s), "csts_layernorm_bwd2")
@@ -819,7 +880,13 @@ class AttnInnerFn(Function):
                 _defer(wws[:wsz], dw[0], nrow, HD * 27)
                 _defer(wws[wsz:], dw[1], nrow, HD * 27)
             for i, slot in enumerate((1, 2)):
-                grads[slot] = (dw[i].view(HD, 1, 3, 3, 3), dgb[i, :HD], dgb[i, HD:])
+                gw, gg, gb = dw[i].view(HD, 1, 3, 3, 3), dgb[i, :HD], dgb[i, HD:]
+                if defer:
+                    _assign_later(P[3 * slot], gw)
+                    _assign_later(P[3 * slot + 1], gg)
+                    _assign_later(P[3 * slot + 2], gb)
+                    gw = gg = gb = None
+                grads[slot] = (gw, gg, gb)
 
         if 0 in saved:
             pooled_bwd(0, tq[0], wq, gq, kind == "dec")
@@ -855,6 +922,84 @@ def attention_probs(qkv, B, N, Cc, H, lse, mask_mode, mask_T, mask_HW):
     a.mask_mode, a.mask_T, a.mask_HW = mask_mode, mask_T, mask_HW
     L.check(_lib().csts_attn_probs(C.byref(a), _p(probs), _stream()), "csts_attn_probs")
     return probs
+
+
+class AudioAttnFn(Function):
+    """Per-token weight from the audio -> pixel attention of the spatial fusion block (MVIT.SPATIAL_AUDIO_ATTN):
+    av_attention.py:356-370 (probabilities of audio token t over frame t's video tokens, min-max rescaled per head) and the
+    head mean of custom_multimodal_builder.py:438.  Differentiable w.r.t. the block's qkv projection (the reference
+    back-propagates through the rescaled map in train mode).  Returns (wmap (B, T*HW), audio_attn (B, H, T, HW))."""
+
+    @staticmethod
+    def forward(ctx, qkv, T: int, HW: int, Cc: int, H: int):
+        _need_gpu(qkv)
+        qkv = qkv.contiguous()
+        B = qkv.shape[0]
+        if qkv.shape[1] != T * HW + T or qkv.shape[2] != 3 * Cc:
+            raise L.CstsError(f"audio_attn: qkv {tuple(qkv.shape)} is not (B, {T * HW + T}, {3 * Cc})")
+        aa = torch.empty(B, H, T, HW, dtype=torch.float32, device=qkv.device)
+        wmap = torch.empty(B, T * HW, dtype=torch.float32, device=qkv.device)
+        scale = (Cc // H) ** -0.5
+        L.check(_lib().csts_audio_attn_fwd(_p(qkv), _dt(qkv), _p(aa), _p(wmap), B, T, HW, Cc, H, scale, _stream()),
+                "csts_audio_attn_fwd")
+        ctx.save_for_backward(qkv)
+        ctx.meta = (B, T, HW, Cc, H, scale)
+        ctx.mark_non_differentiable(aa)
+        ctx.set_materialize_grads(False)
+        return wmap, aa
+
+    @staticmethod
+    def backward(ctx, dwmap, _daa):
+        (qkv,) = ctx.saved_tensors
+        B, T, HW, Cc, H, scale = ctx.meta
+        if dwmap is None:
+            return None, None, None, None, None
+        dwmap = dwmap.contiguous().float()
+        dqkv = torch.zeros_like(qkv)
+        L.check(_lib().csts_audio_attn_bwd(_p(qkv), _dt(qkv), _p(dwmap), _p(dqkv), B, T, HW, Cc, H, scale, _stream()),
+                "csts_audio_attn_bwd")
+        return dqkv, None, None, None, None
+
+
+def audio_attn(qkv, T, HW, Cc, H):
+    return AudioAttnFn.apply(qkv, int(T), int(HW), int(Cc), int(H))
+
+
+class RowWeightFn(Function):
+    """x (B, N, C) * w (B, N)[:, :, None]  (x_temporal * audio_attn, custom_multimodal_builder.py:439-440)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_gpu(x, w)
+        x = x.contiguous()
+        w = w.contiguous().float()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        if w.numel() != M:
+            raise L.CstsError("row_weight: one weight per row expected")
+        y = torch.empty_like(x)
+        L.check(_lib().csts_scale_rows(_p(x), _dt(x), _p(w), 1, _p(y), _dt(y), M, Cc, _stream()), "csts_scale_rows")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            L.check(_lib().csts_scale_rows(_p(dy), _dt(dy), _p(w), 1, _p(dx), _dt(dx), M, Cc, _stream()), "csts_scale_rows(bwd)")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(w.shape, dtype=torch.float32, device=x.device)
+            L.check(_lib().csts_rowdot2(_p(dy), _dt(dy), _p(x), _dt(x), _p(dw), M, Cc, _stream()), "csts_rowdot2")
+        return dx, dw
+
+
+def row_weight(x, w):
+    return RowWeightFn.apply(x, w)
 
 
 # ----------------------------------------------------------------------------------------- resampling
@@ -975,7 +1120,7 @@ class PatchEmbedFn(Function):
         B, N, T, HW, Cout, K, Kpad, compute, wshape = ctx.meta
         dy = dy.contiguous()
         M = B * N
-        dWp = _wgrad(dy, col, M, Cout, Kpad, compute, allow_queue=False)
+        dWp = _wgrad(dy, col, M, Cout, Kpad, compute)
         dW = dWp[:, :K].reshape(wshape)
         db = colsum(dy, 1, M, Cout)
         dpos = colsum(dy, 1, B, N * Cout)                       # sum over batch -> (N*Cout)

@@ -196,6 +196,19 @@ int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void* out, int 
 int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
                     int64_t M, int64_t N, hipStream_t stream);   /* drop-path backward (common.py:46-59) */
 
+int csts_rowdot2(const void* a, int a_dt, const void* b, int b_dt, float* out, int64_t M, int C,
+                 hipStream_t stream);   /* out[m] = <a[m,:], b[m,:]>: gradient of a per-row weight */
+
+/* ---- audio -> pixel attention map of the spatial fusion block (MVIT.SPATIAL_AUDIO_ATTN: av_attention.py:356-370
+ *      min-max-rescaled probabilities of audio token t over the HW video tokens of frame t, per head; averaged over the
+ *      heads into the per-token weight of custom_multimodal_builder.py:438-440).  qkv = the block's (B, T*HW + T, 3C) QKV
+ *      projection; audio_attn (optional) = (B, H, T, HW) per-head maps; wmap = (B, T*HW).  The backward writes
+ *      d(q of the audio tokens) and d(k) into a ZERO-INITIALISED buffer shaped like qkv. */
+int csts_audio_attn_fwd(const void* qkv, int dt, float* audio_attn, float* wmap, int B, int T, int HW, int C, int H,
+                        float scale, hipStream_t stream);
+int csts_audio_attn_bwd(const void* qkv, int dt, const float* d_wmap, void* dqkv, int B, int T, int HW, int C, int H,
+                        float scale, hipStream_t stream);
+
 /* ---- fusion glue (custom_multimodal_builder.py:454-461 re-weighting, :493-494 token mean) */
 int csts_reweight_fwd(const float* x, const float* w, float* y, int64_t BT, int HW, int C, hipStream_t stream);
 int csts_reweight_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, int64_t BT, int HW, int C,

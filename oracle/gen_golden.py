@@ -365,6 +365,71 @@ def gen_model_t32():
          logits_head=t2n(lg).reshape(-1)[:4096].astype(np.float32))
 
 
+def _train_fixture(m, batch, names, alpha=0.05):
+    """Eval-mode (no drop-path) forward + KLDiv + alpha * EgoNCE + backward of the reference model: the quantities the
+    GPU train-step parity tests compare (tools/train_avgaze_net.py:70-99)."""
+    logits, v, a = m([batch["video"]], batch["audio"], return_embed=True)
+    p = ref_utils.frame_softmax(logits, temperature=2)
+    kld = ref_losses.KLDiv()(p, batch["labels_hm"])
+    nce = ref_losses.EgoNCE()(ref_utils.sim_matrix(v, a))
+    loss = kld + alpha * nce
+    m.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    gnorm = [float(named[n].grad.double().norm()) for n in names]
+    total = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m.parameters() if p_.grad is not None)))
+    gslice = {n.replace(".", "_") + "_g": t2n(named[n].grad.flatten()[:64]) for n in names}
+    B, T = p.shape[0], p.shape[2]
+    out = dict(logits=t2n(logits).astype(np.float16), logits_head=t2n(logits).reshape(-1)[:4096].astype(np.float32),
+               v_emb=t2n(v), a_emb=t2n(a), argmax=t2n(p.reshape(B, T, -1).argmax(-1)).astype(np.int32),
+               heat_head=t2n(p).reshape(-1)[:4096].astype(np.float32), kld=t2n(kld), nce=t2n(nce), loss=t2n(loss),
+               grad_names=np.array(names), grad_norms=np.array(gnorm), grad_total_norm=total, **gslice)
+    return out
+
+
+def gen_train_t16():
+    """The BENCHMARKED token grid (16 x 256^2): B = 2 train fixture (loss, KLDiv, EgoNCE, 28 gradient norms + slices,
+    total norm), same recipe as gen_model."""
+    m = load_seeded(CSTS(make_cfg(16))).eval()
+    batch = O.synthetic_batch(2, 16, 256, seed=1004)
+    save("model_T16_B2_train.npz", **_train_fixture(m, batch, GRAD_NAMES))
+
+
+T32_GRAD_NAMES = [
+    "pos_embed_temporal", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "blocks.1.attn.pool_k.weight",
+    "blocks.3.mlp.fc1.weight", "blocks.14.attn.proj.weight", "blocks_audio.2.attn.norm_k.weight", "vision_pool.weight",
+    "spatial_fusion.attn.qkv.weight", "decode_block2.attn.upsample_q.weight", "decode_block4.mlp.fc2.weight",
+    "classifier.weight",
+]
+
+
+def gen_train_t32():
+    """BASELINE config 5 geometry (Aria YAML + DATA.NUM_FRAMES 32): B = 1 forward + backward (EgoNCE is identically 0 at
+    B = 1): loss + 12 gradient norms + slices -- the path with multi-tile keys (N_kv = 4096)."""
+    cfg = get_cfg()
+    cfg.merge_from_file("/root/reference/configs/Aria/CSTS_Aria_Gaze_Forecast.yaml")
+    cfg.NUM_GPUS = 0
+    cfg.MODEL.LOSS_FUNC = "kldiv+egonce"
+    cfg.DATA.NUM_FRAMES = 32
+    m = load_seeded(CSTS(cfg)).eval()
+    batch = O.synthetic_batch(1, 32, 256, seed=1003)
+    save("model_T32_B1_aria_train.npz", **_train_fixture(m, batch, T32_GRAD_NAMES))
+
+
+SAA_GRAD_NAMES = ["spatial_fusion.attn.qkv.weight", "spatial_fusion.attn.qkv.bias", "spatial_fusion.norm1.weight",
+                  "audio_pool.weight", "vision_pool.weight", "blocks.15.mlp.fc2.weight", "blocks_audio.3.mlp.fc2.weight",
+                  "decode_block1.attn.qkv.weight", "classifier.weight"]
+
+
+def gen_train_saa():
+    """MVIT.SPATIAL_AUDIO_ATTN True in TRAIN use: the gradient that flows through the min-max-rescaled audio->pixel
+    attention map (av_attention.py:356-370 -> custom_multimodal_builder.py:438-440), T = 8, B = 2."""
+    cfg = make_cfg(8, [("MVIT.SPATIAL_AUDIO_ATTN", True)])
+    m = load_seeded(CSTS(cfg)).eval()
+    batch = O.synthetic_batch(2, 8, 256, seed=1005)
+    save("model_T8_B2_saa_train.npz", **_train_fixture(m, batch, SAA_GRAD_NAMES))
+
+
 def gen_metrics():
     """adaptive_f1 of the reference (slowfast/utils/metrics.py) on seeded heat maps, all three threshold tables."""
     from slowfast.utils import metrics as ref_metrics
@@ -458,3 +523,9 @@ if __name__ == "__main__":
         gen_model()
     if "model" in what or "t32" in what:
         gen_model_t32()
+    if "train16" in what:
+        gen_train_t16()
+    if "train32" in what:
+        gen_train_t32()
+    if "trainsaa" in what:
+        gen_train_saa()

@@ -99,8 +99,9 @@ def test_block_decoder_and_fusion_fixtures():
         xs = torch.from_numpy(f["xs"]).to(DEV)
         ys, _, attn = blk(xs, [2, 2, 2], want_attn=True)
         assert rel_l2(ys, f["ys"]) < 3e-5 and rel_l2(attn, f["attn_s"]) < 1e-4
-        ys2, _, aa = blk(xs, [2, 2, 2], spatial_audio_attn=True)
+        ys2, _, (aa, wmap) = blk(xs, [2, 2, 2], spatial_audio_attn=True)
         assert rel_l2(ys2, f["ys2"]) < 3e-5 and rel_l2(aa, f["audio_attn"]) < 1e-3
+        assert rel_l2(wmap, f["audio_attn"].mean(axis=1).reshape(2, -1)) < 1e-3
         st = O.BlockSpec("t", "temporal", 192, 192, 2, (1, 1, 1), (1, 1, 1), False, False, 768)
         yt, _, at = _block_from_spec(st, "tp.")(torch.from_numpy(f["xt"]).to(DEV), (2, 2, 2), want_attn=True)
         assert rel_l2(yt, f["yt"]) < 3e-5 and rel_l2(at, f["attn_t"]) < 1e-4
@@ -234,6 +235,166 @@ def test_T32_aria_forward_fp32_and_bf16():
             assert (heat.reshape(32, -1).argmax(-1).cpu().numpy() == g["argmax"]).all()
         del m
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ train-step parity
+def _cos(a, b):
+    a, b = torch.as_tensor(a).double().flatten().cpu(), torch.as_tensor(b).double().flatten().cpu()
+    return float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+def _train_pass(m, cfg, batch):
+    for p in m.parameters():
+        p.grad = None
+    loss, kld, nce, preds = T.compute_loss(cfg, m, batch["video"], batch["audio"], batch["labels_hm"])
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss, kld, nce, preds.detach()
+
+
+def _check_train_fixture(m, g, loss, kld, nce, preds, *, loss_tol, norm_tol, slice_tol=None, cos_min=None, total_tol,
+                         argmax_min=1.0, label=""):
+    B, Tn = preds.shape[0], preds.shape[2]
+    ref_loss, ref_kld, ref_nce = float(g["loss"]), float(g["kld"]), float(g["nce"])
+    agree = float((preds.reshape(B, Tn, -1).argmax(-1).cpu().numpy() == g["argmax"]).mean())
+    named = dict(m.named_parameters())
+    worst_norm, worst_cos, worst_slice = 0.0, 1.0, 0.0
+    for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if n == "classifier.bias":           # softmax is shift-invariant: the true gradient is 0 (rounding noise only)
+            continue
+        gr = named[n].grad
+        assert gr is not None, n
+        if ref_norm == 0.0:                  # EgoNCE branch at B = 1: identically zero in the reference too
+            assert float(gr.double().norm()) < 1e-6, n
+            continue
+        err = abs(float(gr.double().norm()) - ref_norm) / ref_norm
+        worst_norm = max(worst_norm, err)
+        assert err <= norm_tol, (label, n, float(gr.double().norm()), ref_norm)
+        ref_slice = g[n.replace(".", "_") + "_g"]
+        sl = gr.flatten()[:ref_slice.size]
+        if slice_tol is not None:
+            e = rel_l2(sl, ref_slice)
+            worst_slice = max(worst_slice, e)
+            assert e < slice_tol, (label, n, e)
+        if cos_min is not None:
+            c = _cos(sl, ref_slice)
+            worst_cos = min(worst_cos, c)
+            assert c >= cos_min, (label, n, c)
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    ref_total = float(g["grad_total_norm"])
+    print(f"\n[{label}] loss {float(loss):.6f} (ref {ref_loss:.6f})  kld {float(kld):.6f}/{ref_kld:.6f}  nce {float(nce):.5f}/{ref_nce:.5f}  "
+          f"argmax agreement {agree:.3f}  worst grad-norm err {worst_norm:.2e}  worst slice rel-L2 {worst_slice:.2e}  "
+          f"worst slice cosine {worst_cos:.5f}  total-norm err {abs(total - ref_total) / ref_total:.2e}")
+    assert abs(float(loss) - ref_loss) <= loss_tol * abs(ref_loss)
+    assert abs(float(kld) - ref_kld) <= loss_tol * max(abs(ref_kld), 1e-3)
+    assert abs(float(nce) - ref_nce) <= max(10 * loss_tol * abs(ref_nce), 1e-3)
+    assert abs(total - ref_total) <= total_tol * ref_total
+    assert agree >= argmax_min, (label, agree)
+
+
+def test_train_T16_fp32_vs_reference_golden():
+    """The BENCHMARKED token grid (16x256^2), fp32 mode, B=2: loss / KLDiv / EgoNCE / 27 gradient norms + slices / total
+    norm against the fixture generated by the imported reference (tools/train_avgaze_net.py:70-99)."""
+    m, cfg = make_model("fp32", 16)
+    g = _load("model_T16_B2_train.npz")
+    loss, kld, nce, preds = _train_pass(m, cfg, dev_batch(2, 16, 1004))
+    assert rel_l2(preds.flatten()[:4096], g["heat_head"]) < 1e-4
+    _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-4, norm_tol=2e-3, slice_tol=5e-3, total_tol=1e-3,
+                         argmax_min=1.0, label="fp32 T16 B2")
+
+
+@pytest.mark.parametrize("T_,fixture,seed", [(8, "model_T8_B2.npz", 1000), (16, "model_T16_B2_train.npz", 1004)])
+def test_train_bf16_vs_reference_golden(T_, fixture, seed):
+    """bf16 mode (the benchmarked one) at MODEL level, forward AND backward, against the reference fixture.  Stated bars:
+    |loss - ref| / ref < 1e-2, per-tensor gradient-norm error < 5e-2, cosine >= 0.99 on the stored gradient slices,
+    total gradient norm within 2e-2, per-frame argmax agreement >= 0.95 (bf16 operands, fp32 accumulation / residual
+    stream / statistics / softmax / losses: what torch.autocast gives the reference)."""
+    m, cfg = make_model("bf16", T_)
+    g = _load(fixture)
+    loss, kld, nce, preds = _train_pass(m, cfg, dev_batch(2, T_, seed))
+    _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-2, norm_tol=5e-2, cos_min=0.99, total_tol=2e-2,
+                         argmax_min=0.95, label=f"bf16 T{T_} B2")
+
+
+def test_train_T32_aria_vs_reference_golden():
+    """BASELINE config 5 geometry as a TRAIN step on one GPU: CSTS_Aria_Gaze_Forecast.yaml + DATA.NUM_FRAMES 32, B=1
+    (N_kv = 4096: multi-tile keys, query splits, the dK/dV split reduction); fp32 gradients against the reference
+    fixture, then the same step in bf16 mode with its stated bars; peak memory printed."""
+    aria = os.path.join(os.path.dirname(YAML), "..", "Aria", "CSTS_Aria_Gaze_Forecast.yaml")
+    g = _load("model_T32_B1_aria_train.npz")
+    b = dev_batch(1, 32, 1003)
+    for compute in ("fp32", "bf16"):
+        cfg = load_yaml(aria, ["NUM_GPUS", 1, "MODEL.LOSS_FUNC", "kldiv+egonce", "DATA.NUM_FRAMES", 32, "CSTS_AMD.COMPUTE", compute])
+        _MODELS.clear()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        m = build_model(cfg)
+        m.load_state_dict(O.seeded_params(32, 256), strict=True)
+        m.eval()
+        loss, kld, nce, preds = _train_pass(m, cfg, b)
+        print(f"\n[{compute} T32 B1] peak device memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
+        if compute == "fp32":
+            _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-4, norm_tol=2e-3, slice_tol=5e-3, total_tol=1e-3,
+                                 argmax_min=1.0, label="fp32 T32 B1 aria")
+        else:
+            _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-2, norm_tol=5e-2, cos_min=0.99, total_tol=2e-2,
+                                 argmax_min=0.9, label="bf16 T32 B1 aria")
+        del m
+    torch.cuda.empty_cache()
+
+
+def test_spatial_audio_attn_train_gradient_fp32():
+    """MVIT.SPATIAL_AUDIO_ATTN in TRAIN use: the gradient through the min-max-rescaled audio->pixel attention map
+    (av_attention.py:356-370 -> custom_multimodal_builder.py:438-440) against the reference fixture."""
+    m, cfg = make_model("fp32", 8, ("MVIT.SPATIAL_AUDIO_ATTN", True))
+    g = _load("model_T8_B2_saa_train.npz")
+    loss, kld, nce, preds = _train_pass(m, cfg, dev_batch(2, 8, 1005))
+    _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-4, norm_tol=2e-3, slice_tol=5e-3, total_tol=1e-3,
+                         argmax_min=1.0, label="fp32 T8 B2 spatial-audio-attn")
+
+
+def test_gradient_accumulation_and_failed_backward():
+    """Deferred end-of-backward gradients (grouped weight gradients, LayerNorm / stencil second stages): (a) a second
+    backward ACCUMULATES into existing .grad (2 x the single-pass gradient); (b) after a backward pass that raises, the
+    next pass still produces complete, correct gradients (the dead pass's queues are discarded)."""
+    m, cfg = make_model("bf16")
+    batch = T.synthetic_batch(2, 8, 256, 31, DEV)
+    old_mode, ops.GROUP_WGRADS = ops.GROUP_WGRADS, "always"
+    try:
+        _train_pass(m, cfg, batch)
+        ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+        loss, *_ = T.compute_loss(cfg, m, batch["video"], batch["audio"], batch["labels_hm"])
+        loss.backward()                       # no zero_grad in between: accumulate
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, 2 * ref[n], rtol=1e-5, atol=1e-8), n
+
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+
+        for p in m.parameters():
+            p.grad = None
+        orig_pe = ops.patch_embed             # raise LATE in backward (just before the patch-embed nodes): by then the
+        ops.patch_embed = lambda *a_, **k_: Boom.apply(orig_pe(*a_, **k_))   # queues hold the whole trunk's deferred work
+        try:
+            bad, *_ = T.compute_loss(cfg, m, batch["video"], batch["audio"], batch["labels_hm"])
+        finally:
+            ops.patch_embed = orig_pe
+        with pytest.raises(RuntimeError, match="boom"):
+            bad.backward()
+        torch.cuda.synchronize()
+        _train_pass(m, cfg, batch)
+        for n, p in m.named_parameters():
+            assert p.grad is not None and torch.equal(p.grad, ref[n]), n
+    finally:
+        ops.GROUP_WGRADS = old_mode
+        ops.reset_deferred()
 
 
 def test_train_step_runs_bf16_b4():

@@ -617,3 +617,43 @@ def test_input_pipeline_on_device():
     assert torch.allclose(hm.sum(dim=(-1, -2)), torch.ones(B, T), atol=1e-5)
     batch = I.assemble_batch(fr.to(DEV), wav.to(DEV), idx.to(DEV), 90.0, labels.to(DEV))
     assert batch["video"].shape == (B, 3, T, 32, 48) and batch["audio"].shape == (B, 1, T, 256, 256)
+
+
+# ------------------------------------------------------------------------------------------------ audio -> pixel attention
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-5)])
+@pytest.mark.parametrize("B,T,HW,C,H", [(2, 4, 64, 768, 8), (1, 2, 4, 192, 2), (2, 3, 49, 384, 2)])
+def test_audio_attn_forward_backward(dt, tol, B, T, HW, C, H):
+    """csts_audio_attn_{fwd,bwd} + csts_rowdot2 (MVIT.SPATIAL_AUDIO_ATTN: av_attention.py:356-370 and
+    custom_multimodal_builder.py:438-440) against the same computation in plain fp32 torch ops with the reference's
+    additive -1e8 mask, autograd for the gradient.  Both sides read the same (possibly bf16-rounded) qkv values."""
+    N = T * HW + T
+    hd = C // H
+    qkv = rnd(B, N, 3 * C, seed=5, scale=1.5).to(dt)
+    x = rnd(B, T * HW, C, seed=6)
+    gy = rnd(B, T * HW, C, seed=7)
+    # ---- torch reference
+    qr = qkv.float().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    q4 = qr.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    off = torch.full((N, N), 1e8, device=DEV)
+    for t in range(T):
+        off[HW * t:HW * (t + 1), HW * t:HW * (t + 1)] = 0
+        off[HW * t:HW * (t + 1), T * HW + t] = 0
+        off[T * HW + t, HW * t:HW * (t + 1)] = 0
+        off[T * HW + t, T * HW + t] = 0
+    attn = ((q4[0] @ q4[1].transpose(-2, -1)) * hd ** -0.5 - off).softmax(dim=-1)
+    aa = torch.stack([attn[:, :, T * HW + t, HW * t:HW * (t + 1)] for t in range(T)], dim=2)
+    resc = (aa - aa.min(dim=-1, keepdim=True)[0]) / (aa.max(dim=-1, keepdim=True)[0] - aa.min(dim=-1, keepdim=True)[0] + 1e-8)
+    y_ref = xr * resc.mean(dim=1).reshape(B, T * HW, 1)
+    y_ref.backward(gy)
+    # ---- HIP
+    qh = qkv.clone().requires_grad_(True)
+    xh = x.clone().requires_grad_(True)
+    wmap, aah = ops.audio_attn(qh, T, HW, C, H)
+    y = ops.row_weight(xh, wmap)
+    y.backward(gy)
+    assert rel_l2(aah, resc.detach()) < 1e-4 and rel_l2(y, y_ref.detach()) < 1e-4
+    assert rel_l2(xh.grad, xr.grad) < 1e-4
+    gq = qh.grad.float()
+    assert torch.count_nonzero(gq[:, :, 2 * C:]) == 0 and torch.count_nonzero(gq[:, :T * HW, :C]) == 0   # v and video-q untouched
+    assert rel_l2(gq, qr.grad) < (1e-3 if dt == torch.float32 else 2e-2)      # bf16: the gradient itself is stored in bf16

@@ -225,6 +225,51 @@ def test_T32_aria_forward():
     assert (heat.reshape(32, -1).argmax(-1).numpy() == g["argmax"]).all()
 
 
+def _oracle_train(T_, B, seed, saa=False):
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    P = {k: v.requires_grad_(True) for k, v in O.seeded_params(T_, 256).items()}
+    batch = O.synthetic_batch(B, T_, 256, seed=seed)
+    logits, v, a = O.csts_forward(P, batch["video"], batch["audio"], T_, 256, return_embed=True, spatial_audio_attn=saa)
+    loss, kld, nce = O.csts_loss(logits, v, a, batch["labels_hm"], 0.05)
+    loss.backward()
+    return P, logits.detach(), loss, kld, nce
+
+
+def _check_oracle_train(g, P, logits, loss, kld, nce, slice_tol=5e-4):
+    B, T_ = logits.shape[0], logits.shape[2]
+    heat = O.frame_softmax(logits, 2.0)
+    assert rel_l2(logits.reshape(-1)[:4096], g["logits_head"]) < TOL and rel_l2(heat.reshape(-1)[:4096], g["heat_head"]) < TOL
+    assert (heat.reshape(B, T_, -1).argmax(-1).numpy() == g["argmax"]).all()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * max(1, abs(float(g["loss"])))
+    assert abs(float(kld) - float(g["kld"])) < 1e-5 * max(1, abs(float(g["kld"]))) and abs(float(nce) - float(g["nce"])) < 1e-4
+    for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        gn = float(P[n].grad.double().norm())
+        if n == "classifier.bias" or ref_norm == 0.0:
+            assert gn < 1e-6
+            continue
+        assert abs(gn - ref_norm) <= 2e-4 * ref_norm, (n, gn, ref_norm)
+        assert rel_l2(P[n].grad.flatten()[:64], g[n.replace(".", "_") + "_g"]) < slice_tol, n
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in P.values() if p.grad is not None)))
+    assert abs(total - float(g["grad_total_norm"])) < 2e-4 * float(g["grad_total_norm"])
+
+
+def test_train_T16_B2_benchmarked_grid():
+    """The benchmarked token grid (16x256^2): oracle loss and gradients == the reference's (fixture from gen_train_t16)."""
+    _check_oracle_train(_load("model_T16_B2_train.npz"), *_oracle_train(16, 2, 1004))
+
+
+def test_train_spatial_audio_attn_gradient():
+    """MVIT.SPATIAL_AUDIO_ATTN train step: gradient through the rescaled audio->pixel attention (gen_train_saa)."""
+    _check_oracle_train(_load("model_T8_B2_saa_train.npz"), *_oracle_train(8, 2, 1005, saa=True))
+
+
+def test_train_T32_aria_B1():
+    """BASELINE config 5 geometry, forward + backward (gen_train_t32)."""
+    # 64-element slices of gradients reduced over up to 131 k tokens in fp32: the fixture was generated with one thread, this
+    # run uses all cores (another summation order) -> 1e-3 on the smallest slices; norms stay within 2e-4
+    _check_oracle_train(_load("model_T32_B1_aria_train.npz"), *_oracle_train(32, 1, 1003), slice_tol=3e-3)
+
+
 def test_adaptive_f1_metric():
     """slowfast/utils/metrics.py:9-74 on reference-generated fixtures (three threshold tables, untracked frames)."""
     g = _load("metrics_f1.npz")
