@@ -319,6 +319,26 @@ __global__ __launch_bounds__(256) void axpby_kernel(const void* __restrict__ a, 
     st_from_f32(out, o_dt, i, v);
   }
 }
+// out = a + b in fp32 and, optionally, its bf16 copy (gradient of a residual-stream tensor with two consumers); 4 per thread
+__global__ __launch_bounds__(256) void add2_kernel(const void* __restrict__ a, int a_dt, const void* __restrict__ b, int b_dt,
+                                                   float* __restrict__ out, bf16* __restrict__ out16, int64_t total) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    float v[4];
+    if (i + 4 <= total && a_dt == CSTS_F32 && b_dt == CSTS_F32) {
+      const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a) + i);
+      const float4 y = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(b) + i);
+      v[0] = x.x + y.x; v[1] = x.y + y.y; v[2] = x.z + y.z; v[3] = x.w + y.w;
+      *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+      if (out16) { const bf16x4 w = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *reinterpret_cast<bf16x4*>(out16 + i) = w; }
+    } else {
+      for (int j = 0; j < 4 && i + j < total; ++j) {
+        const float s_ = ld_as_f32(a, a_dt, i + j) + ld_as_f32(b, b_dt, i + j);
+        out[i + j] = s_;
+        if (out16) out16[i + j] = (bf16)s_;
+      }
+    }
+  }
+}
 // out[m,n] = x[m,n] * row_scale[m / rows_per_scale]   (backward of the drop-path scaling, common.py:46-59)
 __global__ __launch_bounds__(256) void scale_rows_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ rs,
                                                          int64_t rows_per_scale, void* __restrict__ out, int o_dt,
@@ -707,6 +727,16 @@ extern "C" int csts_audio_attn_bwd(const void* qkv, int dt, const float* d_wmap,
   const size_t smem = ((size_t)(C / H) + 2 * (HW + 1) + 8) * sizeof(float);
   CSTS_REQUIRE(smem <= 64 * 1024, "frame too large for the audio-attention kernel");
   hipLaunchKernelGGL(audio_attn_bwd_kernel, dim3(B * T), dim3(256), smem, stream, qkv, dt, d_wmap, dqkv, T, HW, C, H, scale);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int csts_add2(const void* a, int a_dt, const void* b, int b_dt, float* out, void* out_bf16, int64_t n, hipStream_t stream) {
+  CSTS_REQUIRE(a && b && out && n > 0, "bad args");
+  CSTS_REQUIRE((aligned16(a) && aligned16(b) && aligned16(out) && (!out_bf16 || (reinterpret_cast<uintptr_t>(out_bf16) & 7) == 0)),
+               "operands must be 16-byte aligned");
+  hipLaunchKernelGGL(add2_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, a, a_dt, b, b_dt, out,
+                     reinterpret_cast<bf16*>(out_bf16), n);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

@@ -364,7 +364,10 @@ class CSTS(nn.Module):
                              self.pos_embed_temporal_audio, pa.kernel, pa.stride, pa.padding, rt.act_dt, rt.compute)
         T, H, W = self.patch_dims
         thw, thw_a = [T, H, W], [T, H, W]
-        inter = [(xt, thw)]
+        # encoder features the decoder re-uses (:384,389,396,403): each goes through ops.tap, so that its two gradients
+        # (next block + decoder skip) meet in one kernel that also leaves the bf16 copy the next GEMMs read
+        xt, keep = ops.tap(xt, rt.compute)
+        inter = [(keep, thw)]
 
         def run(t, shape, blocks, names):
             for blk, nm in zip(blocks, names):
@@ -384,9 +387,10 @@ class CSTS(nn.Module):
             yt.record_stream(side)      # allocated on `main`, read on `side`: keep the allocator from recycling it early
             with torch.cuda.stream(side):
                 yt, thw_a = run(yt, thw_a, ab, an)
-        xt, thw = run(xt, thw, vb[:1], vn[:1]); inter.append((xt, thw))
-        xt, thw = run(xt, thw, vb[1:3], vn[1:3]); inter.append((xt, thw))
-        xt, thw = run(xt, thw, vb[3:14], vn[3:14]); inter.append((xt, thw))
+        for lo, hi in ((0, 1), (1, 3), (3, 14)):
+            xt, thw = run(xt, thw, vb[lo:hi], vn[lo:hi])
+            xt, keep = ops.tap(xt, rt.compute)
+            inter.append((keep, thw))
         xt, thw = run(xt, thw, vb[14:], vn[14:])
         if side is not None:
             main.wait_stream(side)

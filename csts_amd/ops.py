@@ -468,16 +468,27 @@ def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False,
         _assign_later(params[1], dgb[Cc:])
         dgb = None
     if dx16 is not None:
-        dx._csts_bf16 = dx16
+        _attach16(dx, dx16)
     return dx, dgb
 
 
+def _attach16(dx: torch.Tensor, dx16: torch.Tensor):
+    """Remember the bf16 copy of the fp32 gradient `dx` on the tensor object, together with dx's version counter: autograd
+    accumulates the gradients of a tensor with several consumers IN PLACE into the first one that arrives, which keeps
+    the Python object (and this attribute) but bumps the version -- the copy is then stale and must not be used."""
+    dx._csts_bf16 = (dx16, dx._version)
+
+
 def _grad16(dy: torch.Tensor, compute: int):
-    """The bf16 copy of a residual-stream gradient left by the LayerNorm backward that produced it (or None)."""
+    """The bf16 copy of a residual-stream gradient left by the kernel that produced it (or None: no copy, or `dy` was
+    modified since the copy was made)."""
     if compute != BF16 or dy.dtype != torch.float32:
         return None
-    d16 = getattr(dy, "_csts_bf16", None)
-    if d16 is None or d16.shape != dy.shape or d16.device != dy.device:
+    tag = getattr(dy, "_csts_bf16", None)
+    if tag is None:
+        return None
+    d16, ver = tag
+    if dy._version != ver or d16.shape != dy.shape or d16.device != dy.device:
         return None
     return d16
 
@@ -1246,6 +1257,37 @@ class AddFn(Function):
     @staticmethod
     def backward(ctx, d):
         return d, (d if d.dtype == ctx.bdtype else d.to(ctx.bdtype))
+
+
+class TapFn(Function):
+    """Identity with two outputs for a residual-stream tensor that has TWO consumers (the encoder features the decoder
+    skips re-use, custom_multimodal_builder.py:384-403,467-479): both gradients meet in ONE backward kernel
+    (d = d_a + d_b, plus the bf16 copy the next block's GEMMs read) instead of autograd's own in-place accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, compute: int):
+        _need_gpu(x)
+        ctx.compute = compute
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None or db is None:
+            return (da if da is not None else db), None
+        da, db = da.contiguous(), db.contiguous()
+        out = torch.empty(da.shape, dtype=torch.float32, device=da.device)
+        want16 = ctx.compute == BF16 and BF16_GRAD_COPY
+        out16 = torch.empty(da.shape, dtype=torch.bfloat16, device=da.device) if want16 else None
+        L.check(_lib().csts_add2(_p(da), _dt(da), _p(db), _dt(db), _p(out), _p(out16), da.numel(), _stream()), "csts_add2")
+        if out16 is not None:
+            _attach16(out, out16)
+        return out, None
+
+
+def tap(x, compute):
+    """(x_a, x_b): two aliases of x, one per consumer."""
+    return TapFn.apply(x, compute)
 
 
 def cast(x: torch.Tensor, dt: int) -> torch.Tensor:

@@ -193,6 +193,10 @@ int csts_colsum(const void* X, int dt, const float* row_weight, float* out, int6
 int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, int64_t n, float alpha, float beta,
                hipStream_t stream);
 
+int csts_add2(const void* a, int a_dt, const void* b, int b_dt, float* out, void* out_bf16, int64_t n,
+              hipStream_t stream);   /* out = a + b (fp32) and optionally its bf16 copy: the two gradients of an encoder
+                                      * feature that the decoder skip re-uses (custom_multimodal_builder.py:467-479) */
+
 int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
                     int64_t M, int64_t N, hipStream_t stream);   /* drop-path backward (common.py:46-59) */
 

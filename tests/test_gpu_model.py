@@ -259,6 +259,7 @@ def _check_train_fixture(m, g, loss, kld, nce, preds, *, loss_tol, norm_tol, sli
     agree = float((preds.reshape(B, Tn, -1).argmax(-1).cpu().numpy() == g["argmax"]).mean())
     named = dict(m.named_parameters())
     worst_norm, worst_cos, worst_slice = 0.0, 1.0, 0.0
+    bad = []
     for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
         if n == "classifier.bias":           # softmax is shift-invariant: the true gradient is 0 (rounding noise only)
             continue
@@ -269,22 +270,20 @@ def _check_train_fixture(m, g, loss, kld, nce, preds, *, loss_tol, norm_tol, sli
             continue
         err = abs(float(gr.double().norm()) - ref_norm) / ref_norm
         worst_norm = max(worst_norm, err)
-        assert err <= norm_tol, (label, n, float(gr.double().norm()), ref_norm)
         ref_slice = g[n.replace(".", "_") + "_g"]
         sl = gr.flatten()[:ref_slice.size]
-        if slice_tol is not None:
-            e = rel_l2(sl, ref_slice)
-            worst_slice = max(worst_slice, e)
-            assert e < slice_tol, (label, n, e)
-        if cos_min is not None:
-            c = _cos(sl, ref_slice)
-            worst_cos = min(worst_cos, c)
-            assert c >= cos_min, (label, n, c)
+        e, c = rel_l2(sl, ref_slice), _cos(sl, ref_slice)
+        worst_slice, worst_cos = max(worst_slice, e), min(worst_cos, c)
+        if err > norm_tol or (slice_tol is not None and e >= slice_tol) or (cos_min is not None and c < cos_min):
+            bad.append(f"{n}: |g| {float(gr.double().norm()):.4e} vs {ref_norm:.4e} (err {err:.2e}), slice rel-L2 {e:.2e}, cosine {c:.5f}")
     total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
     ref_total = float(g["grad_total_norm"])
     print(f"\n[{label}] loss {float(loss):.6f} (ref {ref_loss:.6f})  kld {float(kld):.6f}/{ref_kld:.6f}  nce {float(nce):.5f}/{ref_nce:.5f}  "
           f"argmax agreement {agree:.3f}  worst grad-norm err {worst_norm:.2e}  worst slice rel-L2 {worst_slice:.2e}  "
           f"worst slice cosine {worst_cos:.5f}  total-norm err {abs(total - ref_total) / ref_total:.2e}")
+    if bad:
+        print(f"[{label}] gradients outside the bars:\n  " + "\n  ".join(bad))
+    assert not bad, (label, len(bad), bad[:3])
     assert abs(float(loss) - ref_loss) <= loss_tol * abs(ref_loss)
     assert abs(float(kld) - ref_kld) <= loss_tol * max(abs(ref_kld), 1e-3)
     assert abs(float(nce) - ref_nce) <= max(10 * loss_tol * abs(ref_nce), 1e-3)
@@ -334,7 +333,8 @@ def test_train_T32_aria_vs_reference_golden():
         loss, kld, nce, preds = _train_pass(m, cfg, b)
         print(f"\n[{compute} T32 B1] peak device memory {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
         if compute == "fp32":
-            _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-4, norm_tol=2e-3, slice_tol=5e-3, total_tol=1e-3,
+            # slices of gradients reduced over up to 131 k tokens in fp32 (another summation order than the CPU's): 1e-2
+            _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-4, norm_tol=2e-3, slice_tol=1e-2, total_tol=1e-3,
                                  argmax_min=1.0, label="fp32 T32 B1 aria")
         else:
             _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-2, norm_tol=5e-2, cos_min=0.99, total_tol=2e-2,

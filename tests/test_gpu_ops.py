@@ -657,3 +657,26 @@ def test_audio_attn_forward_backward(dt, tol, B, T, HW, C, H):
     gq = qh.grad.float()
     assert torch.count_nonzero(gq[:, :, 2 * C:]) == 0 and torch.count_nonzero(gq[:, :T * HW, :C]) == 0   # v and video-q untouched
     assert rel_l2(gq, qr.grad) < (1e-3 if dt == torch.float32 else 2e-2)      # bf16: the gradient itself is stored in bf16
+
+
+def test_tap_sums_both_gradients_and_bf16_copy_is_version_guarded():
+    """ops.tap: two aliases of a residual-stream tensor; backward = ONE kernel d_a + d_b (+ bf16 copy).  The bf16 copy
+    attached to a gradient tensor is dropped as soon as the tensor is modified in place (what autograd's own accumulation
+    does to the first-arrived gradient of a multi-consumer tensor)."""
+    x = rnd(3, 50, 96, seed=1).requires_grad_(True)
+    a, b = ops.tap(x, L.BF16)
+    assert torch.equal(a, x) and torch.equal(b, x)
+    ga, gb = rnd(3, 50, 96, seed=2), rnd(3, 50, 96, seed=3)
+    seen = {}
+    x.register_hook(lambda g: seen.setdefault("g", g))
+    (a * ga).sum().backward(retain_graph=True, inputs=[x])
+    assert torch.equal(x.grad, ga)                       # only one branch carried a gradient
+    x.grad = None
+    seen.clear()
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    assert torch.equal(x.grad, ga + gb)
+    g = seen["g"]
+    d16 = ops._grad16(g, L.BF16)
+    assert d16 is not None and torch.equal(d16, (ga + gb).to(torch.bfloat16))
+    g.add_(1.0)                                          # in-place change -> the copy is stale
+    assert ops._grad16(g, L.BF16) is None
