@@ -1,23 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- CSTS training throughput on MI355X (BASELINE.json metric: clips/s, training step).
+"""bench.py -- CSTS throughput on MI355X (BASELINE.json metric: clips/s, training step; --mode fwd: forward only).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 Workload (config.workload): CSTS_Ego4D_Gaze_Forecast.yaml + MODEL.LOSS_FUNC kldiv+egonce, 16 frames x 256^2
-(the reference itself cannot run 224^2), b = 4 clips per GPU (weak scaling), bf16 MFMA mode with fp32
-residual stream, synthetic clips + 24 kHz STFT resident in HBM before the timed region.  One step = forward +
-KLDiv + 0.05 EgoNCE + backward (+ bucketed RCCL gradient all-reduce when N > 1) + L2 clip + AdamW: nothing of the
-reference iteration (train_avgaze_net.py:65-109) is skipped.  Rank 0 prints ONE JSON line.
+(the reference itself cannot run 224^2; --crop 224 runs the labelled, parity-unpinned extension),
+b = 4 clips per GPU (weak scaling), bf16 MFMA mode with fp32 residual stream, synthetic clips + 24 kHz STFT resident
+in HBM before the timed region.
 
-Extra objects: "roofline" for the dominant kernel (the bf16 NT GEMM), measured live with HIP events on the
-launch stream over an instrumented pass, and "cpu_baseline" = the CPU oracle (a port, plain PyTorch fp32) timed on
-the host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+--mode train (default, BASELINE config 3/4): one step = forward + KLDiv + 0.05 EgoNCE + backward (+ RCCL gradient
+all-reduce when N > 1) + L2 clip + AdamW: nothing of the reference iteration (train_avgaze_net.py:65-109) is skipped.
+N = 1 replays the whole iteration as ONE HIP graph; N > 1 replays a chain of graphs with the collectives issued
+eagerly between them (csts_amd.train.SegmentedTrainStep).
+--mode fwd (BASELINE config 2): eval-mode forward + frame_softmax of the same batch, one HIP graph.
+
+Timing: W untimed steps, then EXACTLY K steps between barrier + synchronize, max over ranks -> `value`.  Beside it:
+`median_step_ms` = median of >= 50 single steps timed with HIP events after >= 10 warm-up steps; `fwd_ms` /
+`loss_ms` / `bwd_ms` / `optimizer_ms` (N = 1, train) = medians of the graph chain's segments.  `loss_check` compares the
+eval-mode loss of THIS model on the seed-1000 batch with the value the imported reference gave for the same weights and
+batch (tests/golden/bench_expected.json) and fails the run when they disagree.  Rank 0 prints ONE JSON line.
+
+Extra objects: "roofline" for the dominant kernel, measured live with HIP events on the launch stream over an
+instrumented pass, and "cpu_baseline" = the CPU oracle (a port, plain PyTorch fp32) timed on the host cores on a
+bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-FWD_GFLOP_PER_CLIP = {8: 208.7, 16: 465.3, 32: 1122.3}      # SURVEY.md 8(d) / BASELINE.md section 2
+FWD_GFLOP_PER_CLIP = {8: 208.7, 16: 465.3, 32: 1122.3}      # SURVEY.md 8(d) / BASELINE.md section 2 (256^2)
 BYTES_FWD_GB_PER_CLIP = {8: 1.24, 16: 2.34, 32: 4.53}
 PEAK_BF16_TFLOPS = 2500.0                                     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -35,18 +47,25 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--mode", default="train", choices=["train", "fwd"])
     p.add_argument("--frames", type=int, default=16)
+    p.add_argument("--crop", type=int, default=256, choices=[256, 224],
+                   help="224 = labelled EXTENSION (fusion kernels follow the final grid, parity unpinned: the reference rejects it)")
     p.add_argument("--batch-per-gpu", type=int, default=4)
     p.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--median-steps", type=int, default=50, help="single steps timed with HIP events for median_step_ms")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--quick-cpu-baseline", action="store_true", help="only the headline CPU sample (B=2 at the benchmarked grid)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-segments", action="store_true", help="skip the forward / backward / optimizer split (N = 1, train)")
+    p.add_argument("--no-loss-check", action="store_true")
     p.add_argument("--rehearse-dist", action="store_true",
-                   help="run the N>1 code path (RCCL process group, GradAllReduce buckets, eager step) with ONE rank")
-    p.add_argument("--ddp-graph", action="store_true",
-                   help="EXPERIMENTAL: capture the data-parallel step (RCCL collectives included) into a HIP graph")
-    p.add_argument("--no-graph", action="store_true", help="do not capture the step into a HIP graph (single GPU only)")
+                   help="run the N>1 code path (RCCL process group, graph chain + eager collectives) with ONE rank")
+    p.add_argument("--eager-dist", action="store_true",
+                   help="N>1: the eager step with hook-driven gradient buckets (GradAllReduce) instead of the graph chain")
+    p.add_argument("--no-graph", action="store_true", help="do not capture anything into HIP graphs")
     p.add_argument("--op-breakdown", default=None, help="write per-C-ABI-entry device time of one eager step to this file")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
     return p.parse_args()
@@ -70,23 +89,21 @@ class GemmTimer:
             def timed(argsref, stream):
                 import ctypes as C
                 a = argsref._obj
-                v2, tr, ns = C.c_int(), C.c_int(), C.c_int()
-                lib.csts_gemm_plan(argsref, C.byref(v2), C.byref(tr), C.byref(ns))
+                name_buf = C.create_string_buffer(160)
+                ns = C.c_int()
+                lib.csts_gemm_kernel_name(argsref, name_buf, 160, C.byref(ns))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(argsref, stream)
                 e1.record()
-                tf = lambda b: "true" if b else "false"
-                if v2.value >= 30:
-                    name = f"gemm3_kernel<{tr.value // 64}, {v2.value - 30}>"
-                elif v2.value:
-                    name = (f"gemm2_kernel<{tf(a.layout != 2)}, {tf(a.layout == 0)}, {tf(a.a_dt == 0)}, {tf(a.b_dt == 0)}, "
-                            f"{tr.value // 64}, 2>")
-                else:
-                    name = f"gemm_kernel<{tf(a.layout != 2)}, {tf(a.layout == 0)}, {tf(a.compute == 0)}>"
                 esz = lambda dt: 4 if dt == 0 else 2
                 byt = a.M * a.K * esz(a.a_dt) + a.N * a.K * esz(a.b_dt) + a.M * a.N * esz(a.c_dt)
-                owner.records.append((name, ns.value, 2.0 * a.M * a.N * a.K, byt, e0, e1, (a.layout, a.M, a.N, a.K, ns.value)))
+                if a.aux:
+                    byt += a.M * a.N * esz(a.aux_dt)               # GELU pre-activation written / read
+                if a.residual:
+                    byt += (a.res_row_mod if a.res_row_mod else a.M) * a.N * esz(a.r_dt)
+                owner.records.append((name_buf.value.decode(), ns.value, 2.0 * a.M * a.N * a.K, byt, e0, e1,
+                                      (a.layout, a.M, a.N, a.K, ns.value)))
                 return rc
             return timed
 
@@ -119,14 +136,14 @@ class GemmTimer:
         torch.cuda.synchronize()
         per = {}
         for name, ns, fl, by, e0, e1, shape in self.records:
-            a = per.setdefault(shape, [0, 0.0, fl, by])
+            a = per.setdefault(shape + (name,), [0, 0.0, fl, by])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
         rows = sorted(per.items(), key=lambda kv: -kv[1][1])
         with open(path, "w") as f:
-            f.write("layout M N K split calls total_ms avg_us TFLOPs GBps\n")
-            for (lay, M, N, K, sp), (n, sec, fl, by) in rows:
-                f.write(f"{'NT NN TN'.split()[lay]} {M} {N} {K} {sp} {n} {sec*1e3:.3f} {sec/n*1e6:.1f} {fl*n/sec/1e12:.1f} {by*n/sec/1e9:.0f}\n")
+            f.write("layout M N K split calls total_ms avg_us TFLOPs GBps kernel\n")
+            for (lay, M, N, K, sp, name), (n, sec, fl, by) in rows:
+                f.write(f"{'NT NN TN'.split()[lay]} {M} {N} {K} {sp} {n} {sec*1e3:.3f} {sec/n*1e6:.1f} {fl*n/sec/1e12:.1f} {by*n/sec/1e9:.0f} {name}\n")
 
 
 class OpTimer:
@@ -139,7 +156,8 @@ class OpTimer:
         def __getattr__(self, name):
             fn = getattr(self._lib, name)
             if not name.startswith("csts_") or name.endswith("_workspace") or name in (
-                    "csts_last_error", "csts_abi_version", "csts_gemm_v2_eligible"):
+                    "csts_last_error", "csts_abi_version", "csts_gemm_v2_eligible", "csts_gemm_kernel_name", "csts_gemm_plan",
+                    "csts_stft_frames"):
                 return fn
             rec = self._rec
 
@@ -174,19 +192,124 @@ class OpTimer:
         return {k: {"calls": v[0] // steps, "ms": round(v[1] / steps, 3)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 
 
-def cpu_baseline(frames):
-    """Oracle (CPU port, fp32 PyTorch ops) fwd + loss + bwd on ONE clip of the same shape; a bounded sample."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _host_cpu():
+    """(model string, physical cores visible to this process, logical CPUs visible to this process)."""
+    model, phys = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur and int(cur.get("processor", -1)) in allowed:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = [t.strip() for t in line.split(":", 1)]
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if cur and int(cur.get("processor", -1)) in allowed:
+            phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return model, max(1, len(phys) or len(allowed)), len(allowed)
+
+
+def cpu_baseline(frames, mode, quick, budget_s=150.0):
+    """The CPU oracle (a port of the reference path to plain PyTorch fp32 ops, pinned to the reference by
+    tests/test_oracle_golden.py) on the host cores: 1 warm-up + min of 3 per configuration.
+    `value` = the train step (fwd + loss + bwd, no optimizer) -- or the forward in --mode fwd -- at the benchmarked token
+    grid, B = 2 (EgoNCE is identically 0 at B = 1); the table adds 8 x 256^2 at B = 1 / 2 / 4, forward and train."""
     from oracle import csts_oracle as O
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads only add contention for these op sizes
-    P = {k: v.requires_grad_(True) for k, v in O.seeded_params(frames, 256).items()}
-    batch = O.synthetic_batch(2, frames, 256, seed=1000)    # B=2: EgoNCE is identically 0 at B=1
-    t0 = time.time()
-    logits, v, a = O.csts_forward(P, batch["video"], batch["audio"], frames, 256, return_embed=True)
-    loss, _, _ = O.csts_loss(logits, v, a, batch["labels_hm"], 0.05)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": round(2 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 un-warmed train step (fwd+loss+bwd, no optimizer) of the CPU oracle, B=2, {frames}x256^2, fp32, {dt:.1f} s"}
+    model, phys, logical = _host_cpu()
+    threads = max(1, min(phys, logical))
+    torch.set_num_threads(threads)
+    t_start = time.time()
+
+    def run(T_, B, train, reps=3):
+        P = O.seeded_params(T_, 256)
+        if train:
+            P = {k: v.requires_grad_(True) for k, v in P.items()}
+        batch = O.synthetic_batch(B, T_, 256, seed=1000)
+        best = None
+        for it in range(reps + 1):
+            t0 = time.time()
+            if train:
+                for v in P.values():
+                    v.grad = None
+                logits, ve, ae = O.csts_forward(P, batch["video"], batch["audio"], T_, 256, return_embed=True)
+                loss, _, _ = O.csts_loss(logits, ve, ae, batch["labels_hm"], 0.05)
+                loss.backward()
+            else:
+                with torch.no_grad():
+                    O.csts_forward(P, batch["video"], batch["audio"], T_, 256, return_embed=True)
+            dt = time.time() - t0
+            if it > 0:                          # iteration 0 = warm-up
+                best = dt if best is None else min(best, dt)
+            if time.time() - t_start > budget_s and best is not None:
+                break
+        return best
+
+    train = mode == "train"
+    head = run(frames, 2, train)
+    out = {"value": round(2 / head, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "physical_cores_visible": phys, "logical_cpus_visible": logical,
+           "sample": f"CPU oracle (plain PyTorch fp32 ops), {'train step: fwd + KLDiv + 0.05 EgoNCE + bwd, no optimizer' if train else 'eval forward'}, "
+                     f"B=2, {frames}x256^2, 1 warm-up + min of 3: {head:.2f} s per step, {threads} threads"}
+    if not quick:
+        table = {}
+        for B in (1, 2, 4):
+            for what, tr in (("fwd", False), ("train", True)):
+                if time.time() - t_start > budget_s:
+                    break
+                t = run(8, B, tr)
+                table[f"8x256^2 B={B} {what}"] = {"s_per_step": round(t, 3), "clips_per_s": round(B / t, 3)}
+        out["table"] = table
+    out["wall_s"] = round(time.time() - t_start, 1)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ loss check
+def loss_check(cfg, model, frames, b, crop, dev, T):
+    """Eval-mode loss of this model (as built under torch.manual_seed(cfg.RNG_SEED)) on the CPU-generated seed-1000
+    batch against the value the IMPORTED REFERENCE gave for the same weights and batch (oracle/gen_golden.py bench ->
+    tests/golden/bench_expected.json).  A fingerprint of weights and batch guards the comparison: if this box draws other
+    random numbers than the build container did, the check reports "unverifiable" instead of a false alarm."""
+    path = os.path.join(ROOT, "tests", "golden", "bench_expected.json")
+    key = f"T{frames}_B{b}"
+    if crop != 256 or not os.path.exists(path):
+        return {"status": "no reference value for this configuration"}
+    exp = json.load(open(path)).get(key)
+    if exp is None:
+        return {"status": "no reference value for this configuration"}
+    batch = T.synthetic_batch(b, frames, crop, exp["seed"], "cpu", pipeline="torch")
+    sd = model.state_dict()
+    fp = {n: float(sd[n].double().abs().sum()) for n in exp["fingerprint"] if not n.startswith("batch.")}
+    for k in ("video", "audio", "labels_hm"):
+        fp["batch." + k] = float(batch[k].double().abs().sum())
+    same = all(abs(fp[n] - v) <= 1e-5 * max(abs(v), 1e-12) for n, v in exp["fingerprint"].items())
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        bd = {k: v.to(dev) for k, v in batch.items()}
+        loss, kld, nce, _ = T.compute_loss(cfg, model, bd["video"], bd["audio"], bd["labels_hm"])
+        loss, kld, nce = float(loss), float(kld), float(nce)
+    model.train(was_training)
+    rel = abs(loss - exp["loss"]) / abs(exp["loss"])
+    out = {"loss": round(loss, 6), "kld": round(kld, 6), "nce": round(nce, 5), "expected_loss": round(exp["loss"], 6),
+           "expected_kld": round(exp["kld"], 6), "expected_nce": round(exp["nce"], 5), "rel_err": float(f"{rel:.3e}"),
+           "tolerance": 1e-2 if cfg.CSTS_AMD.COMPUTE == "bf16" else 1e-4,
+           "what": "eval-mode KLDiv + 0.05 EgoNCE of this model on the CPU-generated seed-1000 batch vs the imported reference "
+                   "(same weights, same batch)"}
+    if not same:
+        out["status"] = "unverifiable: weights / batch drawn on this box differ from the build container's"
+    else:
+        out["status"] = "ok" if rel <= out["tolerance"] else "MISMATCH"
+    return out
 
 
 def main():
@@ -203,7 +326,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist_path = world > 1 or args.rehearse_dist
+    train = args.mode == "train"
+    dist_path = (world > 1 or args.rehearse_dist)
     if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
@@ -214,34 +338,74 @@ def main():
         else:
             torch.distributed.init_process_group(backend="nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    rccl_ranks = torch.distributed.get_world_size() if dist_path else 1
 
     from csts_amd.config import load_yaml
     from csts_amd.build import build_model
     from csts_amd import train as T
+    from csts_amd import ops as _ops
     from csts_amd.distributed import GradAllReduce
 
-    b = args.batch_per_gpu
-    cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
-                    ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", b * world, "MODEL.LOSS_FUNC", "kldiv+egonce",
-                     "MODEL.LOSS_ALPHA", 0.05, "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute])
+    b, S = args.batch_per_gpu, args.crop
+    opts = ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", b * world, "MODEL.LOSS_FUNC", "kldiv+egonce", "MODEL.LOSS_ALPHA", 0.05,
+            "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute]
+    if S != 256:
+        opts += ["DATA.TRAIN_CROP_SIZE", S, "DATA.TEST_CROP_SIZE", S, "CSTS_AMD.FUSION_KERNEL_FROM_GRID", True]
+    cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"), opts)
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg)
-    if dist_path and not isinstance(model, GradAllReduce):
+    core = model.module if isinstance(model, GradAllReduce) else model
+    check = None
+    if rank == 0 and not args.no_loss_check:
+        check = loss_check(cfg, core, args.frames, b, S, dev, T)
+    if train and dist_path and not isinstance(model, GradAllReduce):
         model = GradAllReduce(model, bucket_mb=cfg.CSTS_AMD.GRAD_BUCKET_MB)
-    model.train()
-    use_graph = (not dist_path or args.ddp_graph) and not args.no_graph
-    opt = T.construct_optimizer(model, cfg, capturable=use_graph)
-    batch = T.synthetic_batch(b, args.frames, 256, 1000 + rank, dev)      # resident in HBM before timing
+    model.train(train)
+    batch = T.synthetic_batch(b, args.frames, S, 1000 + rank, dev)      # resident in HBM before timing
     lr = T.get_lr_at_epoch(cfg, 0.0)
-    graphed = T.GraphedTrainStep(cfg, model, opt, batch, allow_collectives=args.ddp_graph) if use_graph else None
+    step_kind = "eager"
+    graphed = None
+    if train:
+        use_graph = not args.no_graph and not (dist_path and args.eager_dist)
+        opt = T.construct_optimizer(model, cfg, capturable=use_graph)
+        if use_graph and dist_path:
+            graphed, step_kind = T.SegmentedTrainStep(cfg, model, opt, batch), "hip_graph_chain+eager_collectives"
+        elif use_graph:
+            graphed, step_kind = T.GraphedTrainStep(cfg, model, opt, batch), "hip_graph"
 
-    def step():
-        if graphed is not None:
-            return graphed.run(batch, lr)
-        return T.train_step(cfg, model, batch, opt, lr)
+        def step():
+            if graphed is not None:
+                return graphed.run(batch, lr)
+            return T.train_step(cfg, model, batch, opt, lr)
 
-    def eager_step():
-        return T.train_step(cfg, model, batch, opt, lr)
+        def eager_step():
+            return T.train_step(cfg, model, batch, opt, lr)
+    else:
+        from csts_amd import losses
+
+        def eager_step():
+            with torch.no_grad():
+                logits, v, a = core([batch["video"]], batch["audio"], return_embed=True)
+                return losses.frame_softmax(logits, temperature=2), v, a
+        fgraph = None
+        if not args.no_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            fgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fgraph):
+                fout = eager_step()
+            step_kind = "hip_graph"
+
+        def step():
+            if fgraph is not None:
+                fgraph.replay()
+                return fout
+            return eager_step()
 
     def sync():
         torch.cuda.synchronize()
@@ -254,7 +418,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, kld, nce = step()
+        res = step()
     sync()
     dt = time.perf_counter() - t0
     if dist_path:
@@ -264,24 +428,60 @@ def main():
     clips = b * world * args.steps
     value = clips / dt
     ms_per_step = dt / args.steps * 1e3
+    last_loss = float(res[0]) if train else None
+
+    # ---- median of single steps by HIP events (>= 10 warm-up steps have run by now: warmup + the timed ones)
+    extra_warm = max(0, 10 - args.warmup - args.steps)
+    for _ in range(extra_warm):
+        step()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.median_steps + 1)]
+    evs[0].record()
+    for i in range(args.median_steps):
+        step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.median_steps)]
+    median_ms = statistics.median(per_step) if per_step else None
+
+    # ---- forward / loss / backward / optimizer split: the same step as a chain of graphs, each segment timed by events
+    segments = None
+    if train and world == 1 and not dist_path and not args.no_segments and not args.no_graph:
+        try:
+            seg = T.SegmentedTrainStep(cfg, model, opt, batch, warmup=1)
+            for _ in range(3):
+                seg.run(batch, lr)
+            rows = []
+            for _ in range(15):
+                seg.run(batch, lr, timed=True)
+                rows.append(seg.segment_ms())
+            med = [statistics.median(r[i] for r in rows) for i in range(5)]
+            segments = {"fwd_ms": round(med[0], 3), "loss_ms": round(med[1], 3), "bwd_ms": round(med[2] + med[3], 3),
+                        "bwd_head_ms": round(med[2], 3), "bwd_trunk_ms": round(med[3], 3), "optimizer_ms": round(med[4], 3),
+                        "fwd_bwd_ms": round(med[0] + med[1] + med[2] + med[3], 3),
+                        "note": "graph chain forward | eager losses | backward head | backward trunk | clip+AdamW, median of 15; "
+                                "the headline step is ONE graph of the same kernels"}
+            del seg
+        except Exception as e:      # diagnostics only: never lose the headline line
+            segments = {"error": repr(e)}
 
     roof = None
     if not args.no_roofline:
         # every rank runs the instrumented steps (they contain the gradient collectives); rank 0 reports its own timings
-        from csts_amd import ops as _ops
         _mode = _ops.GROUP_WGRADS
-        if use_graph and _mode == "capture":
+        if train and step_kind != "eager" and _mode == "capture":
             _ops.GROUP_WGRADS = "always"      # instrument the same kernel set the captured (timed) step runs
+        if isinstance(model, GradAllReduce) and not model.hooks_enabled:
+            model.hooks_enabled = True        # the instrumented eager steps reduce through the hook-driven buckets
+            _ops.GROUP_WGRADS = "never"
         gt = GemmTimer()
         gt.install()
-        core = model.module if hasattr(model, "module") else model
         two = core.two_streams
         core.two_streams = False        # one stream: an event pair then brackets exactly one kernel (plus its launch gap)
         # keep the launch stream ahead of the GPU: a spin kernel first, so that the host has every launch of the step
         # queued before the GPU reaches it and an event pair brackets the kernel alone, not the host's launch gap
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize()
-        spin = int(10_000_000 * 120.0 / max(e0.elapsed_time(e1), 1e-3))     # ~120 ms head start
+        spin = int(10_000_000 * (120.0 if train else 40.0) / max(e0.elapsed_time(e1), 1e-3))     # head start
         for _ in range(2):
             torch.cuda._sleep(spin)
             eager_step()
@@ -302,7 +502,7 @@ def main():
             tot = t_ev0.elapsed_time(t_ev1)
             with open(args.op_breakdown if rank == 0 else os.devnull, "w") as f:
                 f.write(f"single-stream eager step {tot:.2f} ms; C-ABI kernels {sum(v['ms'] for v in ops_ms.values()):.2f} ms; "
-                        f"torch-native remainder (optimizer, clip, autograd adds, casts, fills) {tot - sum(v['ms'] for v in ops_ms.values()):.2f} ms\n")
+                        f"torch-native remainder (autograd adds, casts, fills) {tot - sum(v['ms'] for v in ops_ms.values()):.2f} ms\n")
                 for k, v in ops_ms.items():
                     f.write(f"{k:28s} {v['calls']:5d} calls {v['ms']:8.3f} ms\n")
         core.two_streams = two
@@ -333,7 +533,8 @@ def main():
                 "frac": round(max(t_mfma, t_hbm) / sec, 4),
                 "mfma_tflops": round(fl / sec / 1e12, 2), "mfma_frac": round(t_mfma / sec, 4),
                 "algorithmic_gbps": round(by / sec / 1e9, 1), "hbm_frac": round(t_hbm / sec, 4),
-                "traffic": traffic, "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
+                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed per round)",
+                "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
                 "algorithmic_flop_per_launch": round(fl / max(n, 1)), "algorithmic_bytes_per_launch": round(by / max(n, 1)),
                 "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2), "all_gemm_ms_per_step": round(tot_sec / 2 * 1e3, 2),
                 "per_kernel": {k: {"launches_per_step": v[0] // 2, "avg_us": round(v[3] / v[0] * 1e6, 1),
@@ -342,37 +543,59 @@ def main():
     if dist_path:
         torch.distributed.barrier()
 
+    rc = 0
     if rank == 0:
         per_gpu = value / world
-        train_gflop = 3 * FWD_GFLOP_PER_CLIP.get(args.frames, 0.0)
-        train_gb = 3 * BYTES_FWD_GB_PER_CLIP.get(args.frames, 0.0)
+        mult = 3 if train else 1
+        gflop = mult * FWD_GFLOP_PER_CLIP.get(args.frames, 0.0) * (S / 256.0) ** 2
+        gb = mult * BYTES_FWD_GB_PER_CLIP.get(args.frames, 0.0) * (S / 256.0) ** 2
+        what = ("train step (fwd + KLDiv + 0.05*EgoNCE + bwd" + (" + RCCL grad all-reduce" if dist_path else "") + " + clip + AdamW)") \
+            if train else "eval forward + frame_softmax"
         out = {
-            "metric": "clips/sec training (fwd+bwd) CSTS-Ego4D 16x256^2 bf16", "value": round(value, 3), "unit": "clips/s",
+            "metric": f"clips/sec {'training (fwd+bwd)' if train else 'forward'} CSTS-Ego4D {args.frames}x{S}^2 {args.compute}",
+            "value": round(value, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
-            "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml train step (fwd + KLDiv + 0.05*EgoNCE + bwd"
-                                   f"{' + RCCL grad all-reduce' if dist_path else ''} + clip + AdamW), "
-                                   f"{args.frames}x256^2 video + 24 kHz STFT audio, b={b}/GPU",
-                       "global_batch": b * world, "frames": args.frames, "crop": 256, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
-                       "note": "256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)"},
-            "loss": round(float(loss), 5),
-            "end_to_end_roofline": {"mfma_frac": round(per_gpu * train_gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
-                                    "hbm_frac": round(per_gpu * train_gb / PEAK_HBM_GBS, 4),
-                                    "train_gflop_per_clip": train_gflop, "train_gb_per_clip": train_gb},
+            "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml {what}, {args.frames}x{S}^2 video + 24 kHz STFT audio, b={b}/GPU",
+                       "mode": args.mode, "global_batch": b * world, "frames": args.frames, "crop": S, "parallelism": f"dp{world}",
+                       "step": step_kind, "hip_graph": step_kind != "eager", "rccl_ranks": rccl_ranks,
+                       "note": ("256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)" if S == 256 else
+                                "EXTENSION, parity unpinned: 224^2 with (1,7,7) fusion kernels (CSTS_AMD.FUSION_KERNEL_FROM_GRID); "
+                                "the reference cannot run this grid, FLOP/byte figures scaled by (224/256)^2")},
+            "median_step_ms": round(median_ms, 3) if median_ms is not None else None,
+            "median_over_steps": args.median_steps,
+            "median_clips_per_s": round(b * world / median_ms * 1e3, 3) if median_ms else None,
+            "end_to_end_roofline": {"mfma_frac": round(per_gpu * gflop / 1e3 / PEAK_BF16_TFLOPS, 4),
+                                    "hbm_frac": round(per_gpu * gb / PEAK_HBM_GBS, 4),
+                                    "gflop_per_clip": round(gflop, 1), "gb_per_clip": round(gb, 2)},
         }
+        if last_loss is not None:
+            out["loss"] = round(last_loss, 5)
+        if segments is not None:
+            out["segments"] = segments
+            for k in ("fwd_bwd_ms", "optimizer_ms"):
+                if k in segments:
+                    out[k] = segments[k]
+        if check is not None:
+            out["loss_check"] = check
+            if check.get("status") == "MISMATCH":
+                rc = 3
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not dist_path and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.frames)
+                out["cpu_baseline"] = cpu_baseline(args.frames, args.mode, args.quick_cpu_baseline)
             except Exception as e:  # keep the line valid even if the host runs out of memory
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         sys.stdout.flush()
         os.dup2(_stdout_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)       # teardown chatter of native libraries stays off stdout as well
+        if rc:
+            print(f"bench.py: loss check FAILED: {check}", file=sys.stderr)
     if dist_path:
         torch.distributed.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

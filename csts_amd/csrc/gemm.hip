@@ -12,6 +12,7 @@
 // ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32), so staging is always a straight 16-byte copy.
 #include "common.h"
 #include <type_traits>
+#include <cstdio>
 
 namespace {
 
@@ -1237,6 +1238,22 @@ extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, 
   *v2 = use_v2 ? 1 : 0;
   *nsplit = (int)ns;
   *tile_rows = use_v2 ? pick_tile_rows(a, cdiv(a->N, BN) * ns) : BM;
+  return 0;
+}
+
+// The same decision as a kernel NAME, spelled as rocprofv3 prints it (bench.py attributes its HIP-event timings to it).
+extern "C" int csts_gemm_kernel_name(const csts_gemm_args* a, char* buf, int buflen, int* nsplit) {
+  CSTS_REQUIRE(a != nullptr && buf != nullptr && buflen > 0 && nsplit != nullptr, "null pointer");
+  int v2 = 0, rows = 0;
+  if (csts_gemm_plan(a, &v2, &rows, nsplit) != 0) return -1;
+  auto tf = [](bool b) { return b ? "true" : "false"; };
+  if (v2 >= 30) snprintf(buf, buflen, "gemm3_kernel<%d, %d>", rows / 64, v2 - 30);
+  else if (v2)
+    snprintf(buf, buflen, "gemm2_kernel<%s, %s, %s, %s, %d, 2>", tf(a->layout != CSTS_GEMM_TN), tf(a->layout == CSTS_GEMM_NT),
+             tf(a->a_dt == CSTS_F32), tf(a->b_dt == CSTS_F32), rows / 64);
+  else
+    snprintf(buf, buflen, "gemm_kernel<%s, %s, %s>", tf(a->layout != CSTS_GEMM_TN), tf(a->layout == CSTS_GEMM_NT),
+             tf(a->compute == CSTS_F32));
   return 0;
 }
 

@@ -85,6 +85,7 @@ class GradAllReduce(nn.Module):
     def __init__(self, module: nn.Module, bucket_mb: int = 64):
         super().__init__()
         self.module = module
+        self.hooks_enabled = True       # csts_amd.train.SegmentedTrainStep drives the buckets itself and switches this off
         self.world = dist.get_world_size() if is_dist() else 1
         self.bucket_bytes = int(bucket_mb) * (1 << 20)
         self._late = []
@@ -136,26 +137,33 @@ class GradAllReduce(nn.Module):
         self._iters_since_assign = 0
 
     def _hook(self, p):
+        if not self.hooks_enabled:
+            return
         if not self._observed:
             self._ready_order.append(p)
         bi = p._csts_bucket
         c = self._count[bi] + 1
         self._count[bi] = c
-        if self._iters_since_assign < 2 and p.grad.is_cuda and (self.world > 1 or _FORCE):
+        if self._iters_since_assign < 2 and (self.world > 1 or _FORCE):
             # backward replays on more than one HIP stream (the audio trunk has its own): learn, during the first two
             # iterations after a bucket assignment, which streams produce gradients of this bucket (the graph is static),
             # so that its launch can wait for them
-            cur = torch.cuda.current_stream()
-            self._bucket_streams.setdefault(bi, {})[cur.cuda_stream] = cur
+            cur = self._cur_stream(p.grad)
+            if cur is not None:
+                self._bucket_streams.setdefault(bi, {})[cur.cuda_stream] = cur
         if c == self._bucket_len[bi]:
             self._launch(bi)
+
+    def _cur_stream(self, grad):
+        """The HIP stream the calling autograd node runs on (None for CPU tensors; tests substitute a stub)."""
+        return torch.cuda.current_stream() if grad.is_cuda else None
 
     def _launch(self, bi):
         if self.world == 1 and not _FORCE:
             return
         ps = self._buckets[bi]
-        if ps[0].grad.is_cuda:
-            cur = torch.cuda.current_stream()
+        cur = self._cur_stream(ps[0].grad)
+        if cur is not None:
             for sid, st in self._bucket_streams.get(bi, {}).items():
                 if sid != cur.cuda_stream:
                     cur.wait_stream(st)      # gradients of this bucket that were produced on another stream
@@ -178,6 +186,8 @@ class GradAllReduce(nn.Module):
     def finish(self):
         """Wait for the outstanding buckets and hand the averaged gradients back (call after backward): every p.grad
         becomes a VIEW of its bucket's flat buffer -- no copy back."""
+        if not self.hooks_enabled:
+            return
         if self._late and (self.world > 1 or _FORCE):
             # complete by now: the deferred reductions ran in the autograd final callback, on this stream
             ps = [p for p in self._late if p.grad is not None]

@@ -348,8 +348,11 @@ class CSTS(nn.Module):
         return {}
 
     # ------------------------------------------------------------------ forward (custom_multimodal_builder.py:343-498)
-    def forward(self, x, y, return_embed=False, return_spatial_attn=False, return_temporal_attn=False, keep_masks=None):
-        rt = self.rt
+    def forward(self, x, y, return_embed=False, return_spatial_attn=False, return_temporal_attn=False, keep_masks=None,
+                boundary=None):
+        """boundary (optional, csts_amd.train.SegmentedTrainStep): callable applied to the list of tensors that cross from
+        the encoder trunks to the fusion / decoder head [video tokens, audio tokens, the four encoder features the decoder
+        re-uses]; it may return detached stand-ins, which cuts the autograd graph into a trunk part and a head part."""
         inpt = x[0]
         if not inpt.is_cuda:
             raise L.CstsError("CSTS (csts_amd) runs on MI355X only: inputs must be GPU tensors; there is no CPU fallback")
@@ -357,6 +360,14 @@ class CSTS(nn.Module):
         if self.training and keep_masks is None:
             km = self._draw_drop_paths(inpt.shape[0], inpt.device)
         self._refresh_w16()
+        feats, geo = self.forward_trunk(inpt, y, km)
+        if boundary is not None:
+            feats = boundary(feats)
+        return self.forward_head(feats, geo, km, return_embed, return_spatial_attn, return_temporal_attn)
+
+    def forward_trunk(self, inpt, y, km):
+        """Patch embeddings + the video and audio encoders (custom_multimodal_builder.py:346-411)."""
+        rt = self.rt
         pe, pa = self.patch_embed, self.patch_embed_audio
         xt = ops.patch_embed(inpt.float(), pe.proj.weight, pe.proj.bias, self.pos_embed_spatial, self.pos_embed_temporal,
                              pe.kernel, pe.stride, pe.padding, rt.act_dt, rt.compute)
@@ -367,7 +378,8 @@ class CSTS(nn.Module):
         # encoder features the decoder re-uses (:384,389,396,403): each goes through ops.tap, so that its two gradients
         # (next block + decoder skip) meet in one kernel that also leaves the bf16 copy the next GEMMs read
         xt, keep = ops.tap(xt, rt.compute)
-        inter = [(keep, thw)]
+        inter = [keep]
+        inter_thw = [list(thw)]
 
         def run(t, shape, blocks, names):
             for blk, nm in zip(blocks, names):
@@ -390,13 +402,22 @@ class CSTS(nn.Module):
         for lo, hi in ((0, 1), (1, 3), (3, 14)):
             xt, thw = run(xt, thw, vb[lo:hi], vn[lo:hi])
             xt, keep = ops.tap(xt, rt.compute)
-            inter.append((keep, thw))
+            inter.append(keep)
+            inter_thw.append(list(thw))
         xt, thw = run(xt, thw, vb[14:], vn[14:])
         if side is not None:
             main.wait_stream(side)
             yt.record_stream(main)
         else:
             yt, thw_a = run(yt, thw_a, ab, an)
+        return [xt, yt] + inter, (list(thw), list(thw_a), inter_thw)
+
+    def forward_head(self, feats, geo, km, return_embed=False, return_spatial_attn=False, return_temporal_attn=False):
+        """Spatial / temporal fusion, re-weighting, decoder, classifier, embeddings (custom_multimodal_builder.py:413-498)."""
+        rt = self.rt
+        xt, yt = feats[0], feats[1]
+        thw, thw_a, inter_thw = geo
+        inter = list(zip(feats[2:], inter_thw))
 
         # ---- spatial fusion (:415-432)
         B, Nv, Cc = xt.shape

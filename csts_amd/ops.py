@@ -186,7 +186,7 @@ def flush_deferred():
     dev = items[0][0].device
     tab = _deferred_tables.get(dev.index)
     if tab is None:
-        tab = _deferred_tables[dev.index] = HostTable(C.sizeof(L.ReduceDesc) * 2048, dev, ring=4, captures=8)
+        tab = _deferred_tables[dev.index] = HostTable(C.sizeof(L.ReduceDesc) * 2048, dev, ring=4, captures=16)
     # one launch per size class (the grid is sized by the widest reduction of the launch)
     descs = (L.ReduceDesc * len(items))()
     for i, (ws, out, nrows, ncols) in enumerate(items):
@@ -312,7 +312,7 @@ def flush_wgrads():
     dev = q[0][0].device
     tab = _wg_tables.get(dev.index)
     if tab is None:
-        tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=3, captures=4)
+        tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=3, captures=16)
     keep = []
     # 256 x 128 tiles where they divide the layer's output rows (bf16 dY): a quarter less operand traffic per FLOP
     for a_f32, rows in ((False, 256), (False, 128), (True, 128)):

@@ -1,8 +1,11 @@
 """Thin training-step harness: this package's counterpart of tools/train_avgaze_net.py:25-155 (reference Python
 never ships to the GPU box).  It reproduces the timed iteration -- LR set, forward, frame_softmax + KLDiv +
 LOSS_ALPHA * EgoNCE, backward (+ RCCL gradient all-reduce), L2 clip 1.0, AdamW -- without the reference's
-per-iteration host syncs (isnan / .item() / metric gathers run only when asked).  Optimizer and LR schedule are
-stock torch (a fused device optimizer is a "next" row)."""
+per-iteration host syncs (isnan / .item() / metric gathers run only when asked).  The optimizer is the device-side
+csts_amd.optim.FusedAdamW (clip + AdamW + bf16 shadow refresh in three launches); the LR schedule is
+slowfast/utils/lr_policy.py's cosine.  Three ways to run the step: eagerly (train_step), as ONE HIP graph
+(GraphedTrainStep, single GPU) or as a chain of HIP graphs with the loss and the RCCL collectives issued eagerly
+between them (SegmentedTrainStep, the data-parallel step)."""
 from __future__ import annotations
 
 import math
@@ -144,6 +147,10 @@ def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device, pipel
         labels = torch.cat([xy, torch.zeros(B, T, 1, device=device)], dim=-1)
         frames_idx = (torch.arange(T, device=device, dtype=torch.float32) + 0.5)[None].expand(B, T)
         batch = inputs.assemble_batch(frames, wav, frames_idx, float(T), labels)
+        if S != 256:      # the 224^2 extension: S frequency bins x S columns around each frame, (S/4)^2 heat maps
+            o = (256 - S) // 2
+            batch["audio"] = batch["audio"][:, :, :, :S, o:o + S].contiguous()
+            batch["labels_hm"] = inputs.gaze_heatmaps(labels, H=S // 4, W=S // 4)
         batch["labels"] = labels.double()
         return batch
     u = torch.randint(0, 256, (B, 3, T, S, S), generator=g, device=device).float()
@@ -159,14 +166,15 @@ def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device, pipel
     for t in range(T):
         c = max(128, min(cols - 129, int(round((t + 0.5) / T * cols))))
         audio[:, 0, t] = logp[:, :S, c - S // 2:c + S // 2]
-    yy, xx = torch.meshgrid(torch.arange(64.0, device=device), torch.arange(64.0, device=device), indexing="ij")
-    cx = (torch.rand(B, T, generator=g, device=device) * 63).round()
-    cy = (torch.rand(B, T, generator=g, device=device) * 63).round()
+    G = S // 4
+    yy, xx = torch.meshgrid(torch.arange(float(G), device=device), torch.arange(float(G), device=device), indexing="ij")
+    cx = (torch.rand(B, T, generator=g, device=device) * (G - 1)).round()
+    cy = (torch.rand(B, T, generator=g, device=device) * (G - 1)).round()
     dx = xx[None, None] - cx[..., None, None]
     dy = yy[None, None] - cy[..., None, None]
     k = torch.exp(-(dx ** 2 + dy ** 2) / (2 * 3.2 ** 2)) * (dx.abs() <= 9) * (dy.abs() <= 9)
     hm = k / k.sum(dim=(-1, -2), keepdim=True)
-    labels = torch.stack([cx / 63, cy / 63, torch.zeros_like(cx)], dim=-1).double()
+    labels = torch.stack([cx / (G - 1), cy / (G - 1), torch.zeros_like(cx)], dim=-1).double()
     return {"video": video, "audio": audio, "labels_hm": hm, "labels": labels}
 
 
@@ -228,3 +236,197 @@ class GraphedTrainStep:
             core._refresh_w16()              # only acts after an out-of-band weight change (load_state_dict)
         self.graph.replay()
         return self.out
+
+
+
+class SegmentedTrainStep:
+    """The training iteration as a CHAIN of HIP graphs -- forward | backward of the fusion/decoder head | backward of the
+    encoder trunks | clip + AdamW -- with the loss and every RCCL collective issued EAGERLY between them:
+
+        G_fwd -> [EgoNCE all-gather, losses, their backward: ~20 small launches] -> G_bwd_head -> all-reduce(head grads, async)
+              -> G_bwd_trunk -> all-reduce(trunk grads) -> wait -> G_opt
+
+    This is the data-parallel step: the compute runs from graphs exactly as on one GPU (grouped weight gradients, deferred
+    reductions, two-stream trunks included), no collective is ever captured, and the head bucket -- the three 37.7 M-parameter
+    fusion convs, 60 % of all gradient bytes -- travels over xGMI underneath the whole trunk backward.  Gradients are
+    averaged in two flat fp32 buffers (filled by one multi-tensor copy at the end of each backward graph) and the optimizer
+    reads them through p.grad views.  With one process it degenerates to the same chain without collectives (used by
+    bench.py to time forward / backward / optimizer separately)."""
+
+    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2):
+        from . import ops
+        self.cfg, self.model, self.opt = cfg, model, optimizer
+        self.core = model.module if isinstance(model, GradAllReduce) else model
+        self.dist = du.is_dist()
+        if isinstance(model, GradAllReduce):
+            model.hooks_enabled = False               # buckets are driven from here, not from autograd hooks ...
+            if ops.GROUP_WGRADS == "never":           # ... so nothing reads a gradient in the middle of backward any more:
+                ops.GROUP_WGRADS = "capture"          # the grouped end-of-backward weight gradients are back
+        self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
+        core = self.core
+        head_mods = [core.vision_pool, core.audio_pool, core.audio_pool2, core.temporal_fusion, core.spatial_fusion,
+                     core.decode_block1, core.decode_block2, core.decode_block3, core.decode_block4, core.classifier]
+        for nm in ("vision_proj", "audio_proj"):
+            if hasattr(core, nm):
+                head_mods.append(getattr(core, nm))
+        self.head_params = [p for m_ in head_mods for p in m_.parameters() if p.requires_grad]
+        hid = {id(p) for p in self.head_params}
+        self.trunk_params = [p for p in core.parameters() if p.requires_grad and id(p) not in hid]
+        self._avg = None
+        if self.dist:
+            import torch.distributed as dist
+            self._avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None
+            self.flat = [self._flat_for(self.head_params), self._flat_for(self.trunk_params)]
+        self.events = None
+        mode = ops.GROUP_WGRADS
+        ops.GROUP_WGRADS = "always" if mode != "never" else mode     # warm-up takes the same (grouped) path as the capture
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    self._chain(capture=False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graphs = {}
+            self._chain(capture=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.GROUP_WGRADS = mode
+
+    # ------------------------------------------------------------------ pieces
+    def _flat_for(self, params):
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        return flat, [flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
+
+    def _segment(self, name, fn, capture):
+        """Run fn() eagerly, or capture it into graph `name` (all graphs share one memory pool: they always replay in the
+        same order, so a block freed by one may be re-used by the next)."""
+        if not capture:
+            return fn()
+        g = torch.cuda.CUDAGraph()
+        pool = self.graphs["fwd"].pool() if "fwd" in self.graphs else None
+        with torch.cuda.graph(g, pool=pool):
+            out = fn()
+        self.graphs[name] = g
+        return out
+
+    def _all_reduce(self, k):
+        import torch.distributed as dist
+        flat = self.flat[k][0]
+        if self._avg is not None:
+            return dist.all_reduce(flat, op=self._avg, async_op=True)
+        flat /= dist.get_world_size()
+        return dist.all_reduce(flat, async_op=True)
+
+    def _loss_eager(self):
+        """EgoNCE all-gather + frame_softmax + KLDiv + LOSS_ALPHA * EgoNCE on the forward graph's static outputs, and the
+        backward of just that part into the static gradient buffers the head graph starts from."""
+        cfg = self.cfg
+        leaves = [t.detach().requires_grad_(True) for t in self.outs]
+        if cfg.MODEL.LOSS_FUNC == "kldiv+egonce":
+            logits, v_emb, a_emb = leaves
+            if du.is_dist():
+                v_emb, a_emb = du.all_gather_with_grad([v_emb, a_emb])
+            preds = losses.frame_softmax(logits, temperature=2)
+            kld = losses.KLDiv()(preds, self.static["labels_hm"])
+            nce = losses.EgoNCE()(losses.sim_matrix(v_emb, a_emb))
+            loss = kld + cfg.MODEL.LOSS_ALPHA * nce
+        else:
+            preds = losses.frame_softmax(leaves[0], temperature=2)
+            kld = losses.get_loss_func(cfg.MODEL.LOSS_FUNC)()(preds, self.static["labels_hm"])
+            loss, nce = kld, None
+        loss.backward()
+        for buf, leaf in zip(self.douts, leaves):
+            buf.copy_(leaf.grad)
+        return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
+
+    def _chain(self, capture):
+        core, cfg = self.core, self.cfg
+        with_embed = cfg.MODEL.LOSS_FUNC == "kldiv+egonce"
+        self.opt.zero_grad(set_to_none=True)
+        cut = {}
+
+        def boundary(feats):
+            cut["out"] = feats
+            cut["in"] = [f.detach().requires_grad_(True) for f in feats]
+            return cut["in"]
+
+        def fwd():
+            out = core([self.static["video"]], self.static["audio"], return_embed=with_embed, boundary=boundary)
+            return list(out) if with_embed else [out]
+
+        self.outs = self._segment("fwd", fwd, capture)
+        if capture or not hasattr(self, "douts"):
+            self.douts = [torch.zeros_like(o) for o in self.outs]
+        res = self._loss_eager()
+        if capture:
+            self.result = res
+
+        def bwd_head():
+            torch.autograd.backward(self.outs, self.douts, inputs=self.head_params + cut["in"])
+            if self.dist:
+                torch._foreach_copy_(self.flat[0][1], [p.grad for p in self.head_params])
+
+        self._segment("bwd_head", bwd_head, capture)
+        works = [self._all_reduce(0)] if self.dist else []
+
+        def bwd_trunk():
+            torch.autograd.backward(cut["out"], [t.grad for t in cut["in"]], inputs=self.trunk_params)
+            if self.dist:
+                torch._foreach_copy_(self.flat[1][1], [p.grad for p in self.trunk_params])
+
+        self._segment("bwd_trunk", bwd_trunk, capture)
+        if self.dist:
+            works.append(self._all_reduce(1))
+            for w in works:
+                w.wait()
+            self._raw_grads = [p.grad for p in self.head_params + self.trunk_params]   # graph-owned: keep them alive
+            for k, ps in enumerate((self.head_params, self.trunk_params)):
+                for p, v in zip(ps, self.flat[k][1]):
+                    p.grad = v
+        self._segment("opt", lambda: _clip_and_step(cfg, self.model, self.opt), capture)
+        del cut
+        return res
+
+    # ------------------------------------------------------------------ replay
+    def run(self, batch=None, lr: Optional[float] = None, timed: bool = False):
+        if batch is not None:
+            for k in self.static:
+                if batch[k] is not self.static[k]:
+                    self.static[k].copy_(batch[k], non_blocking=True)
+        if lr is not None:
+            set_lr(self.opt, lr)
+        if hasattr(self.core, "_refresh_w16"):
+            self.core._refresh_w16()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed else None
+        mark = (lambda i: ev[i].record()) if timed else (lambda i: None)
+        mark(0)
+        self.graphs["fwd"].replay()
+        mark(1)
+        res = self._loss_eager()
+        mark(2)
+        self.graphs["bwd_head"].replay()
+        works = [self._all_reduce(0)] if self.dist else []
+        mark(3)
+        self.graphs["bwd_trunk"].replay()
+        if self.dist:
+            works.append(self._all_reduce(1))
+            for w in works:
+                w.wait()
+        mark(4)
+        self.graphs["opt"].replay()
+        mark(5)
+        if timed:
+            self.events = ev
+        return res
+
+    def segment_ms(self):
+        """(forward, loss, backward head, backward trunk [+ exposed all-reduce], optimizer) of the last run(timed=True)."""
+        torch.cuda.synchronize()
+        e = self.events
+        return [e[i].elapsed_time(e[i + 1]) for i in range(5)]

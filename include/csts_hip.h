@@ -62,7 +62,9 @@ typedef struct {
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
 size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);
-int csts_gemm_plan(const csts_gemm_args* args, int* v2, int* tile_rows, int* nsplit);   /* which kernel / tile / k-split csts_gemm picks: v2 = 0 generic, 1 register-staged bf16 kernel, 30 + stages = persistent LDS-DMA NT kernel */
+int csts_gemm_plan(const csts_gemm_args* args, int* v2, int* tile_rows, int* nsplit);
+/* The kernel csts_gemm would launch, by NAME as rocprofv3 prints it (for attributing live timings); *nsplit = k-splits. */
+int csts_gemm_kernel_name(const csts_gemm_args* a, char* buf, int buflen, int* nsplit);   /* which kernel / tile / k-split csts_gemm picks: v2 = 0 generic, 1 register-staged bf16 kernel, 30 + stages = persistent LDS-DMA NT kernel */
 int csts_gemm_v2_eligible(const csts_gemm_args* args);   /* 1 when the fast bf16 kernel (and fused colsum) applies */
 
 /* Grouped weight gradients: every dW[M,N] = dY[tokens,M]^T X[tokens,N] of a backward pass (nn.Linear weight gradients of

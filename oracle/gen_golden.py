@@ -430,6 +430,47 @@ def gen_train_saa():
     save("model_T8_B2_saa_train.npz", **_train_fixture(m, batch, SAA_GRAD_NAMES))
 
 
+def bench_fingerprint(model, batch):
+    """A few float64 sums that identify (weights, batch) of bench.py's loss check (tolerant comparison: see bench.py)."""
+    sd = model.state_dict()
+    names = ["pos_embed_spatial", "blocks.0.attn.qkv.weight", "blocks.15.mlp.fc2.weight", "vision_pool.weight",
+             "decode_block4.mlp.fc2.weight", "classifier.weight"]
+    fp = {n: float(sd[n].double().abs().sum()) for n in names}
+    for k in ("video", "audio", "labels_hm"):
+        fp["batch." + k] = float(batch[k].double().abs().sum())
+    return fp
+
+
+def gen_bench_expected():
+    """Expected loss of bench.py's loss check: the BENCHMARKED configuration (16 x 256^2, b = 4, kldiv+egonce) in eval
+    mode on the CPU-generated seed-1000 batch, computed by the imported reference with the weights csts_amd's own model
+    constructor draws under torch.manual_seed(cfg.RNG_SEED) -- exactly what bench.py builds on the GPU box."""
+    from csts_amd.config import load_yaml
+    from csts_amd.build import build_model
+    from csts_amd import train as T
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    out = {}
+    for frames, b in ((16, 4),):
+        cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
+                        ["NUM_GPUS", 0, "TRAIN.BATCH_SIZE", b, "MODEL.LOSS_FUNC", "kldiv+egonce", "MODEL.LOSS_ALPHA", 0.05,
+                         "DATA.NUM_FRAMES", frames, "CSTS_AMD.COMPUTE", "bf16"])
+        torch.manual_seed(cfg.RNG_SEED)
+        mine = build_model(cfg)
+        batch = T.synthetic_batch(b, frames, 256, 1000, "cpu", pipeline="torch")
+        ref = CSTS(make_cfg(frames)).eval()
+        ref.load_state_dict(mine.state_dict(), strict=True)
+        with torch.no_grad():
+            logits, v, a = ref([batch["video"]], batch["audio"], return_embed=True)
+            p = ref_utils.frame_softmax(logits, temperature=2)
+            kld = ref_losses.KLDiv()(p, batch["labels_hm"])
+            nce = ref_losses.EgoNCE()(ref_utils.sim_matrix(v, a))
+        out[f"T{frames}_B{b}"] = {"loss": float(kld + 0.05 * nce), "kld": float(kld), "nce": float(nce),
+                                  "fingerprint": bench_fingerprint(mine, batch), "seed": 1000, "rng_seed": int(cfg.RNG_SEED)}
+        print(out)
+    with open(os.path.join(OUT, "bench_expected.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def gen_metrics():
     """adaptive_f1 of the reference (slowfast/utils/metrics.py) on seeded heat maps, all three threshold tables."""
     from slowfast.utils import metrics as ref_metrics
@@ -529,3 +570,5 @@ if __name__ == "__main__":
         gen_train_t32()
     if "trainsaa" in what:
         gen_train_saa()
+    if "bench" in what:
+        gen_bench_expected()

@@ -180,6 +180,126 @@ def _dist_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _TinyBlock(torch.nn.Module):
+    """CSTS-shaped parameter names (norm1 / attn.qkv / attn.pool_k / attn.norm_k / norm2 / mlp.fc1 / mlp.fc2) over plain
+    torch CPU ops: what GradAllReduce sees of a block."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.norm1 = torch.nn.LayerNorm(dim)
+        self.attn = torch.nn.Module()
+        self.attn.qkv = torch.nn.Linear(dim, dim)
+        self.attn.pool_k = torch.nn.Conv1d(dim, dim, 3, padding=1, groups=dim, bias=False)
+        self.attn.norm_k = torch.nn.LayerNorm(dim)
+        self.norm2 = torch.nn.LayerNorm(dim)
+        self.mlp = torch.nn.Module()
+        self.mlp.fc1 = torch.nn.Linear(dim, 2 * dim)
+        self.mlp.fc2 = torch.nn.Linear(2 * dim, dim)
+
+    def forward(self, x):
+        h = self.attn.qkv(self.norm1(x))
+        h = self.attn.norm_k(self.attn.pool_k(h.transpose(1, 2)).transpose(1, 2))
+        x = x + h
+        return x + self.mlp.fc2(torch.relu(self.mlp.fc1(self.norm2(x))))
+
+
+class _TinyCSTS(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([_TinyBlock(8) for _ in range(2)])
+        self.blocks_audio = torch.nn.ModuleList([_TinyBlock(8)])
+        self.vision_pool = torch.nn.Linear(8, 8)
+        self.classifier = torch.nn.Linear(8, 1)
+
+    def forward(self, x, y):
+        for b in self.blocks:
+            x = b(x)
+        for b in self.blocks_audio:
+            y = b(y)
+        return self.classifier(self.vision_pool(x) + y.mean(dim=1, keepdim=True))
+
+
+class _StubStream:
+    """Stands in for a HIP stream on the CPU: records who waited for whom."""
+    def __init__(self, sid, log):
+        self.cuda_stream, self._log = sid, log
+
+    def wait_stream(self, other):
+        self._log.append((self.cuda_stream, other.cuda_stream))
+
+
+def _dist_worker_whole(rank, world, port, q):
+    """The WHOLE GradAllReduce on a CSTS-shaped module, 2 ranks over gloo: hook-driven buckets in gradient-ready order, the
+    late bucket (LayerNorm / pooling-stencil parameters, reduced by finish()), re-bucketing after the first iteration, and
+    the cross-stream wait logic (audio-trunk gradients are produced on another stream) behind stub streams."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from csts_amd import distributed as du
+        from csts_amd import ops
+        torch.manual_seed(3)
+        net = _TinyCSTS()
+        waits = []
+        main, side = _StubStream(1, waits), _StubStream(2, waits)
+        audio = list(net.blocks_audio.parameters())
+        audio_ids = {id(p) for p in audio}
+
+        class Wrapped(du.GradAllReduce):
+            def _cur_stream(self, grad):       # audio-trunk gradients are "produced on the side stream"
+                return side if any(grad is p_.grad for p_ in audio) else main
+
+        w = Wrapped(net, bucket_mb=0)
+        w.bucket_bytes = 700                   # a few parameters per bucket: video and audio gradients share buckets
+        w._assign(list(reversed(w._params)))
+        want_late = {n for n, _ in net.named_parameters() if any(t in n for t in (".norm1.", ".norm2.", ".norm_k.", ".pool_k."))}
+        ok_late = {n for n, p in net.named_parameters() if any(p is l for l in w._late)} == want_late and len(want_late) == 21
+        ok = True
+        for it in range(3):
+            gen = torch.Generator().manual_seed(50 + rank + 7 * it)
+            x, y = torch.randn(2, 5, 8, generator=gen), torch.randn(2, 5, 8, generator=gen)
+            for p in net.parameters():
+                p.grad = None
+            w(x, y).pow(2).sum().backward()
+            local = {n: p.grad.clone() for n, p in net.named_parameters()}
+            w.finish()
+            for n, p in net.named_parameters():
+                buf = [torch.empty_like(local[n]) for _ in range(world)]
+                dist.all_gather(buf, local[n])
+                ok = ok and bool(torch.allclose(p.grad, sum(buf) / world, atol=1e-6))
+        ok_order = w._observed and len(w._ready_order) == len(w._params) and not w._pending
+        # a bucket that holds both video and audio gradients is launched from one stream and must wait for the other
+        mixed = [bi for bi, b_ in enumerate(w._buckets) if 0 < sum(id(p) in audio_ids for p in b_) < len(b_)]
+        ok_wait = len(mixed) > 0 and len(waits) > 0 and all(a_ != b_ for a_, b_ in waits)
+        ok_mode = ops.GROUP_WGRADS == "never"            # hook-driven buckets read gradients mid-backward: no grouped tail
+        q.put((rank, bool(ok), bool(ok_late), bool(ok_order), bool(ok_wait), bool(ok_mode), len(mixed), len(waits)))
+    except Exception as e:       # surface the failure instead of a queue timeout
+        q.put((rank, False, False, False, False, False, repr(e), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_whole_grad_allreduce_on_csts_shaped_module():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dist_worker_whole, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert r[1], "averaged gradients != mean of the per-rank gradients"
+        assert r[2], "late bucket is not exactly the LayerNorm / pooling-stencil parameters"
+        assert r[3], "ready-order re-bucketing / pending buckets"
+        assert r[4], ("cross-stream waits", r[6], r[7])
+        assert r[5], "GradAllReduce must switch the grouped weight-gradient tail off"
+
+
 def test_two_rank_gloo_data_parallel_logic():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
