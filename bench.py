@@ -97,13 +97,14 @@ class GemmTimer:
                 rc = fn(argsref, stream)
                 e1.record()
                 esz = lambda dt: 4 if dt == 0 else 2
-                byt = a.M * a.K * esz(a.a_dt) + a.N * a.K * esz(a.b_dt) + a.M * a.N * esz(a.c_dt)
+                byt = a.M * a.K * esz(a.a_dt) + a.N * a.K * esz(a.b_dt) + a.M * a.N * esz(a.c_dt)     # A + B + C once
+                ext = 0                                            # compulsory epilogue operands on top of A + B + C
                 if a.aux:
-                    byt += a.M * a.N * esz(a.aux_dt)               # GELU pre-activation written / read
+                    ext += a.M * a.N * esz(a.aux_dt)               # GELU pre-activation written / read
                 if a.residual:
-                    byt += (a.res_row_mod if a.res_row_mod else a.M) * a.N * esz(a.r_dt)
+                    ext += (a.res_row_mod if a.res_row_mod else a.M) * a.N * esz(a.r_dt)
                 owner.records.append((name_buf.value.decode(), ns.value, 2.0 * a.M * a.N * a.K, byt, e0, e1,
-                                      (a.layout, a.M, a.N, a.K, ns.value)))
+                                      (a.layout, a.M, a.N, a.K, ns.value), ext))
                 return rc
             return timed
 
@@ -123,19 +124,20 @@ class GemmTimer:
         """kernel name -> [launches, flops, bytes, seconds, has_finish_pass]"""
         torch.cuda.synchronize()
         agg = {}
-        for name, ns, fl, by, e0, e1, _shape in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, False])
+        for name, ns, fl, by, e0, e1, _shape, ext in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, False, 0.0])
             a[0] += 1
             a[1] += fl
             a[2] += by
             a[3] += e0.elapsed_time(e1) * 1e-3
             a[4] = a[4] or ns > 1
+            a[5] += ext
         return agg
 
     def dump_shapes(self, path):
         torch.cuda.synchronize()
         per = {}
-        for name, ns, fl, by, e0, e1, shape in self.records:
+        for name, ns, fl, by, e0, e1, shape, ext in self.records:
             a = per.setdefault(shape + (name,), [0, 0.0, fl, by])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -226,7 +228,9 @@ def cpu_baseline(frames, mode, quick, budget_s=150.0):
     grid, B = 2 (EgoNCE is identically 0 at B = 1); the table adds 8 x 256^2 at B = 1 / 2 / 4, forward and train."""
     from oracle import csts_oracle as O
     model, phys, logical = _host_cpu()
-    threads = max(1, min(phys, logical))
+    # these op sizes stop scaling well before a big host's core count (EPYC 9575F box: 26.8 s per 16x256^2 B=2 train step
+    # with 128 threads, 10.6 s with 32): 32 threads, or every physical core when there are fewer
+    threads = max(1, min(phys, logical, 32))
     torch.set_num_threads(threads)
     t_start = time.time()
 
@@ -513,7 +517,7 @@ def main():
         # dominant kernel = the single-kernel GEMM variant (no split-K finishing pass inside the event pair) with the most time
         single = {k: v for k, v in agg.items() if not v[4]}
         name = max(single, key=lambda k: single[k][3]) if single else None
-        n, fl, by, sec, _ = agg.get(name, (0, 0.0, 0.0, 1.0, False))
+        n, fl, by, sec, _, ext = agg.get(name, (0, 0.0, 0.0, 1.0, False, 0.0))
         tot_sec = sum(a[3] for a in agg.values())
         tot_fl = sum(a[1] for a in agg.values())
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
@@ -536,6 +540,8 @@ def main():
                 "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed per round)",
                 "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2),
                 "algorithmic_flop_per_launch": round(fl / max(n, 1)), "algorithmic_bytes_per_launch": round(by / max(n, 1)),
+                "epilogue_operand_bytes_per_launch": round(ext / max(n, 1)),     # GELU pre-activation out / in, residual in: on top of A + B + C
+                "hbm_frac_incl_epilogue_operands": round((by + ext) / (PEAK_HBM_GBS * 1e9) / sec, 4),
                 "all_gemm_tflops": round(tot_fl / tot_sec / 1e12, 2), "all_gemm_ms_per_step": round(tot_sec / 2 * 1e3, 2),
                 "per_kernel": {k: {"launches_per_step": v[0] // 2, "avg_us": round(v[3] / v[0] * 1e6, 1),
                                    "tflops": round(v[1] / v[3] / 1e12, 1), "ms_per_step": round(v[3] / 2 * 1e3, 3)}

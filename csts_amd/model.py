@@ -10,6 +10,7 @@ through csts_amd.ops -> libcsts_hip.so.  Compute mode comes from ``cfg.CSTS_AMD.
 """
 from __future__ import annotations
 
+import logging
 import math
 import weakref
 from functools import partial
@@ -37,6 +38,31 @@ def round_width(width, multiplier, min_width=1, divisor=1):
     if out < 0.9 * width:
         out += divisor
     return int(out)
+
+
+_log = logging.getLogger("csts_amd")
+
+
+def resolve_compute(cfg) -> str:
+    """CSTS_AMD.COMPUTE ("fp32" | "bf16" | "auto") together with the reference's TRAIN.MIXED_PRECISION key
+    (slowfast/config/defaults.py:79; tools/train_avgaze_net.py:70,99-109,277: torch.cuda.amp.autocast = fp16 + GradScaler).
+    There is no fp16 mode here: MIXED_PRECISION True selects the bf16 mode -- bf16 MFMA operands with fp32 accumulation,
+    fp32 master weights, residual stream, LayerNorm statistics, softmax and losses, i.e. the tensors autocast keeps in fp32
+    -- and no loss scaling is applied (or needed: bf16 has fp32's exponent range, so GradScaler's overflow / skipped-step
+    logic has nothing to act on).  "auto" follows the key: False -> fp32 (the reference's default arithmetic), True -> bf16.
+    The key is never ignored silently: the mapping is logged."""
+    amd = getattr(cfg, "CSTS_AMD", None)
+    compute = str(getattr(amd, "COMPUTE", "auto") if amd is not None else "auto").lower()
+    mp = bool(getattr(getattr(cfg, "TRAIN", None), "MIXED_PRECISION", False))
+    if compute == "auto":
+        compute = "bf16" if mp else "fp32"
+    if mp:
+        if compute == "bf16":
+            _log.warning("TRAIN.MIXED_PRECISION True: the reference's fp16 autocast + GradScaler runs here as the bf16 compute mode "
+                         "(fp32 master weights / residual stream / statistics / losses, no loss scaling: bf16 has fp32's exponent range)")
+        else:
+            _log.warning("TRAIN.MIXED_PRECISION True but CSTS_AMD.COMPUTE is %r: the explicit compute mode wins, no mixed precision", compute)
+    return compute
 
 
 class Runtime:
@@ -198,7 +224,7 @@ class CSTS(nn.Module):
             raise NotImplementedError("csts_amd implements the configuration of the shipped CSTS YAMLs: no class "
                                       "token, separable pos-embed, 3-D patches, conv pooling, no dropout, no stem norm")
         amd = getattr(cfg, "CSTS_AMD", None)
-        self.rt = Runtime(amd.COMPUTE if amd is not None else "bf16")
+        self.rt = Runtime(resolve_compute(cfg))
         self.two_streams = bool(getattr(amd, "TWO_STREAMS", True)) if amd is not None else True
         rt = self.rt
         S, T = cfg.DATA.TRAIN_CROP_SIZE, cfg.DATA.NUM_FRAMES

@@ -359,3 +359,23 @@ def test_checkpoint_wire_format_reads_reference_written_pyth(tmp_path):
     again = Tiny(4, 3)
     assert ck.load_checkpoint(path, again)[0] == 2
     assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), src.state_dict().values()))
+
+
+def test_mixed_precision_key_is_mapped_not_ignored(caplog):
+    """TRAIN.MIXED_PRECISION (reference: fp16 autocast + GradScaler) selects the bf16 mode and says so; with COMPUTE "auto"
+    the reference default (False) means fp32 arithmetic."""
+    import logging
+    from csts_amd.config import load_yaml
+    from csts_amd.model import resolve_compute
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "CSTS_AMD.COMPUTE", "auto"])
+    assert resolve_compute(cfg) == "fp32"
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "CSTS_AMD.COMPUTE", "auto", "TRAIN.MIXED_PRECISION", True])
+    with caplog.at_level(logging.WARNING, logger="csts_amd"):
+        assert resolve_compute(cfg) == "bf16"
+    assert "MIXED_PRECISION" in caplog.text and "bf16" in caplog.text and "loss scaling" in caplog.text
+    caplog.clear()
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "CSTS_AMD.COMPUTE", "fp32", "TRAIN.MIXED_PRECISION", True])
+    with caplog.at_level(logging.WARNING, logger="csts_amd"):
+        assert resolve_compute(cfg) == "fp32"
+    assert "explicit compute mode wins" in caplog.text
+    assert resolve_compute(load_yaml(YAML, ["NUM_GPUS", 0])) == "bf16"      # the shipped YAMLs name their mode
