@@ -11,8 +11,10 @@
 // Operands whose reduction dim is NOT the contiguous one are kept [k][out] in LDS and fed to the MFMA through
 // ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32), so staging is always a straight 16-byte copy.
 #include "common.h"
+#include "gemm_shared.h"
 #include <type_traits>
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -27,16 +29,6 @@ template <bool F32> struct Cmp;
 template <> struct Cmp<false> { typedef bf16 T; };
 template <> struct Cmp<true> { typedef float T; };
 
-struct Params {
-  const void* A; const void* B; void* C;
-  const float* bias; void* aux; const void* residual; const float* row_scale; float* ws;
-  float* colsum; float* colsum_ws;   // TN only: colsum[m] = sum_k A[k][m] (bias gradient), fused into the v2 kernel
-  int64_t lda, ldb, ldc, ldaux, ldr;
-  int64_t M, N, K, res_row_mod, rows_per_scale, k_chunk;
-  int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
-  int64_t ntiles;   // gemm3 (persistent): output tiles of the whole problem
-  unsigned long long* stamps;   // gemm3 built with -DCSTS_GEMM3_STAMPS: cycle stamps of two workgroups (diagnostics)
-};
 
 // load 8 consecutive source elements (guarded) as floats
 __device__ __forceinline__ void load8(const void* p, int dt, int64_t idx, int nvalid, bool vec, float (&o)[8]) {
@@ -329,7 +321,6 @@ static void launch_finish(const Params& p, int nsplit, hipStream_t stream) {
 // tiles (small grids get twice the workgroups), and an epilogue staged through LDS so that every global
 // load/store of C / residual / aux is a coalesced 16-byte access.
 // =====================================================================================================
-constexpr int BK2 = 64;
 constexpr int KC2_LD = BK2 + 8;            // 144 B rows: conflict-free ds_read_b128 over 16 rows
 constexpr int CS_LD = 128 + 4;             // fp32 C staging row stride
 
@@ -611,54 +602,6 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
 // holds k-chunk s ^ ((r >> 1) & 7), which puts the 16 rows a 16-lane group reads on 16 distinct 16-byte slots.
 // Preconditions (host-checked): bf16 A and B, 16-byte aligned rows, K % 16 == 0, split_k == 1, gridDim.x % 8 == 0.
 // =====================================================================================================
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it leaves LDS-DMA loads in flight
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// 4 consecutive elements -> 4 floats
-__device__ __forceinline__ f32x4 ld4_as_f32(const void* p, int dt, int64_t i) {
-  if (dt == CSTS_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i);
-  const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + i);
-  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
-// Store a lane's four 4-column runs o[q] (columns c0 + 8 q .. + 3 of one row; c0 already includes this half-wave's
-// +4 * hi) at element offset `at` (= row * ld + c0).  fp32: one 16-byte store per run.  bf16: lanes l and l + 32 hold
-// adjacent runs of the same row, so v_permlane32_swap pairs them into 8 contiguous columns per lane -> one 16-byte
-// store per two runs (lower half-wave: columns 16 p .. + 7, upper: 16 p + 8 .. + 15, relative to the unit's first column).
-// Must be called with all lanes active (the swap is a cross-lane exchange); `rowok` / N only mask the stores.
-__device__ __forceinline__ void st4x4(void* base, int dt, int64_t at, const f32x4 (&o)[4], bool rowok, int64_t c0, int64_t N, int hi) {
-  if (dt == CSTS_F32) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (rowok && c0 + 8 * q < N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + at + 8 * q) = o[q];
-  } else {
-    uint2 pk[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bf16x4 b = {(bf16)o[q][0], (bf16)o[q][1], (bf16)o[q][2], (bf16)o[q][3]};
-      pk[q] = __builtin_bit_cast(uint2, b);
-    }
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      uint2 a = pk[2 * pr], b = pk[2 * pr + 1];
-      const auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-      const auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-      a.x = rx[0]; b.x = rx[1]; a.y = ry[0]; b.y = ry[1];
-      // lower half-wave now holds columns 16 pr .. 16 pr + 7 of the unit, the upper half-wave 16 pr + 8 .. 16 pr + 15
-      const int64_t cfirst = c0 - 4 * hi + 16 * pr + 8 * hi;
-      if (rowok && cfirst < N)
-        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(base) + at - 4 * hi + 16 * pr + 8 * hi) = make_uint4(a.x, a.y, b.x, b.y);
-    }
-  }
-}
-
 #ifdef CSTS_GEMM3_STAMPS
 #define G3_STAMP() do { if (stamp_on && nstamp < 500) stamp_buf[nstamp++] = (unsigned long long)clock64(); } while (0)
 #else
@@ -1087,6 +1030,29 @@ bool pick3(const csts_gemm_args* a, int split, int* mt, int* stages) {
   return true;
 }
 
+// Library heuristic for the 8-wave LDS-DMA kernel (gemm4.hip): filled in from tools/gemm4_lab.py measurements.
+// Measured on MI355X against the register-staged / 4-wave ring kernels (tools/gemm4_lab.py, profiles/r2_gemm4_lab.txt):
+// 128 x 192 tiles on 8 waves, 2 workgroups per CU, win 1.1-1.3 x wherever the grid gives >= 1 tile per workgroup slot; with
+// exactly one round of tiles and a long K the 3-stage ring (1 workgroup per CU) is ahead; problems with few 192-wide tiles
+// take 128 x 128 tiles on 8 waves.  The 256-row variants (256 x 128 / 192 / 256) measured 5-25 % SLOWER than these on every
+// CSTS shape: with K = 384..3072 a workgroup's k-loop is 6-48 steps, and bytes in flight per CU (resident workgroups),
+// not FLOP per staged byte, decide.  CSTS_GEMM4=0 switches the family off (A/B runs).
+bool pick4(const csts_gemm_args* a, int split, int* variant) {
+  static const bool enabled = [] { const char* e = getenv("CSTS_GEMM4"); return !(e && e[0] == '0'); }();
+  if (!enabled || a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->K % 64 != 0 || a->M < 2048) return false;
+  const int64_t rows = cdiv(a->M, 128);
+  if (a->N % 192 == 0 && rows * (a->N / 192) >= 256) {
+    *variant = (a->K >= 1536 && rows * (a->N / 192) <= 256) ? 63 : 62;
+    return true;
+  }
+  const int64_t t128 = rows * cdiv(a->N, 128);
+  if (a->N % 128 == 0 && t128 >= 128 && t128 <= 512) {
+    *variant = a->K >= 1024 ? 33 : 32;
+    return true;
+  }
+  return false;
+}
+
 template <int MT>
 void launch3_mt(const Params& p, int stages, dim3 grid, hipStream_t s) {
   if (stages == 2) hipLaunchKernelGGL((gemm3_kernel<MT, 2>), grid, dim3(256), 0, s, p);
@@ -1170,7 +1136,19 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
     CSTS_LAUNCH_CHECK();
     return 0;
   }
+  if (a->algo % 1000 >= 400 && a->algo % 1000 < 500) {   // forced: 1000 * workgroups-per-CU + 400 + gemm4 variant code (gemm4.hip)
+    CSTS_REQUIRE(v3_ok(a, split), "algo 4xx (8-wave LDS-DMA NT kernel) not applicable to this problem");
+    CSTS_REQUIRE(csts_gemm4_launch(p, a, a->algo % 1000 - 400, a->algo / 1000, stream), "unknown gemm4 variant");
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   {
+    int v4;
+    if (pick4(a, split, &v4)) {
+      csts_gemm4_launch(p, a, v4, 0, stream);
+      CSTS_LAUNCH_CHECK();
+      return 0;
+    }
     int mt3, st3;
     if (pick3(a, split, &mt3, &st3)) {
       launch3(p, a, mt3, st3, 0, stream);
@@ -1228,7 +1206,13 @@ extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, 
   const int bk = use_v2 ? BK2 : BK;
   const int64_t k_chunk = cdiv(cdiv(a->K, bk), split) * bk;
   const int64_t ns = cdiv(a->K, k_chunk);
-  int mt3, st3;
+  int mt3, st3, v4;
+  if (pick4(a, split, &v4)) {          // gemm4 variant v4 (name: csts_gemm_kernel_name)
+    *v2 = 400 + v4;
+    *nsplit = 1;
+    *tile_rows = 0;
+    return 0;
+  }
   if (pick3(a, split, &mt3, &st3)) {   // gemm3_kernel<tile_rows / 64, stages>
     *v2 = 30 + st3;
     *nsplit = 1;
@@ -1247,6 +1231,11 @@ extern "C" int csts_gemm_kernel_name(const csts_gemm_args* a, char* buf, int buf
   int v2 = 0, rows = 0;
   if (csts_gemm_plan(a, &v2, &rows, nsplit) != 0) return -1;
   auto tf = [](bool b) { return b ? "true" : "false"; };
+  if (a->algo % 1000 >= 400 && a->algo % 1000 < 500) {
+    *nsplit = 1;
+    return csts_gemm4_name(a->algo % 1000 - 400, buf, buflen) ? 0 : -1;
+  }
+  if (v2 >= 400) return csts_gemm4_name(v2 - 400, buf, buflen) ? 0 : -1;
   if (v2 >= 30) snprintf(buf, buflen, "gemm3_kernel<%d, %d>", rows / 64, v2 - 30);
   else if (v2)
     snprintf(buf, buflen, "gemm2_kernel<%s, %s, %s, %s, %d, 2>", tf(a->layout != CSTS_GEMM_TN), tf(a->layout == CSTS_GEMM_NT),

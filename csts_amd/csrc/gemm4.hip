@@ -1,0 +1,274 @@
+// gemm4: PERSISTENT NT kernel (activations x bf16 shadow weights, both k-contiguous) on 8-wave workgroups.
+//
+// Why: a 128 x 128 x 64 k-step moves 32 KiB through the CU's vector-memory path for 16 MFMAs per wave -- the two take
+// the same ~512 cycles, so 4-wave 128-row tiles sit ON the ridge between the L2 -> LDS path and the matrix pipe and every
+// variant of them measured alike ("What bounds the activation GEMMs").  Here a workgroup is 8 waves (two per
+// SIMD: one wave's fragment reads / LDS-DMA issue / waits run under its partner's MFMAs) on a 256-row tile, 128 / 192 /
+// 256 columns wide: 85 / 110 / 128 FLOP per staged byte instead of 64, i.e. 1.33 - 2 x fewer bytes through L2 -> LDS per
+// FLOP, and the row panel of A is read by half as many column tiles.
+//
+// Structure (as gemm3, gemm.hip): a workgroup owns a list of output tiles (an XCD works on a contiguous tile range, n
+// fastest: the column tiles of one A row panel follow each other on one L2) and runs ONE flattened stream of 64-deep
+// k-tiles over them; operand tiles go L2/HBM -> LDS by global_load_lds_dwordx4 into a ring of S stages that stays in
+// flight across the single raw s_barrier of a k-step (counted s_waitcnt vmcnt) and across tile boundaries; the LDS image
+// is lane-linear per wave-instruction (8 rows x 128 B) with the XOR swizzle on the per-lane SOURCE address and on the
+// fragment read; MFMA operands are swapped (weights as the row operand) so that a lane owns 4-column runs of one output
+// row and the epilogue goes straight from the accumulators to 16-byte stores (v_permlane32_swap pairs for bf16).
+// Wave grid WM x 2, wave tile (32 MT) x (32 NT): tile (32 MT WM) x (64 NT).
+// Preconditions (host-checked): bf16 A and B, 16-byte aligned rows, K % 16 == 0, split_k == 1, gridDim.x % 8 == 0.
+#include "gemm_shared.h"
+#include <algorithm>
+#include <cstdio>
+#include <type_traits>
+
+namespace {
+
+template <int WM, int MT, int NT, int S> struct G4 {
+  static constexpr int DB = (MT * NT >= 6) ? 1 : 2;      // fragment register sets: the 96 / 128-accumulator tiles have no room for two
+  static constexpr int NWAVES = WM * 2, NTHR = 64 * NWAVES;
+  static constexpr int BM = WM * 32 * MT, BN = 64 * NT;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int NA = BM / 8 / NWAVES, NB = BN / 8 / NWAVES, LPT = NA + NB;   // LDS-DMA instructions per thread per k-tile
+  static constexpr int FIT = (160 * 1024) / (S * STAGE);
+  static constexpr int WG = FIT < 1 ? 1 : (FIT > 2 ? 2 : FIT);                        // workgroups per CU the register budget is set for
+  static constexpr int WPS = (WG * NWAVES + 3) / 4;                                   // waves per SIMD
+  static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "pieces must divide over the waves");
+  static_assert(S * STAGE <= 160 * 1024, "ring exceeds the CU's LDS");
+  static_assert(2 * LPT <= 63, "vmcnt immediate");
+};
+
+// KTAIL: K % 64 != 0 (a last k-tile of 16, 32 or 48) is supported; without it the k-loop carries no tail code at all.
+template <int WM, int MT, int NT, int S, bool KTAIL>
+__global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)) void gemm4_kernel(Params p) {
+  typedef G4<WM, MT, NT, S> G;
+  constexpr int BM = G::BM, BN = G::BN, A_BYTES = G::A_BYTES, STAGE = G::STAGE, NA = G::NA, NB = G::NB, LPT = G::LPT;
+  __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it (and all it feeds) scalar
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nk = (int)((p.K + BK2 - 1) / BK2), nk_full = (int)(p.K / BK2), k_tail = KTAIL ? (int)((p.K % BK2) >> 4) : 0;
+
+  // this workgroup's tiles: XCD x (= blockIdx.x % 8: workgroups are dealt round-robin over the XCDs) owns a contiguous
+  // range of tiles; its workgroups walk the range with stride = workgroups on the XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  const int64_t tq = p.ntiles >> 3, tr = p.ntiles & 7;
+  const int64_t t_beg = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq), t_end = t_beg + tq + (xcd < tr ? 1 : 0);
+  const int64_t t_first = t_beg + slot;
+  const int my_tiles = t_first < t_end ? (int)((t_end - t_first + stride - 1) / stride) : 0;
+  const int total_k = my_tiles * nk;
+
+  // ---- producer side: per-lane source offsets (bytes, relative to the tile's first row) of the pieces this wave stages
+  // (8 rows x 128 B per wave-instruction); chunk slot (lane & 7) of row r holds k-chunk (lane & 7) ^ ((r >> 1) & 7)
+  unsigned aoff[NA], boff[NB];
+  const char* abase = nullptr;                       // wave-uniform: first row of the current producer tile
+  const char* bbase = nullptr;
+  auto chunk = [&](int piece) { return ((lane & 7) ^ (((piece * 8 + (lane >> 3)) >> 1) & 7)) * 16; };   // bytes
+  auto set_tile = [&](int64_t t) {
+    const int64_t m0 = (t / p.ntiles_n) * BM, n0 = (t % p.ntiles_n) * BN;
+    abase = reinterpret_cast<const char*>(p.A) + m0 * p.lda * 2;
+    bbase = reinterpret_cast<const char*>(p.B) + n0 * p.ldb * 2;
+    const int ra = (int)min((int64_t)BM, p.M - m0) - 1, rb = (int)min((int64_t)BN, p.N - n0) - 1;   // last valid row of the tile
+#pragma unroll
+    for (int i = 0; i < NA; ++i) aoff[i] = (unsigned)(min((wave * NA + i) * 8 + (lane >> 3), ra) * (int)p.lda * 2 + chunk(wave * NA + i));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) boff[i] = (unsigned)(min((wave * NB + i) * 8 + (lane >> 3), rb) * (int)p.ldb * 2 + chunk(wave * NB + i));
+  };
+  int64_t pt = t_first;                              // producer position: tile, k-tile inside it, flattened index
+  int pk = 0, pidx = 0, pstage = 0;
+  auto issue = [&](int i, char* st, int64_t k0, bool full) {      // LDS-DMA instruction i of this thread's share of a k-tile
+    const int piece = (i < NA) ? wave * NA + i : wave * NB + (i - NA);
+    unsigned off = (i < NA) ? aoff[i] : boff[i - NA];
+    if (KTAIL && !full && k0 + chunk(piece) / 2 >= p.K) off -= chunk(piece);   // chunks past K are fetched from chunk 0 (never used)
+    const char* src = ((i < NA) ? abase : bbase) + k0 * 2 + off;
+    char* dst = st + ((i < NA) ? 0 : A_BYTES) + piece * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+  };
+  auto advance = [&]() {
+    ++pidx;
+    pstage = (pstage + 1 == S) ? 0 : pstage + 1;
+    if (++pk == nk) {
+      pk = 0;
+      pt += stride;
+      if (pidx < total_k) set_tile(pt);
+    }
+  };
+  if (my_tiles > 0) set_tile(pt);
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) {
+    if (pidx < total_k) {
+      char* st = smem_raw + pstage * STAGE;
+      const int64_t k0 = (int64_t)pk * BK2;
+      const bool full = !KTAIL || k0 + BK2 <= p.K;
+#pragma unroll
+      for (int i = 0; i < LPT; ++i) issue(i, st, k0, full);
+      advance();
+    }
+  }
+
+  // ---- consumer side.  Fragment row = obase + (lane & 31) with obase % 32 == 0: the swizzle key is a per-lane constant
+  const int key = (lane >> 1) & 7, hi = lane >> 5;
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = (lane & 31) * 128 + (((ks * 2 + hi) ^ key) << 4);
+  int cidx = 0, cstage = 0;
+
+  for (int64_t t = t_first; t < t_end; t += stride) {
+    // The MFMA operands are SWAPPED (weights as the row operand): acc[mi][ni][r] is C[m][n] with m = the lane's row
+    // (lane & 31) of 32-row unit mi and n = 32 * ni + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3) -- every lane owns runs of
+    // 4 consecutive columns of ONE output row, so the epilogue needs no LDS transpose and no barrier.
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int64_t m0 = (t / p.ntiles_n) * BM + wm * 32 * MT + (lane & 31), n0 = (t % p.ntiles_n) * BN + wn * 32 * NT + 4 * hi;
+
+    auto kstep = [&](auto nks_tag) {
+      constexpr int NKS = decltype(nks_tag)::value;
+      // k-tile cidx has landed once at most `ahead` younger k-tiles (LPT instructions each) are outstanding; epilogue
+      // stores issued meanwhile are younger still, so the count only ever over-waits
+      const int ahead = min(S - 2, total_k - 1 - cidx);
+      if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
+      else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();                  // every wave's share landed; everyone is done with the previous stage
+      const char* As = smem_raw + cstage * STAGE;
+      const char* Bs = As + A_BYTES;
+      cstage = (cstage + 1 == S) ? 0 : cstage + 1;
+      ++cidx;
+      const bool refill = pidx < total_k;            // wave-uniform
+      char* st = smem_raw + pstage * STAGE;
+      const int64_t k0 = (int64_t)pk * BK2;
+      const bool full = !KTAIL || k0 + BK2 <= p.K;
+      constexpr int DB = G::DB;
+      bf16x8 fa[DB][MT], fb[DB][NT];
+      auto frags = [&](int ks, int buf) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          fb[buf][j] = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 * NT + j * 32) * 128 + foff[ks]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          fa[buf][i] = *reinterpret_cast<const bf16x8*>(As + (wm * 32 * MT + i * 32) * 128 + foff[ks]);
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (DB == 2 && ks + 1 < NKS) frags(ks + 1, (ks + 1) & 1);
+        if (refill) {
+#pragma unroll
+          for (int i = 0; i < LPT; ++i) {
+            // (front-loading the refill at ks == 0 measured 4-8 % slower on the 2-stage variants: the issue cost of 5-8
+            // LDS-DMA instructions in a row is not hidden even with a partner wave)
+            const bool mine = (NKS == 4) ? (i * 4 / LPT == ks) : (ks == 0);
+            if (mine) issue(i, st, k0, full);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & (DB - 1)][j], fa[ks & (DB - 1)][i], acc[i][j], 0, 0, 0);
+        if (DB == 1 && ks + 1 < NKS) frags(ks + 1, 0);
+      }
+      if (refill) advance();
+    };
+    for (int kt = 0; kt < nk_full; ++kt) kstep(std::integral_constant<int, 4>());
+    if constexpr (KTAIL) {                                           // K % 64 = 16, 32 or 48 (K % 16 == 0)
+      if (k_tail == 1) kstep(std::integral_constant<int, 1>());
+      else if (k_tail == 2) kstep(std::integral_constant<int, 2>());
+      else if (k_tail == 3) kstep(std::integral_constant<int, 3>());
+    }
+
+    // ---------------- epilogue straight from the accumulators (same arithmetic order as gemm2_kernel / gemm3_kernel)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int64_t m = m0 + mi * 32;
+      const bool mok = m < p.M;
+      float rsc = 1.f;
+      if (p.row_scale != nullptr && mok) rsc = p.row_scale[m / p.rows_per_scale];
+      const int64_t rm = (p.residual != nullptr && p.res_row_mod > 0) ? (m % p.res_row_mod) : m;
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        f32x4 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t c = n0 + ni * 32 + 8 * q;
+          const bool ok = mok && c < p.N;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias != nullptr && c < p.N) v = *reinterpret_cast<const f32x4*>(p.bias + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += acc[mi][ni][4 * q + j];
+          if (p.epilogue == CSTS_EPI_DGELU) {
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+            if (ok) h = ld4_as_f32(p.aux, p.aux_dt, m * p.ldaux + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= (p.aux_dt == CSTS_BF16) ? dgelu_fast(h[j]) : dgelu_f(h[j]);
+          }
+          o[q] = v;
+        }
+        if (p.epilogue == CSTS_EPI_GELU) {
+          if (p.aux != nullptr) st4x4(p.aux, p.aux_dt, m * p.ldaux + n0 + ni * 32, o, mok, n0 + ni * 32, p.N, hi);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[q][j] = (p.aux_dt == CSTS_BF16) ? gelu_fast(o[q][j]) : gelu_f(o[q][j]);
+        }
+        if (p.row_scale != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] *= rsc;
+        }
+        if (p.residual != nullptr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t c = n0 + ni * 32 + 8 * q;
+            if (mok && c < p.N) o[q] += ld4_as_f32(p.residual, p.r_dt, rm * p.ldr + c);
+          }
+        }
+        st4x4(p.C, p.c_dt, m * p.ldc + n0 + ni * 32, o, mok, n0 + ni * 32, p.N, hi);
+      }
+    }
+  }
+  wait_vm<0>();
+}
+
+template <int WM, int MT, int NT, int S, bool TAIL_OK>
+bool launch4(Params p, int wpc, hipStream_t s) {
+  typedef G4<WM, MT, NT, S> G;
+  const int64_t ntiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN);
+  p.ntiles = ntiles;
+  p.ntiles_n = (int)cdiv(p.N, G::BN);
+  if (wpc <= 0 || wpc > G::WG) wpc = G::WG;
+  const int64_t g = std::min<int64_t>(cdiv(ntiles, 8) * 8, (int64_t)256 * wpc);
+  if (p.K % BK2 == 0) hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, false>), dim3((unsigned)g), dim3(G::NTHR), 0, s, p);
+  else if (TAIL_OK) hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, TAIL_OK>), dim3((unsigned)g), dim3(G::NTHR), 0, s, p);
+  else return false;
+  return true;
+}
+
+struct Variant { int code, wm, mt, nt, s; };
+// shape ids: 0 = 256x128, 1 = 256x192, 2 = 256x256 (8 waves, wave tile 64 x 64/96/128);
+//            3 = 128x128, 6 = 128x192, 4 = 128x256 (8 waves, wave tile 32 x 64/96/128); 5 = 128x128 on 4 waves (wave tile 64 x 64)
+#define G4_VARIANTS(X) \
+  X(2, 4, 2, 2, 2) X(3, 4, 2, 2, 3) X(12, 4, 2, 3, 2) X(22, 4, 2, 4, 2) \
+  X(32, 4, 1, 2, 2) X(33, 4, 1, 2, 3) X(34, 4, 1, 2, 4) X(62, 4, 1, 3, 2) X(63, 4, 1, 3, 3) X(42, 4, 1, 4, 2) X(43, 4, 1, 4, 3) \
+  X(52, 2, 2, 2, 2) X(53, 2, 2, 2, 3)
+
+}  // namespace
+
+bool csts_gemm4_launch(const csts_gemm_params& p, const csts_gemm_args* a, int variant, int wpc, hipStream_t s) {
+  (void)a;
+#define X(code, wm, mt, nt, st) if (variant == code) return launch4<wm, mt, nt, st, false>(p, wpc, s);
+  G4_VARIANTS(X)
+#undef X
+  return false;
+}
+
+bool csts_gemm4_name(int variant, char* buf, int buflen) {
+#define X(code, wm, mt, nt, st) if (variant == code) { snprintf(buf, buflen, "gemm4_kernel<%d, %d, %d, %d, false>", wm, mt, nt, st); return true; }
+  G4_VARIANTS(X)
+#undef X
+  return false;
+}

@@ -1,0 +1,75 @@
+// Shared between gemm.hip (dispatcher, register-staged and LDS-DMA ring kernels) and gemm4.hip (8-wave LDS-DMA ring kernel).
+#pragma once
+#include "common.h"
+
+struct csts_gemm_params {
+  const void* A; const void* B; void* C;
+  const float* bias; void* aux; const void* residual; const float* row_scale; float* ws;
+  float* colsum; float* colsum_ws;   // TN only: colsum[m] = sum_k A[k][m] (bias gradient), fused into the v2 kernel
+  int64_t lda, ldb, ldc, ldaux, ldr;
+  int64_t M, N, K, res_row_mod, rows_per_scale, k_chunk;
+  int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
+  int64_t ntiles;   // gemm3 (persistent): output tiles of the whole problem
+  unsigned long long* stamps;   // gemm3 built with -DCSTS_GEMM3_STAMPS: cycle stamps of two workgroups (diagnostics)
+};
+
+namespace {
+
+constexpr int BK2 = 64;                    // k-tile of the bf16 kernels
+
+typedef csts_gemm_params Params;
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it leaves LDS-DMA loads in flight
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 4 consecutive elements -> 4 floats
+__device__ __forceinline__ f32x4 ld4_as_f32(const void* p, int dt, int64_t i) {
+  if (dt == CSTS_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i);
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + i);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+// Store a lane's four 4-column runs o[q] (columns c0 + 8 q .. + 3 of one row; c0 already includes this half-wave's
+// +4 * hi) at element offset `at` (= row * ld + c0).  fp32: one 16-byte store per run.  bf16: lanes l and l + 32 hold
+// adjacent runs of the same row, so v_permlane32_swap pairs them into 8 contiguous columns per lane -> one 16-byte
+// store per two runs (lower half-wave: columns 16 p .. + 7, upper: 16 p + 8 .. + 15, relative to the unit's first column).
+// Must be called with all lanes active (the swap is a cross-lane exchange); `rowok` / N only mask the stores.
+__device__ __forceinline__ void st4x4(void* base, int dt, int64_t at, const f32x4 (&o)[4], bool rowok, int64_t c0, int64_t N, int hi) {
+  if (dt == CSTS_F32) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (rowok && c0 + 8 * q < N) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + at + 8 * q) = o[q];
+  } else {
+    uint2 pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16x4 b = {(bf16)o[q][0], (bf16)o[q][1], (bf16)o[q][2], (bf16)o[q][3]};
+      pk[q] = __builtin_bit_cast(uint2, b);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      uint2 a = pk[2 * pr], b = pk[2 * pr + 1];
+      const auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+      const auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+      a.x = rx[0]; b.x = rx[1]; a.y = ry[0]; b.y = ry[1];
+      // lower half-wave now holds columns 16 pr .. 16 pr + 7 of the unit, the upper half-wave 16 pr + 8 .. 16 pr + 15
+      const int64_t cfirst = c0 - 4 * hi + 16 * pr + 8 * hi;
+      if (rowok && cfirst < N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(base) + at - 4 * hi + 16 * pr + 8 * hi) = make_uint4(a.x, a.y, b.x, b.y);
+    }
+  }
+}
+
+}  // namespace
+
+// gemm4.hip: persistent NT kernel, 256-row (8-wave) and 128-row (4- or 8-wave) tiles, LDS-DMA ring.
+// variant = 10 * shape + stages (see gemm4.hip); returns false when the variant does not exist.
+bool csts_gemm4_launch(const csts_gemm_params& p, const csts_gemm_args* a, int variant, int wpc, hipStream_t s);
+bool csts_gemm4_name(int variant, char* buf, int buflen);
