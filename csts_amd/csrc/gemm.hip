@@ -1040,6 +1040,11 @@ bool pick3(const csts_gemm_args* a, int split, int* mt, int* stages) {
 bool pick4(const csts_gemm_args* a, int split, int* variant) {
   static const bool enabled = [] { const char* e = getenv("CSTS_GEMM4"); return !(e && e[0] == '0'); }();
   if (!enabled || a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->K % 64 != 0 || a->M < 2048) return false;
+  // Inside the train step (bench.py --dump-gemm, same-box A/B, profiles/r2_gemm4_instep_ab.txt) the family wins 5-23 % on
+  // the GEMMs with a bf16 output (qkv, fc1 + GELU, the data gradients that feed bf16) and LOSES 5-15 % on the fp32
+  // residual-stream outputs (proj, fc2: C and the residual are 4 bytes per element and the register epilogue reaches them in
+  // 32-byte row segments, where gemm2's LDS-staged epilogue moves whole 128-byte lines): bf16 outputs only.
+  if (a->c_dt != CSTS_BF16 || a->residual != nullptr) return false;
   const int64_t rows = cdiv(a->M, 128);
   if (a->N % 192 == 0 && rows * (a->N / 192) >= 256) {
     *variant = (a->K >= 1536 && rows * (a->N / 192) <= 256) ? 63 : 62;
