@@ -220,6 +220,13 @@ def flush_deferred():
 # forward were measured), so eager steps keep the in-line split-K weight gradients unless CSTS_GROUP_WGRADS=1 forces
 # grouping; CSTS_GROUP_WGRADS=0 switches it off everywhere.
 GROUP_WGRADS = {"0": "never", "1": "always"}.get(os.environ.get("CSTS_GROUP_WGRADS", ""), "capture")
+# 192 x 384 tiles on 8-wave workgroups (wgrad8.hip: half the operand bytes per FLOP through L2 -> CU).  Correct
+# (test_grouped_weight_gradients_match_inline runs it) but measured NEUTRAL in the step on MI355X: 1541 us against the 1497 us
+# the same layers took as 128 x 128 / 256 x 128 items, 25.14-25.17 ms vs 25.19 ms per step, any token chunk from 1024 to 8192
+# (profiles/r2_wgrad8_ab.txt) -- the grouped weight gradients are not bound by operand traffic.  Off unless CSTS_WGRAD8=1.
+WGRAD8 = os.environ.get("CSTS_WGRAD8", "0") == "1"
+WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "4096"))   # tokens per 192 x 384 work item: one workgroup per CU, so the
+#   ~264 whole-layer items of the 384-channel stage (8192 tokens each) would run as two rounds on 256 CUs
 WGRAD_CHUNK = int(os.environ.get("CSTS_WGRAD_CHUNK", "8192"))   # tokens per work item (measured per step: 4096 -> 24.93 ms, 8192 -> 24.95, 16384 -> 25.47)
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 _wg_tables = {}
@@ -258,7 +265,7 @@ def _wg_dtype():
     return _WG_DTYPE
 
 
-def _wg_plan(sig, rows=128):
+def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
     """Work-item layout of one grouped launch for the problem list `sig` = ((tokens, N, K), ...): everything except the
     device addresses, which change from step to step.  Cached: building ~7000 items in Python costs ~15 ms.
 
@@ -267,18 +274,19 @@ def _wg_plan(sig, rows=128):
     is laid out at positions x, x + 8, x + 16, ... (rocprofv3: 7x the algorithmic HBM bytes when consecutive tiles landed
     on different XCDs).  Padding slots keep A == NULL (the kernel skips them)."""
     import numpy as np
-    plan = _wg_plans.get((sig, rows))
+    CH = chunk_tokens or WGRAD_CHUNK
+    plan = _wg_plans.get((sig, rows, cols, CH))
     if plan is not None:
         return plan
     groups = []
     for pi, (tokens, N, K) in enumerate(sig):
-        nch = -(-tokens // WGRAD_CHUNK)
+        nch = -(-tokens // CH)
         for c in range(nch):
-            kb, ke = c * WGRAD_CHUNK, min(tokens, (c + 1) * WGRAD_CHUNK)
+            kb, ke = c * CH, min(tokens, (c + 1) * CH)
             # one group = ALL tiles of this (layer, token chunk): they run together on one XCD and stream the same
             # token range in near lockstep, so its L2 serves every dY / X panel slice to all the tiles that share it
             # (grouping by tile-row only reused the dY panel: rocprofv3 still counted 18.6 GB per launch)
-            groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, rows) for n0 in range(0, K, 128)])
+            groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, rows) for n0 in range(0, K, cols)])
     groups.sort(key=lambda g_: -g_[0][0] * len(g_))
     lists, load = [[] for _ in range(8)], [0] * 8
     for g_ in groups:
@@ -299,7 +307,7 @@ def _wg_plan(sig, rows=128):
             tmpl[i] = (0, 0, 0, 0, N, K, K, kb, ke, N, K, m0, n0)
             pidx[i], chunk[i] = pi, c
     valid = pidx >= 0
-    plan = _wg_plans[(sig, rows)] = (tmpl, valid, pidx[valid], chunk[valid], n_items)
+    plan = _wg_plans[(sig, rows, cols, CH)] = (tmpl, valid, pidx[valid], chunk[valid], n_items)
     return plan
 
 
@@ -312,20 +320,27 @@ def flush_wgrads():
     dev = q[0][0].device
     tab = _wg_tables.get(dev.index)
     if tab is None:
-        tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=3, captures=16)
+        tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=6, captures=16)
     keep = []
-    # 256 x 128 tiles where they divide the layer's output rows (bf16 dY): a quarter less operand traffic per FLOP
-    for a_f32, rows in ((False, 256), (False, 128), (True, 128)):
-        wants256 = lambda t: not a_f32 and t[5] % 256 == 0
-        probs = [t for t in q if (t[0].dtype == torch.float32) == a_f32 and (wants256(t) == (rows == 256))]
+    # tile classes: 192 x 384 on 8-wave workgroups where it divides the layer (the 384- and 768-channel stages: half the
+    # operand bytes per FLOP of a 128 x 128 tile); else 256 x 128 where 256 divides the output rows; else 128 x 128
+    def tile_class(t):
+        if t[0].dtype == torch.float32:
+            return (True, 128)
+        if WGRAD8 and t[5] % 192 == 0 and t[6] % 384 == 0:
+            return (False, 192)
+        return (False, 256 if t[5] % 256 == 0 else 128)
+    for a_f32, rows in ((False, 192), (False, 256), (False, 128), (True, 128)):
+        probs = [t for t in q if tile_class(t) == (a_f32, rows)]
         if not probs:
             continue
-        tmpl, valid, pidx, chunk, n_items = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows)
+        CH = WGRAD8_CHUNK if rows == 192 else WGRAD_CHUNK
+        tmpl, valid, pidx, chunk, n_items = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, 384 if rows == 192 else 128, CH)
         A = np.empty(len(probs), dtype=np.uint64); B = np.empty_like(A); Cb = np.empty_like(A); Cs = np.zeros_like(A)
         cstride = np.zeros(len(probs), dtype=np.uint64); sstride = np.zeros_like(cstride)
         for i, (dY, X, dW, db, tokens, N, K) in enumerate(probs):
             A[i], B[i] = dY.data_ptr(), X.data_ptr()
-            nch = -(-tokens // WGRAD_CHUNK)
+            nch = -(-tokens // CH)
             if nch == 1:
                 Cb[i], Cs[i] = dW.data_ptr(), (db.data_ptr() if db is not None else 0)
             else:          # several token chunks: one partial slab per chunk, summed by the batched reducer
@@ -345,7 +360,10 @@ def flush_wgrads():
         arr["C"][valid] = Cb[pidx] + ch * cstride[pidx]
         arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
         ptr = tab.upload(arr.tobytes())
-        L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
+        if rows == 192:
+            L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
+        else:
+            L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
     del q, keep
 
 

@@ -79,6 +79,9 @@ typedef struct {
   int M, N, m0, n0;
 } csts_wgrad_item;
 int csts_wgrad_grouped(const csts_wgrad_item* device_items, int nitems, int a_f32, int tile_rows, hipStream_t stream);
+/* the same items as 192 x 384 tiles on 8-wave workgroups (bf16 dY; M % 192 == 0 and N % 384 == 0 layers): half the operand
+ * bytes per FLOP through the L2 -> CU path */
+int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStream_t stream);
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */
