@@ -70,9 +70,10 @@ def _plain(cfg):
 
 
 def load_checkpoint(path_to_checkpoint, model, data_parallel=False, optimizer=None, scaler=None, epoch_reset=False,
-                    clear_name_pattern=()):
+                    clear_name_pattern=(), report=None):
     """checkpoint.py:185-354 for the PyTorch (.pyth) branch: name + shape matching, pos-embed interpolation, optional
-    optimizer state.  Returns the checkpoint's epoch (-1 when fine-tuning / epoch_reset)."""
+    optimizer state.  Returns the checkpoint's epoch (-1 when fine-tuning / epoch_reset), like the reference; pass a list
+    as `report` to receive the names of the model entries the checkpoint did not provide (the reference only logs them)."""
     assert os.path.exists(path_to_checkpoint), "Checkpoint '{}' not found".format(path_to_checkpoint)
     ms = _core(model) if data_parallel or hasattr(model, "module") else model
     with open(path_to_checkpoint, "rb") as f:
@@ -98,20 +99,22 @@ def load_checkpoint(path_to_checkpoint, model, data_parallel=False, optimizer=No
             optimizer.load_state_dict(checkpoint["optimizer_state"])
         if scaler is not None and "scaler_state" in checkpoint:
             scaler.load_state_dict(checkpoint["scaler_state"])
-    return epoch, not_loaded
+    if report is not None:
+        report.extend(not_loaded)
+    return epoch
 
 
 def load_train_checkpoint(cfg, model, optimizer, scaler=None):
     """checkpoint.py:617-659: auto-resume from OUTPUT_DIR, else TRAIN.CHECKPOINT_FILE_PATH (fine-tune init), else epoch 0.
     (The separate video + audio pre-training pair of :645-656 is not provided.)"""
     if cfg.TRAIN.AUTO_RESUME and has_checkpoint(cfg.OUTPUT_DIR):
-        epoch, _ = load_checkpoint(get_last_checkpoint(cfg.OUTPUT_DIR), model, cfg.NUM_GPUS > 1, optimizer, scaler=scaler)
+        epoch = load_checkpoint(get_last_checkpoint(cfg.OUTPUT_DIR), model, cfg.NUM_GPUS > 1, optimizer, scaler=scaler)
         return epoch + 1
     if cfg.TRAIN.CHECKPOINT_FILE_PATH != "":
         if getattr(cfg.TRAIN, "AUDIO_CHECKPOINT_FILE_PATH", "") != "":
             raise NotImplementedError("separate video / audio pre-training checkpoints (checkpoint.py:357-470) are out of scope")
-        epoch, _ = load_checkpoint(cfg.TRAIN.CHECKPOINT_FILE_PATH, model, cfg.NUM_GPUS > 1, optimizer, scaler=scaler,
-                                   epoch_reset=cfg.TRAIN.CHECKPOINT_EPOCH_RESET,
-                                   clear_name_pattern=getattr(cfg.TRAIN, "CHECKPOINT_CLEAR_NAME_PATTERN", ()))
+        epoch = load_checkpoint(cfg.TRAIN.CHECKPOINT_FILE_PATH, model, cfg.NUM_GPUS > 1, optimizer, scaler=scaler,
+                                epoch_reset=cfg.TRAIN.CHECKPOINT_EPOCH_RESET,
+                                clear_name_pattern=getattr(cfg.TRAIN, "CHECKPOINT_CLEAR_NAME_PATTERN", ()))
         return epoch + 1
     return 0

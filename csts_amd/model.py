@@ -366,6 +366,15 @@ class CSTS(nn.Module):
             st = _SIDE_STREAMS[self] = torch.cuda.Stream()
         return st
 
+    def head_parameters(self):
+        """Parameters of everything after the encoder trunks (fusion convs and blocks, decoder, classifier, EgoNCE
+        projections): the first gradient bucket of csts_amd.train.SegmentedTrainStep (complete when the decoder / fusion
+        backward is, 60 % of all gradient bytes)."""
+        mods = [self.vision_pool, self.audio_pool, self.audio_pool2, self.temporal_fusion, self.spatial_fusion,
+                self.decode_block1, self.decode_block2, self.decode_block3, self.decode_block4, self.classifier]
+        mods += [getattr(self, n) for n in ("vision_proj", "audio_proj") if hasattr(self, n)]
+        return [p for m_ in mods for p in m_.parameters()]
+
     @torch.jit.ignore
     def no_weight_decay(self):
         """custom_multimodal_builder.py:327-341."""

@@ -156,6 +156,11 @@ class FusedAdamW:
         if len(state) not in (0, len(self.params)):
             raise ValueError("optimizer state has a different number of parameters")
         steps = set()
+        for i, p in enumerate(self.params):       # refuse a state whose tensors do not fit the parameters at the same positions
+            st = state.get(i, state.get(str(i)))
+            if st is not None and (st["exp_avg"].numel() != p.numel() or st["exp_avg_sq"].numel() != p.numel()):
+                raise ValueError(f"optimizer state {i}: {tuple(st['exp_avg'].shape)} does not fit parameter {tuple(p.shape)} "
+                                 "(parameter groups / order differ from the run that wrote the checkpoint)")
         for i, p in enumerate(self.params):
             st = state.get(i, state.get(str(i)))
             if st is None:

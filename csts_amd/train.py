@@ -53,12 +53,15 @@ def construct_optimizer(model, cfg, capturable: bool = False, device_fused: bool
     core = model.module if isinstance(model, GradAllReduce) else model
     skip = core.no_weight_decay() if hasattr(core, "no_weight_decay") else {}
     decay, no_decay = [], []
+    # Group membership AND order follow the reference exactly (optimizer.py:40-52), quirk included: it tests the MODULE
+    # name -- `name in skip`, `name.endswith(".bias")` -- so the root-level pos_embed_* parameters (module name "") are never
+    # in `skip` and keep their weight decay even with MVIT.ZERO_DECAY_POS_CLS, and only the 1-D test ever fires for biases.
+    # The "optimizer_state" indices of a reference checkpoint are positions in these lists (checkpoint.py:131).
     for name, m in core.named_modules():
-        for pn, p in m.named_parameters(recurse=False):
+        for p in m.parameters(recurse=False):
             if not p.requires_grad:
                 continue
-            full = f"{name}.{pn}" if name else pn
-            if full in skip or (cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or full.endswith(".bias"))):
+            if name in skip or (cfg.SOLVER.ZERO_WD_1D_PARAM and (p.dim() == 1 or name.endswith(".bias"))):
                 no_decay.append(p)
             else:
                 decay.append(p)
@@ -178,6 +181,36 @@ def synthetic_batch(B: int, num_frames: int, crop: int, seed: int, device, pipel
     return {"video": video, "audio": audio, "labels_hm": hm, "labels": labels}
 
 
+class _TrainStateSnapshot:
+    """Parameters, optimizer moments / step count and the device RNG state, taken before the warm-up iterations of a graph
+    capture and put back after it: warm-up runs REAL optimizer steps (lazy tables, autotuned plans and the allocator have to
+    see the real thing), and a fresh or resumed run must not start two AdamW steps down the road with the schedule's
+    learning rate ignored (the capture itself executes nothing)."""
+
+    def __init__(self, model, optimizer):
+        self.params = [p for p in model.parameters()]
+        self.values = [p.detach().clone() for p in self.params]
+        self.opt = optimizer
+        if hasattr(optimizer, "exp_avg"):                       # csts_amd.optim.FusedAdamW
+            self.opt_state = (optimizer.exp_avg.clone(), optimizer.exp_avg_sq.clone(), optimizer.state_t.clone(), optimizer._lr.clone())
+        else:
+            import copy
+            self.opt_state = copy.deepcopy(optimizer.state_dict())
+        self.rng = torch.cuda.get_rng_state() if torch.cuda.is_available() else None
+
+    def restore(self):
+        with torch.no_grad():
+            torch._foreach_copy_(self.params, self.values)      # bumps the version counters: bf16 shadows refresh on the next run
+        if hasattr(self.opt, "exp_avg"):
+            a, b, c, d = self.opt_state
+            self.opt.exp_avg.copy_(a); self.opt.exp_avg_sq.copy_(b); self.opt.state_t.copy_(c); self.opt._lr.copy_(d)
+        else:
+            self.opt.load_state_dict(self.opt_state)
+        if self.rng is not None:
+            torch.cuda.set_rng_state(self.rng)
+        self.values = self.opt_state = None
+
+
 class GraphedTrainStep:
     """The whole training iteration (forward + loss + backward + clip + AdamW) captured ONCE into a HIP graph and
     replayed: ~2000 kernel launches per step become one graph launch, so the step is bounded by the kernels, not by
@@ -199,6 +232,7 @@ class GraphedTrainStep:
             # the warm-up steps must take the same (grouped) path as the capture: its lazily built host tables and
             # pinned buffers may not be allocated while a capture is open
             ops.GROUP_WGRADS = "always"
+        snap = _TrainStateSnapshot(model, optimizer)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -213,6 +247,7 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
         finally:
             ops.GROUP_WGRADS = mode
+            snap.restore()
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
@@ -253,23 +288,21 @@ class SegmentedTrainStep:
     reads them through p.grad views.  With one process it degenerates to the same chain without collectives (used by
     bench.py to time forward / backward / optimizer separately)."""
 
-    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2):
+    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2, use_graphs: bool = True, loss_fn=None):
+        """use_graphs=False runs the same chain eagerly (any device: the bucket / collective logic is then testable with
+        gloo on the CPU); loss_fn(outs, static) -> (loss, kld, nce) replaces the built-in HIP losses (tests)."""
         from . import ops
         self.cfg, self.model, self.opt = cfg, model, optimizer
         self.core = model.module if isinstance(model, GradAllReduce) else model
         self.dist = du.is_dist()
+        self.use_graphs, self.loss_fn = use_graphs, loss_fn
         if isinstance(model, GradAllReduce):
             model.hooks_enabled = False               # buckets are driven from here, not from autograd hooks ...
             if ops.GROUP_WGRADS == "never":           # ... so nothing reads a gradient in the middle of backward any more:
                 ops.GROUP_WGRADS = "capture"          # the grouped end-of-backward weight gradients are back
         self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
         core = self.core
-        head_mods = [core.vision_pool, core.audio_pool, core.audio_pool2, core.temporal_fusion, core.spatial_fusion,
-                     core.decode_block1, core.decode_block2, core.decode_block3, core.decode_block4, core.classifier]
-        for nm in ("vision_proj", "audio_proj"):
-            if hasattr(core, nm):
-                head_mods.append(getattr(core, nm))
-        self.head_params = [p for m_ in head_mods for p in m_.parameters() if p.requires_grad]
+        self.head_params = [p for p in core.head_parameters() if p.requires_grad]
         hid = {id(p) for p in self.head_params}
         self.trunk_params = [p for p in core.parameters() if p.requires_grad and id(p) not in hid]
         self._avg = None
@@ -278,8 +311,12 @@ class SegmentedTrainStep:
             self._avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None
             self.flat = [self._flat_for(self.head_params), self._flat_for(self.trunk_params)]
         self.events = None
+        self.graphs = {}
+        if not use_graphs:
+            return
         mode = ops.GROUP_WGRADS
         ops.GROUP_WGRADS = "always" if mode != "never" else mode     # warm-up takes the same (grouped) path as the capture
+        snap = _TrainStateSnapshot(model, optimizer)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -288,11 +325,11 @@ class SegmentedTrainStep:
                     self._chain(capture=False)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self.graphs = {}
             self._chain(capture=True)
             torch.cuda.synchronize()
         finally:
             ops.GROUP_WGRADS = mode
+            snap.restore()
 
     # ------------------------------------------------------------------ pieces
     def _flat_for(self, params):
@@ -328,7 +365,9 @@ class SegmentedTrainStep:
         backward of just that part into the static gradient buffers the head graph starts from."""
         cfg = self.cfg
         leaves = [t.detach().requires_grad_(True) for t in self.outs]
-        if cfg.MODEL.LOSS_FUNC == "kldiv+egonce":
+        if self.loss_fn is not None:
+            loss, kld, nce = self.loss_fn(leaves, self.static)
+        elif cfg.MODEL.LOSS_FUNC == "kldiv+egonce":
             logits, v_emb, a_emb = leaves
             if du.is_dist():
                 v_emb, a_emb = du.all_gather_with_grad([v_emb, a_emb])
@@ -345,10 +384,23 @@ class SegmentedTrainStep:
             buf.copy_(leaf.grad)
         return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
 
+    def step_eager(self, batch=None, lr: Optional[float] = None):
+        """One iteration of the chain without graphs (use_graphs=False)."""
+        if batch is not None:
+            for k in self.static:
+                self.static[k].copy_(batch[k])
+        if lr is not None:
+            set_lr(self.opt, lr)
+        return self._chain(capture=False)
+
     def _chain(self, capture):
         core, cfg = self.core, self.cfg
         with_embed = cfg.MODEL.LOSS_FUNC == "kldiv+egonce"
-        self.opt.zero_grad(set_to_none=True)
+        if hasattr(self.opt, "params"):
+            self.opt.zero_grad(set_to_none=True)
+        else:
+            for p in self.head_params + self.trunk_params:
+                p.grad = None
         cut = {}
 
         def boundary(feats):

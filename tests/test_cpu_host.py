@@ -300,6 +300,113 @@ def test_two_rank_gloo_whole_grad_allreduce_on_csts_shaped_module():
         assert r[5], "GradAllReduce must switch the grouped weight-gradient tail off"
 
 
+class _ToySegModel(torch.nn.Module):
+    """A two-part model with the CSTS segment interface (forward(x, y, return_embed, boundary) / head_parameters) over
+    plain torch CPU ops: trunk = two encoders, head = fusion + 'decoder' + embedding projections."""
+
+    def __init__(self):
+        super().__init__()
+        self.enc_v = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 16))
+        self.enc_a = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 16))
+        self.fuse = torch.nn.Linear(32, 16)
+        self.dec = torch.nn.Linear(16, 5)
+        self.vision_proj = torch.nn.Linear(16, 4)
+        self.audio_proj = torch.nn.Linear(16, 4)
+
+    def head_parameters(self):
+        return [p for m in (self.fuse, self.dec, self.vision_proj, self.audio_proj) for p in m.parameters()]
+
+    def forward(self, x, y, return_embed=False, boundary=None):
+        feats = [self.enc_v(x[0]), self.enc_a(y)]
+        if boundary is not None:
+            feats = boundary(feats)
+        v, a = feats
+        logits = self.dec(torch.tanh(self.fuse(torch.cat([v, a], dim=-1))))
+        return [logits, self.vision_proj(v.mean(dim=1)), self.audio_proj(a.mean(dim=1))]
+
+
+def _toy_loss(gathered_fn):
+    def loss_fn(leaves, static):
+        logits, v, a = leaves
+        v, a = gathered_fn([v, a])
+        kld = (logits - static["labels_hm"]).pow(2).mean()
+        sim = torch.nn.functional.normalize(v, dim=1) @ torch.nn.functional.normalize(a, dim=1).t()
+        nce = -(torch.log_softmax(sim / 0.05, dim=1).diag().mean() + torch.log_softmax(sim / 0.05, dim=0).diag().mean())
+        return kld + 0.05 * nce, kld, nce
+    return loss_fn
+
+
+def _dist_worker_segmented(rank, world, port, q):
+    """csts_amd.train.SegmentedTrainStep (the data-parallel step: forward | eager losses + embedding all-gather | backward
+    head | all-reduce(head bucket) | backward trunk | all-reduce(trunk bucket) | optimizer) run WITHOUT graphs on 2 gloo
+    ranks: the gradients the optimizer sees must equal those of ONE process on the concatenated batch, p.grad must be
+    views of the two flat buckets, and the replicas must stay identical after the step."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from csts_amd import distributed as du
+        from csts_amd import train as T
+        from csts_amd.config import load_yaml
+        cfg = load_yaml(YAML, ["NUM_GPUS", 0, "MODEL.LOSS_FUNC", "kldiv+egonce", "SOLVER.CLIP_GRAD_L2NORM", None])
+        torch.manual_seed(7)
+        net = _ToySegModel()
+        g = torch.Generator().manual_seed(123)
+        full = {"video": torch.randn(4, 3, 6, generator=g), "audio": torch.randn(4, 3, 6, generator=g),
+                "labels_hm": torch.randn(4, 3, 5, generator=g)}
+        mine = {k: v[2 * rank:2 * rank + 2] for k, v in full.items()}
+        # single-process reference on the concatenated batch (mean over the global batch = mean of the per-rank means)
+        import copy
+        ref = copy.deepcopy(net)
+        out = ref([full["video"]], full["audio"], return_embed=True)
+        l0 = (out[0][:2] - full["labels_hm"][:2]).pow(2).mean()
+        l1 = (out[0][2:] - full["labels_hm"][2:]).pow(2).mean()
+        loss_ref, _, nce_ref = _toy_loss(lambda ts: ts)([out[0], out[1], out[2]], {"labels_hm": full["labels_hm"]})
+        ((l0 + l1) / 2 + 0.05 * nce_ref).backward()
+        wrapped = du.GradAllReduce(net, bucket_mb=1)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        seg = T.SegmentedTrainStep(cfg, wrapped, opt, mine, use_graphs=False, loss_fn=_toy_loss(du.all_gather_with_grad))
+        before = [p.detach().clone() for p in net.parameters()]
+        loss, kld, nce = seg.step_eager(mine, lr=0.1)
+        ok_hooks = not wrapped.hooks_enabled
+        flat_rng = [(f.data_ptr(), f.data_ptr() + 4 * f.numel()) for f, _ in seg.flat]
+        ok_view = all(any(lo <= p.grad.data_ptr() < hi for lo, hi in flat_rng) for p in net.parameters())
+        ok_grad = all(torch.allclose(p.grad, r.grad, atol=1e-6) for p, r in zip(net.parameters(), ref.parameters()))
+        ok_nce = abs(float(nce) - float(nce_ref)) < 1e-5          # every rank sees the global similarity matrix
+        ok_step = all(torch.allclose(p, b - 0.1 * r.grad, atol=1e-6) for p, b, r in zip(net.parameters(), before, ref.parameters()))
+        flatw = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.empty_like(flatw) for _ in range(world)]
+        dist.all_gather(both, flatw)
+        ok_same = torch.equal(both[0], both[1])
+        q.put((rank, ok_hooks, ok_view, ok_grad, ok_nce, ok_step, ok_same))
+    except Exception as e:
+        import traceback
+        q.put((rank, False, False, False, False, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_segmented_data_parallel_step():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dist_worker_segmented, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert r[1], ("hook-driven buckets must be off", r)
+        assert r[2], "p.grad must be views of the flat buckets"
+        assert r[3], ("averaged gradients != single-process gradients on the concatenated batch", r[6])
+        assert r[4], "EgoNCE over the gathered embeddings"
+        assert r[5] and r[6] is True, ("optimizer step / replicas diverged", r)
+
+
 def test_two_rank_gloo_data_parallel_logic():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -338,7 +445,8 @@ def test_checkpoint_wire_format_reads_reference_written_pyth(tmp_path):
     g = np.load(os.path.join(GOLDEN, "ref_checkpoint_loaded.npz"))
     dst = Tiny(8, 5)
     dst.load_state_dict({k: torch.from_numpy(g["before__" + k.replace(".", "__")]) for k in dst.state_dict()})
-    epoch, not_loaded = ck.load_checkpoint(ref_file, dst, epoch_reset=True)
+    not_loaded = []
+    epoch = ck.load_checkpoint(ref_file, dst, epoch_reset=True, report=not_loaded)
     assert epoch == int(g["epoch"]) == -1
     assert sorted(not_loaded) == ["head.bias", "head.weight"]          # shape mismatch: left untouched, like the reference
     for k, v in dst.state_dict().items():
@@ -346,7 +454,8 @@ def test_checkpoint_wire_format_reads_reference_written_pyth(tmp_path):
     # resume semantics: epoch and the torch AdamW state come back
     src = Tiny(4, 3)
     opt = torch.optim.AdamW(src.parameters(), lr=5e-4, eps=1e-8, weight_decay=0.05)
-    epoch, not_loaded = ck.load_checkpoint(ref_file, src, optimizer=opt)
+    not_loaded = []
+    epoch = ck.load_checkpoint(ref_file, src, optimizer=opt, report=not_loaded)
     assert epoch == 6 and not not_loaded
     assert len(opt.state_dict()["state"]) == 8 and abs(opt.param_groups[0]["lr"] - 1e-3) < 1e-12
     # our writer -> same layout (keys, file name), readable by our reader
@@ -357,7 +466,7 @@ def test_checkpoint_wire_format_reads_reference_written_pyth(tmp_path):
     blob = torch.load(path, map_location="cpu", weights_only=False)
     assert sorted(blob) == ["cfg", "epoch", "model_state", "optimizer_state"] and isinstance(blob["cfg"], str)
     again = Tiny(4, 3)
-    assert ck.load_checkpoint(path, again)[0] == 2
+    assert ck.load_checkpoint(path, again) == 2
     assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), src.state_dict().values()))
 
 
