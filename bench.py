@@ -401,7 +401,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             fgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fgraph):
+            with torch.cuda.graph(fgraph, capture_error_mode="thread_local"):
                 fout = eager_step()
             step_kind = "hip_graph"
 

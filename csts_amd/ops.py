@@ -7,6 +7,7 @@ Each Function cites the reference op it replaces (paths under the reference repo
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 import os
@@ -128,9 +129,16 @@ DEFER_REDUCTIONS = os.environ.get("CSTS_DEFER_REDUCE", "1") != "0"
 
 def reset_deferred():
     """Drop everything queued for an end-of-backward flush (used when a backward pass died before its final callback)."""
+    if _wg_side_used[0]:                # a dead pass may have launches in flight that read / write what is dropped below
+        for st in _wg_side.values():
+            st.synchronize()
+        _wg_side_used[0] = False
     _deferred.clear()
     _assign.clear()
     _wgq.clear()
+    _wg_pending.clear()
+    _wg_prod.clear()
+    _wg_work[0] = 0.0
     _deferred_task[0] = -1
 
 
@@ -176,6 +184,7 @@ def flush_deferred():
     their parameters (idempotent)."""
     _deferred_task[0] = -1
     flush_wgrads()
+    _join_wgrad_side()
     if not _deferred:
         _hand_over()
         return
@@ -230,6 +239,18 @@ WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "4096"))   # tokens per 1
 WGRAD_CHUNK = int(os.environ.get("CSTS_WGRAD_CHUNK", "8192"))   # tokens per work item (measured per step: 4096 -> 24.93 ms, 8192 -> 24.95, 16384 -> 25.47)
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 _wg_tables = {}
+# Optional: every WG_FLUSH_GFLOP of queued work goes out as its own grouped launch on a SIDE stream, beside the rest of
+# backward (the idea: backward's kernels are small, and the audio trunk on its own stream was worth 8 ms of a 41 ms step).
+# Operands, slabs and results stay referenced until the final callback has joined the side stream.
+# MEASURED SLOWER on MI355X (bench.py, same box, ms per step): one launch at the end 25.19-25.28, flushes of 600 / 350 / 200
+# GFLOP on the side stream 25.62 / 25.46-25.51 / 26.74 -- backward does not leave the matrix pipes idle enough for a second
+# MFMA-heavy kernel beside it.  Default 0 (off); the switch stays for re-measuring on other workloads.
+WG_FLUSH_FLOP = float(os.environ.get("CSTS_WGRAD_FLUSH_GFLOP", "0")) * 1e9
+_wg_work = [0.0]
+_wg_prod = {}           # raw stream id -> torch stream that produced operands queued since the last flush
+_wg_side = {}           # device index -> side stream
+_wg_pending = []        # strong references of side-stream flushes in flight
+_wg_side_used = [False]
 
 
 def queue_wgrad(dY, X, tokens, N, K, Wp, bp):
@@ -248,6 +269,11 @@ def queue_wgrad(dY, X, tokens, N, K, Wp, bp):
     _wgq.append((dY, X, dW, db, tokens, N, K))
     _assign_later(Wp, dW)
     _assign_later(bp, db)
+    cur = torch.cuda.current_stream()
+    _wg_prod[cur.cuda_stream] = cur
+    _wg_work[0] += 2.0 * tokens * N * K
+    if WG_FLUSH_FLOP > 0 and _wg_work[0] >= WG_FLUSH_FLOP:
+        flush_wgrads(side=True)
     return True
 
 
@@ -311,17 +337,32 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
     return plan
 
 
-def flush_wgrads():
+def flush_wgrads(side: bool = False):
+    """Launch the queued weight gradients: on the current stream (end of backward), or -- side=True, from queue_wgrad in
+    the middle of backward -- on the side stream, after everything the producing streams have enqueued so far."""
     if not _wgq:
         return
     import numpy as np
     q = list(_wgq)
     _wgq.clear()
+    _wg_work[0] = 0.0
     dev = q[0][0].device
-    tab = _wg_tables.get(dev.index)
+    key = (dev.index, side)
+    tab = _wg_tables.get(key)
     if tab is None:
-        tab = _wg_tables[dev.index] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=6, captures=16)
+        tab = _wg_tables[key] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=8, captures=40 if side else 16)
     keep = []
+    launch_stream = None
+    if side:
+        launch_stream = _wg_side.get(dev.index)
+        if launch_stream is None:
+            launch_stream = _wg_side[dev.index] = torch.cuda.Stream(device=dev)
+        for st in _wg_prod.values():          # autograd runs every node of this device on ONE thread: whatever produced the
+            ev = torch.cuda.Event()           # queued operands is already enqueued on these streams
+            ev.record(st)
+            launch_stream.wait_event(ev)
+        _wg_side_used[0] = True
+    _wg_prod.clear()
     # tile classes: 192 x 384 on 8-wave workgroups where it divides the layer (the 384- and 768-channel stages: half the
     # operand bytes per FLOP of a 128 x 128 tile); else 256 x 128 where 256 divides the output rows; else 128 x 128
     def tile_class(t):
@@ -359,12 +400,25 @@ def flush_wgrads():
         arr["B"][valid] = B[pidx]
         arr["C"][valid] = Cb[pidx] + ch * cstride[pidx]
         arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
-        ptr = tab.upload(arr.tobytes())
-        if rows == 192:
-            L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
-        else:
-            L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
+        with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
+            ptr = tab.upload(arr.tobytes())
+            if rows == 192:
+                L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
+            else:
+                L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
+    if side:
+        _wg_pending.append((q, keep))      # alive until the final callback has joined the side stream
     del q, keep
+
+
+def _join_wgrad_side():
+    """Make the current stream wait for the side-stream weight-gradient launches of this backward pass."""
+    if _wg_side_used[0]:
+        cur = torch.cuda.current_stream()
+        for st in _wg_side.values():
+            cur.wait_stream(st)
+        _wg_side_used[0] = False
+    _wg_pending.clear()
 
 
 # ----------------------------------------------------------------------------------------- raw wrappers

@@ -242,7 +242,8 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: a process group's watchdog thread may poll events while this capture is open (see SegmentedTrainStep)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.out = self._step()
             torch.cuda.synchronize()
         finally:
@@ -347,7 +348,10 @@ class SegmentedTrainStep:
             return fn()
         g = torch.cuda.CUDAGraph()
         pool = self.graphs["fwd"].pool() if "fwd" in self.graphs else None
-        with torch.cuda.graph(g, pool=pool):
+        # thread_local: RCCL's watchdog thread polls the events of the eager collectives issued between the captures
+        # (hipEventQuery); under the default "global" mode that call fails while ANY stream is capturing and takes the
+        # process down ("operation not permitted when stream is capturing")
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
             out = fn()
         self.graphs[name] = g
         return out
