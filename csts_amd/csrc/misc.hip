@@ -339,6 +339,36 @@ __global__ __launch_bounds__(256) void add2_kernel(const void* __restrict__ a, i
     }
   }
 }
+// Many bf16 matrices transposed in ONE launch (the [K][N] twins of the Linear weights' bf16 shadows, refreshed once per
+// training step): one 64 x 64 tile per workgroup, described by a device table.
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const csts_transpose_tile* __restrict__ tiles) {
+  __shared__ bf16 t[64][64 + 8];
+  const csts_transpose_tile d = tiles[blockIdx.x];
+  const bf16* __restrict__ src = reinterpret_cast<const bf16*>(d.src);
+  bf16* __restrict__ dst = reinterpret_cast<bf16*>(d.dst);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                       // 64 rows x 8 chunks of 8 elements
+    const int c = tid + 256 * i, r = c >> 3, cc = (c & 7) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+    if (d.r0 + r < d.R && d.c0 + cc < d.C) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)(d.r0 + r) * d.C + d.c0 + cc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[r][cc + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                       // output rows = source columns
+    const int c = tid + 256 * i, r = c >> 3, cc = (c & 7) * 8;
+    if (d.c0 + r < d.C && d.r0 + cc < d.R) {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = t[cc + j][r];
+      *reinterpret_cast<bf16x8*>(dst + (int64_t)(d.c0 + r) * d.R + d.r0 + cc) = v;
+    }
+  }
+}
 // out[m,n] = x[m,n] * row_scale[m / rows_per_scale]   (backward of the drop-path scaling, common.py:46-59)
 __global__ __launch_bounds__(256) void scale_rows_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ rs,
                                                          int64_t rows_per_scale, void* __restrict__ out, int o_dt,
@@ -737,6 +767,13 @@ extern "C" int csts_add2(const void* a, int a_dt, const void* b, int b_dt, float
                "operands must be 16-byte aligned");
   hipLaunchKernelGGL(add2_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, a, a_dt, b, b_dt, out,
                      reinterpret_cast<bf16*>(out_bf16), n);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int csts_transpose_multi(const csts_transpose_tile* device_tiles, int ntiles, hipStream_t stream) {
+  CSTS_REQUIRE(device_tiles != nullptr && ntiles > 0, "no tiles");
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, device_tiles);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

@@ -97,6 +97,10 @@ class OptArgs(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/csts_hip.h declares
 _I, _F = C.c_int, C.c_float
+class TransposeTile(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R", C.c_int), ("C", C.c_int), ("r0", C.c_int), ("c0", C.c_int)]
+
+
 SYMBOLS = {
     "csts_last_error": (C.c_char_p, []),
     "csts_abi_version": (_I, []),
@@ -132,6 +136,7 @@ SYMBOLS = {
     "csts_im2col": (_I, [C.POINTER(Im2colGeom), vp, _I, vp, _I, vp]),
     "csts_posembed_build": (_I, [vp, vp, vp, _I, _I, _I, vp]),
     "csts_transpose_batched": (_I, [vp, _I, vp, _I, i64, _I, _I, vp]),
+    "csts_transpose_multi": (_I, [vp, _I, vp]),
     "csts_colsum_workspace": (sz, [i64, i64, i64]),
     "csts_colsum": (_I, [vp, _I, vp, vp, i64, i64, i64, vp, sz, vp]),
     "csts_axpby": (_I, [vp, _I, vp, _I, vp, _I, i64, _F, _F, vp]),

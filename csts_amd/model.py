@@ -154,7 +154,8 @@ class Block(nn.Module):
         # x + f(LN(x)): LN returns an alias of x whose gradient (the residual branch) is folded into its backward kernel
         xn, x = ops.layer_norm(x.contiguous(), self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt, passthrough=True)
         w16 = lambda lin: getattr(lin, "_w16", None)      # bf16 shadow maintained by CSTS._refresh_w16 (bf16 mode)
-        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv))
+        w16t = lambda lin: getattr(lin, "_w16t", None)    # its [in][out] twin (training): the data gradients run as NT GEMMs
+        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv), w16t=w16t(a.qkv))
         mask_mode, mT, mHW = L.MASK_NONE, 0, 0
         if self.kind == "spatial":
             mask_mode, mT, mHW = L.MASK_SPATIAL, thw[0], thw[1] * thw[2]
@@ -183,14 +184,15 @@ class Block(nn.Module):
         Nq = o.shape[1]
         s_attn, s_mlp = self._drop_scales(B, x.device, keep_masks)
         x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x_res, row_scale=s_attn, rows_per_scale=Nq, out_dt=L.F32,
-                        compute=rt.compute, w16=w16(a.proj))
+                        compute=rt.compute, w16=w16(a.proj), w16t=w16t(a.proj))
         xn2, x1 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt, passthrough=True)
         base = x1
         if self.dim != self.dim_out:
-            base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj))
+            base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj),
+                              w16t=w16t(self.proj))
         out = ops.mlp(xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=base,
                       row_scale=s_mlp, rows_per_scale=Nq, act_dt=rt.act_dt, out_dt=L.F32, compute=rt.compute,
-                      w16_1=w16(self.mlp.fc1), w16_2=w16(self.mlp.fc2))
+                      w16_1=w16(self.mlp.fc1), w16_2=w16(self.mlp.fc2), w16t_1=w16t(self.mlp.fc1), w16t_2=w16t(self.mlp.fc2))
         extra = None
         if spatial_audio_attn:       # av_attention.py:360-370: (per-head rescaled audio->pixel map, its head mean per token)
             T, HW = thw[0], thw[1] * thw[2]
@@ -341,6 +343,15 @@ class CSTS(nn.Module):
                 torch._foreach_copy_([l._w16 for l in lins], [l.weight.detach() for l in lins])
             for l in lins:
                 l._w16_ver = l.weight._version
+        # [in][out] twins for the data-gradient GEMMs: one multi-tensor transpose per forward that records a backward graph
+        # (refreshed in the same forward whose backward reads them: never stale)
+        if torch.is_grad_enabled() and ops.USE_W16T:
+            ts = getattr(self, "_w16t_set", None)
+            if ts is None or ts.pairs[0][0].device != lins[0]._w16.device or any(l._w16 is not p_[0] for l, p_ in zip(lins, ts.pairs)):
+                for l in lins:
+                    l._w16t = torch.empty(l.weight.shape[1], l.weight.shape[0], dtype=torch.bfloat16, device=l.weight.device)
+                ts = self._w16t_set = ops._TransposeSet([(l._w16, l._w16t) for l in lins])
+            ts.refresh()
 
     def _draw_drop_paths(self, B, device):
         """All stochastic-depth scales of one forward in ONE draw (4 small kernels instead of 4 per block branch):

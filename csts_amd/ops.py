@@ -622,7 +622,7 @@ class LinearFn(Function):
     of attention.py:242,247 folded into the epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int, w16):
+    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int, w16, w16t=None):
         _need_gpu(x, W)
         x = x.contiguous()
         W = W.contiguous()
@@ -638,6 +638,7 @@ class LinearFn(Function):
         ctx.save_for_backward(x, Wop, row_scale)
         ctx.wdtype = W.dtype
         ctx.params = (W, b)
+        ctx.w16t = w16t if (w16t is not None and compute == BF16 and Wop is w16) else None
         ctx.meta = (M, N, K, rows_per_scale, compute, b is not None, residual is not None,
                     residual.dtype if residual is not None else None)
         return y
@@ -655,7 +656,7 @@ class LinearFn(Function):
         dx = dW = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, dys, 0, N, W, 0, K, dx, K, M, K, N, compute=compute)
+            _dgrad(dys, W, ctx.w16t, dx, M, N, K, compute)
         if ctx.needs_input_grad[1]:
             if has_b and ctx.needs_input_grad[2]:
                 dW, db = _wgrad(dys, x, M, N, K, compute, want_bias=True, params=ctx.params)
@@ -667,11 +668,47 @@ class LinearFn(Function):
             db = colsum(dys, 1, M, N)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == res_dtype else dy.to(res_dtype)
-        return dx, dW, db, dres, None, None, None, None, None
+        return dx, dW, db, dres, None, None, None, None, None, None
 
 
-def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32, w16=None):
-    return LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16)
+def _dgrad(dy, W, Wt, dx, M, N, K, compute, epilogue=L.EPI_NONE, aux=None):
+    """dx[M,K] = dy[M,N] W[N,K].  With the [K][N] twin of the bf16 shadow (csts_transpose_multi) and a bf16 dy this is an
+    NT GEMM -- both operands contiguous along the reduction, the forward's kernels -- else NN on W itself."""
+    if Wt is not None and dy.dtype == torch.bfloat16 and USE_W16T:
+        gemm(L.GEMM_NT, dy, 0, N, Wt, 0, N, dx, K, M, K, N, compute=compute, epilogue=epilogue, aux=aux)
+    else:
+        gemm(L.GEMM_NN, dy, 0, N, W, 0, K, dx, K, M, K, N, compute=compute, epilogue=epilogue, aux=aux)
+
+
+USE_W16T = os.environ.get("CSTS_W16T", "1") != "0"
+
+
+class _TransposeSet:
+    """The [in][out] twins of a fixed set of bf16 matrices, refreshed by ONE csts_transpose_multi launch (tile table built
+    once: the buffers never move)."""
+
+    def __init__(self, pairs):
+        self.pairs = list(pairs)                 # (src [R, C] bf16, dst [C, R] bf16)
+        tiles = []
+        for src, dst in self.pairs:
+            R, Cc = src.shape
+            assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and tuple(dst.shape) == (Cc, R)
+            assert R % 8 == 0 and Cc % 8 == 0 and src.is_contiguous() and dst.is_contiguous()
+            for r0 in range(0, R, 64):
+                for c0 in range(0, Cc, 64):
+                    tiles.append((src.data_ptr(), dst.data_ptr(), R, Cc, r0, c0))
+        arr = (L.TransposeTile * len(tiles))()
+        for i, t in enumerate(tiles):
+            arr[i].src, arr[i].dst, arr[i].R, arr[i].C, arr[i].r0, arr[i].c0 = t
+        self.n = len(tiles)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.pairs[0][0].device)
+
+    def refresh(self):
+        L.check(_lib().csts_transpose_multi(self.table.data_ptr(), self.n, _stream()), "csts_transpose_multi")
+
+
+def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32, w16=None, w16t=None):
+    return LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16, w16t)
 
 
 class MlpFn(Function):
@@ -680,11 +717,13 @@ class MlpFn(Function):
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, residual, row_scale, rows_per_scale: int, act_dt: int, out_dt: int, compute: int,
-                w16_1, w16_2):
+                w16_1, w16_2, w16t_1=None, w16t_2=None):
         _need_gpu(x, W1, W2)
         ctx.params = (W1, b1, W2, b2)
+        ctx.w16t = (None, None)
         if compute == BF16 and w16_1 is not None and w16_2 is not None:   # bf16 shadows of the fp32 master weights
             W1, W2 = w16_1, w16_2
+            ctx.w16t = (w16t_1, w16t_2)
         x = x.contiguous()
         K = x.shape[-1]
         Hd = W1.shape[0]
@@ -715,18 +754,19 @@ class MlpFn(Function):
         P1, pb1, P2, pb2 = ctx.params
         dW2, db2 = _wgrad(dys, g, M, N, Hd, compute, want_bias=True, params=(P2, pb2))
         dh = torch.empty_like(h)
-        gemm(L.GEMM_NN, dys, 0, N, W2, 0, Hd, dh, Hd, M, Hd, N, compute=compute, epilogue=L.EPI_DGELU, aux=h)
+        _dgrad(dys, W2, ctx.w16t[1], dh, M, N, Hd, compute, epilogue=L.EPI_DGELU, aux=h)
         dW1, db1 = _wgrad(dh, x, M, Hd, K, compute, want_bias=True, params=(P1, pb1))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(L.GEMM_NN, dh, 0, Hd, W1, 0, K, dx, K, M, K, Hd, compute=compute)
-        return dx, dW1, db1, dW2, db2, (dy if has_res else None), None, None, None, None, None, None, None
+            _dgrad(dh, W1, ctx.w16t[0], dx, M, Hd, K, compute)
+        return dx, dW1, db1, dW2, db2, (dy if has_res else None), None, None, None, None, None, None, None, None, None
 
 
 def mlp(x, W1, b1, W2, b2, *, residual=None, row_scale=None, rows_per_scale=1, act_dt=F32, out_dt=F32, compute=F32,
-        w16_1=None, w16_2=None):
-    return MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute, w16_1, w16_2)
+        w16_1=None, w16_2=None, w16t_1=None, w16t_2=None):
+    return MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute, w16_1, w16_2,
+                       w16t_1, w16t_2)
 
 
 # ----------------------------------------------------------------------------------------- attention inner

@@ -192,6 +192,11 @@ int csts_posembed_build(const float* spatial, const float* temporal, float* pos,
 /* ---- layout / reductions */
 int csts_transpose_batched(const void* in, int in_dt, void* out, int out_dt, int64_t batch, int R, int Cc,
                            hipStream_t stream);   /* token fold for the (1,8,8) fusion convs */
+/* Many bf16 matrices (R x C, both % 8 == 0, 16-byte aligned) transposed in one launch: one 64 x 64 tile per entry of a DEVICE
+ * table.  Keeps the [in][out] twins of the Linear weights' bf16 shadows, so that the data gradient dX = dY W runs as an
+ * NT GEMM (k-contiguous operands) like the forward (nn.Linear backward: attention.py:130,159; common.py:27-33). */
+typedef struct { const void* src; void* dst; int R, C, r0, c0; } csts_transpose_tile;
+int csts_transpose_multi(const csts_transpose_tile* device_tiles, int ntiles, hipStream_t stream);
 size_t csts_colsum_workspace(int64_t batch, int64_t M, int64_t N);
 int csts_colsum(const void* X, int dt, const float* row_weight, float* out, int64_t batch, int64_t M, int64_t N,
                 void* workspace, size_t ws_bytes, hipStream_t stream);   /* bias / pos-embed / classifier grads */
