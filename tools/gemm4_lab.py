@@ -15,7 +15,7 @@ SHAPES = [(8192, 1536, 384), (8192, 384, 1536), (8192, 1152, 384), (8192, 384, 3
           (131072, 384, 384), (131072, 192, 768), (32768, 768, 768), (8192, 768, 1536), (8192, 3072, 768), (8192, 768, 3072)]
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default=None)
-ap.add_argument("--algos", default="0,402,403,412,422,432,433,434,462,463,442,443,452,453")
+ap.add_argument("--algos", default="0,402,403,412,422,432,433,434,462,463,442,452")
 ap.add_argument("--epi", default="none", choices=["none", "gelu", "res"])
 ap.add_argument("--rounds", type=int, default=3)
 a = ap.parse_args()
