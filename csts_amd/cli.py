@@ -84,15 +84,17 @@ def train(cfg):
     from . import checkpoint as ck
     start_epoch = ck.load_train_checkpoint(cfg, model, optimizer)          # train_avgaze_net.py:280
     model.train()
-    graphed = None        # single GPU: the iteration is captured into a HIP graph (the step is launch-bound from Python)
+    # the iteration runs from HIP graphs (the step is launch-bound from Python): one graph on a single GPU, a chain of graphs
+    # with the RCCL collectives issued eagerly between them when data-parallel (train.SegmentedTrainStep)
+    graphed = None
     for epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCH):
         t0 = time.time()
         for it in range(steps):
             batch = T.synthetic_batch(b, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, 1000 + rank + 7919 * (epoch * steps + it), dev)
             lr = T.get_lr_at_epoch(cfg, epoch + float(it) / steps)
-            if world == 1 and getattr(cfg.CSTS_AMD, "HIP_GRAPH", True):
+            if getattr(cfg.CSTS_AMD, "HIP_GRAPH", True):
                 if graphed is None:
-                    graphed = T.GraphedTrainStep(cfg, model, optimizer, batch)
+                    graphed = (T.GraphedTrainStep if world == 1 else T.SegmentedTrainStep)(cfg, model, optimizer, batch)
                 loss, kld, nce = graphed.run(batch, lr)
             else:
                 loss, kld, nce = T.train_step(cfg, model, batch, optimizer, lr)
