@@ -66,6 +66,8 @@ def parse():
     p.add_argument("--eager-dist", action="store_true",
                    help="N>1: the eager step with hook-driven gradient buckets (GradAllReduce) instead of the graph chain")
     p.add_argument("--no-graph", action="store_true", help="do not capture anything into HIP graphs")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo: control-flow rehearsal of the N>1 path with several ranks on ONE GPU (RCCL refuses two ranks per device)")
     p.add_argument("--op-breakdown", default=None, help="write per-C-ABI-entry device time of one eager step to this file")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
     return p.parse_args()
@@ -298,7 +300,8 @@ def loss_check(cfg, model, frames, b, crop, dev, T):
     same = all(abs(fp[n] - v) <= 1e-5 * max(abs(v), 1e-12) for n, v in exp["fingerprint"].items())
     was_training = model.training
     model.eval()
-    with torch.no_grad():
+    from csts_amd import distributed as du
+    with torch.no_grad(), du.local_only():      # only rank 0 comes here: no embedding all-gather
         bd = {k: v.to(dev) for k, v in batch.items()}
         loss, kld, nce, _ = T.compute_loss(cfg, model, bd["video"], bd["audio"], bd["labels_hm"])
         loss, kld, nce = float(loss), float(kld), float(nce)
@@ -328,6 +331,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)          # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     train = args.mode == "train"
@@ -339,6 +344,8 @@ def main():
             torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
             from csts_amd import distributed as _du
             _du._FORCE = True        # 1-rank rehearsal: take the collective code paths anyway
+        elif args.dist_backend == "gloo":
+            torch.distributed.init_process_group(backend="gloo")
         else:
             torch.distributed.init_process_group(backend="nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
@@ -351,7 +358,7 @@ def main():
     from csts_amd.distributed import GradAllReduce
 
     b, S = args.batch_per_gpu, args.crop
-    opts = ["NUM_GPUS", world, "TRAIN.BATCH_SIZE", b * world, "MODEL.LOSS_FUNC", "kldiv+egonce", "MODEL.LOSS_ALPHA", 0.05,
+    opts = ["NUM_GPUS", min(world, ndev), "TRAIN.BATCH_SIZE", b * world, "MODEL.LOSS_FUNC", "kldiv+egonce", "MODEL.LOSS_ALPHA", 0.05,
             "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute]
     if S != 256:
         opts += ["DATA.TRAIN_CROP_SIZE", S, "DATA.TEST_CROP_SIZE", S, "CSTS_AMD.FUSION_KERNEL_FROM_GRID", True]
@@ -565,6 +572,7 @@ def main():
             "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml {what}, {args.frames}x{S}^2 video + 24 kHz STFT audio, b={b}/GPU",
                        "mode": args.mode, "global_batch": b * world, "frames": args.frames, "crop": S, "parallelism": f"dp{world}",
                        "step": step_kind, "hip_graph": step_kind != "eager", "rccl_ranks": rccl_ranks,
+                       "dist_backend": (torch.distributed.get_backend() if dist_path else None),
                        "note": ("256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)" if S == 256 else
                                 "EXTENSION, parity unpinned: 224^2 with (1,7,7) fusion kernels (CSTS_AMD.FUSION_KERNEL_FROM_GRID); "
                                 "the reference cannot run this grid, FLOP/byte figures scaled by (224/256)^2")},

@@ -17,10 +17,22 @@ from . import ops as _ops
 
 
 _FORCE = False    # tests: exercise the collective code paths on a 1-rank process group
+_LOCAL = [0]      # > 0: inside local_only()
 
 
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+    return _LOCAL[0] == 0 and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
+class local_only:
+    """Context manager: the code inside runs on THIS rank alone (a check that only rank 0 performs, an eval pass): the
+    collective wrappers of this module behave as in a single process instead of waiting for ranks that never come."""
+
+    def __enter__(self):
+        _LOCAL[0] += 1
+
+    def __exit__(self, *a):
+        _LOCAL[0] -= 1
 
 
 class _AllGatherWithGrad(torch.autograd.Function):
