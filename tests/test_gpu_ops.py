@@ -680,3 +680,48 @@ def test_tap_sums_both_gradients_and_bf16_copy_is_version_guarded():
     assert d16 is not None and torch.equal(d16, (ga + gb).to(torch.bfloat16))
     g.add_(1.0)                                          # in-place change -> the copy is stale
     assert ops._grad16(g, L.BF16) is None
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,hd", [(1, 2, 4096, 2048, 96), (2, 1, 8192, 512, 96), (1, 4, 1000, 2048, 96), (1, 2, 2048, 1024, 192),
+                                           (1, 1, 16384, 4096, 96)])
+def test_attention_bf16_backward_many_key_tiles(B, H, Nq, Nk, hd):
+    """csts_attn_fwd / csts_attn_bwd in bf16 at the key counts of the benchmarked grids (N_k = 512 ... 2048 at 16x256^2, 4096 at
+    32x256^2): keys span many LDS tiles (online softmax over them), queries are split over workgroups, dK / dV partials go
+    through attn_dkv_reduce -- against fp32 torch autograd of softmax(q k^T / sqrt(hd)) v on the same bf16-rounded inputs.
+    q is read in place inside a qkv buffer (token stride 3C), dq written in place into its slot."""
+    import ctypes as C
+    Cc = H * hd
+    qkv = rnd(B, Nq, 3 * Cc, seed=1).to(torch.bfloat16)
+    k, v = rnd(B, Nk, Cc, seed=2).to(torch.bfloat16), rnd(B, Nk, Cc, seed=3).to(torch.bfloat16)
+    do = rnd(B, Nq, Cc, seed=4).to(torch.bfloat16)
+    o = torch.empty(B, Nq, Cc, device=DEV, dtype=torch.bfloat16)
+    lse, delta = torch.empty(B, H, Nq, device=DEV), torch.empty(B, H, Nq, device=DEV)
+    dqkv = torch.full((B, Nq + 1, 3 * Cc), 7.0, device=DEV, dtype=torch.bfloat16)
+    dk, dv = torch.empty_like(k), torch.empty_like(v)
+    a = L.AttnArgs()
+    a.Q, a.K, a.V, a.O, a.LSE = qkv.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    a.dO, a.delta, a.dQ, a.dK, a.dV = do.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.dtype, a.B, a.H, a.Nq, a.Nk, a.head_dim = L.BF16, B, H, Nq, Nk, hd
+    a.q_strides = (C.c_int64 * 3)(Nq * 3 * Cc, 3 * Cc, hd)
+    a.dq_strides = (C.c_int64 * 3)((Nq + 1) * 3 * Cc, 3 * Cc, hd)
+    so, sk = (C.c_int64 * 3)(Nq * Cc, Cc, hd), (C.c_int64 * 3)(Nk * Cc, Cc, hd)
+    a.o_strides = so; a.do_strides = so
+    a.k_strides = sk; a.v_strides = sk; a.dk_strides = sk; a.dv_strides = sk
+    a.scale = hd ** -0.5
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.csts_attn_fwd(C.byref(a), st), "fwd")
+    ws = torch.empty(max(16, lib.csts_attn_bwd_workspace(C.byref(a))), dtype=torch.uint8, device=DEV)
+    L.check(lib.csts_attn_bwd(C.byref(a), ws.data_ptr(), ws.numel(), st), "bwd")
+    torch.cuda.synchronize()
+    qf = qkv[:, :, :Cc].float().reshape(B, Nq, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    kf = k.float().reshape(B, Nk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    vf = v.float().reshape(B, Nk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    of = torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf
+    of.backward(do.float().reshape(B, Nq, H, hd).transpose(1, 2))
+    back = lambda t, n: t.transpose(1, 2).reshape(B, n, Cc)
+    assert rel_l2(o.float(), back(of, Nq)) < 1e-2, "o"
+    assert rel_l2(dqkv[:, :Nq, :Cc].float(), back(qf.grad, Nq)) < 2e-2, "dq"
+    assert rel_l2(dk.float(), back(kf.grad, Nk)) < 2e-2, "dk"
+    assert rel_l2(dv.float(), back(vf.grad, Nk)) < 2e-2, "dv"
+    assert (dqkv[:, Nq] == 7).all() and (dqkv[:, :Nq, Cc:] == 7).all()
