@@ -1245,10 +1245,10 @@ class PatchEmbedFn(Function):
         M = B * N
         dWp = _wgrad(dy, col, M, Cout, Kpad, compute)
         dW = dWp[:, :K].reshape(wshape)
-        db = colsum(dy, 1, M, Cout)
-        dpos = colsum(dy, 1, B, N * Cout)                       # sum over batch -> (N*Cout)
+        dpos = colsum(dy, 1, B, N * Cout)                       # sum over batch -> (N*Cout): the only pass over dy itself
         dps = colsum(dpos, 1, T, HW * Cout).view(1, HW, Cout)   # sum over t
         dpt = colsum(dpos, T, HW, Cout).view(1, T, Cout)        # sum over hw, per t
+        db = colsum(dpt, 1, T, Cout)                            # bias gradient = sum over every token: from the T partial rows
         return None, dW, db, dps, dpt, None, None, None, None, None
 
 
