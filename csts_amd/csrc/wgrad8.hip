@@ -1,35 +1,46 @@
 // Grouped weight gradients on 8-wave workgroups: dW[M,N] tiles of 192 x 384 (M = the Linear's output features, N = its
 // input features), one (tile, token-chunk) work item per workgroup, same item table as wgrad_grouped_kernel (gemm.hip).
 //
-// Why: the 128 x 128 items of wgrad_grouped_kernel run at ~750 TF/s with 35 % of their L2 requests hitting
-// (rocprofv3 TCC_HIT / TCC_MISS, profiles/r2_wgrad_pmc.txt): the tiles that share a dY / X column slice drift apart over
-// their 128-step token loops and miss each other in the 4 MiB L2, so every tile streams its own 2 x 256-byte row segments
-// from the Infinity Cache -- 64 FLOP per byte through the L2 -> CU path, which tops out at ~12 TB/s on this chip.  A
-// 192 x 384 tile gets 128 FLOP per staged byte (half the bytes through that path) and needs no luck in L2: the reuse is
-// inside the workgroup.  All Linear layers of the 384- and 768-channel stages have output features % 192 == 0 and input
-// features % 384 == 0 (1152 / 384 / 1536 x 384, 384 x 1536, 2304 / 768 / 3072 x 768, 768 x 3072).
+// Why this shape and this structure (profiles/r2_wgrad8_ab.txt, r2_wgrad_ladder.txt): the 128 x 128 items of
+// wgrad_grouped_kernel run at ~750 TF/s with 35-50 % of their L2 requests hitting, i.e. ~6.3 TB/s of L2-miss traffic -- they
+// sit on the fabric / HBM bandwidth at 64 FLOP per staged byte.  A 192 x 384 tile has 128 FLOP per staged byte and needs no
+// luck in L2: the reuse is inside the workgroup.  A first version of this kernel staged the k-tile through registers
+// (global_load -> ds_write_b128 between two barriers) and was exactly as fast as the kernel it replaced; the TN k-loop
+// calibrated in isolation runs at 1010 TF/s from L2 when the k-tile comes in by LDS-DMA instead.  So: LDS-DMA
+// (global_load_lds_dwordx4) into a 2-stage ring, one raw barrier per 64-token k-tile, no ds_write at all.
 //
-// TN form, bf16 x bf16: both operands are token-major, so a 64-token k-tile is staged [token][feature] (straight 16-byte
-// copies through registers, the next k-tile's global loads in flight under the MFMAs) and fed to v_mfma_f32_32x32x16_bf16
-// through ds_read_b64_tr_b16.  Wave grid 2 x 4, wave tile 96 x 96 (9 accumulators).  The fp32 tile goes straight from the
-// accumulators to memory: lane = column, so every store instruction writes two full 128-byte lines.
+// TN form, bf16 x bf16: both operands are token-major, a k-tile is kept [token][feature], UNPADDED (the DMA image is
+// lane-linear), and fed to v_mfma_f32_32x32x16_bf16 through ds_read_b64_tr_b16.  Bank conflicts of the transposing reads are
+// removed by rotating the 16-byte chunks of a token row -- by 4 chunks x ((row >> 1) & 1) in the 192-wide image (row stride
+// 384 B), by 4 x (row & 3) in the 384-wide one (768 B) -- applied to the per-lane SOURCE address of the DMA and, identically,
+// to the fragment read (checked exhaustively: every 32-lane read group touches 64 distinct banks).
+// Wave grid 2 x 4, wave tile 96 x 96 (9 accumulators).  The fp32 tile goes straight from the accumulators to memory: lane =
+// column, so every store instruction writes two full 128-byte lines.  All Linear layers of the 384- and 768-channel stages
+// have output features % 192 == 0 and input features % 384 == 0; token chunks must be multiples of 64 (host-checked).
 #include "common.h"
 
 namespace {
 
 constexpr int W8_TM = 192, W8_TN = 384, W8_BK = 64, W8_THR = 512;
-constexpr int W8_LDA = W8_TM + 32, W8_LDB = W8_TN + 32;      // row strides 448 B / 832 B: conflict-free transposing reads
-constexpr int W8_A_CH = W8_TM / 8, W8_B_CH = W8_TN / 8;      // 16-byte chunks per token row
-constexpr int W8_NA = W8_BK * W8_A_CH / W8_THR, W8_NB = W8_BK * W8_B_CH / W8_THR;   // chunks per thread: 3, 6
+constexpr int W8_AROW = W8_TM * 2, W8_BROW = W8_TN * 2;                  // bytes per token row: 384, 768
+constexpr int W8_A_BYTES = W8_BK * W8_AROW, W8_B_BYTES = W8_BK * W8_BROW, W8_STAGE = W8_A_BYTES + W8_B_BYTES;   // 24 + 48 = 72 KiB
+constexpr int W8_NPA = W8_A_BYTES / 1024 / 8, W8_NPB = W8_B_BYTES / 1024 / 8;                                   // 1-KiB pieces per wave: 3, 6
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-// MFMA 32x32x16 fragment of rows obase .. obase + 31 of an operand kept [k][out] in LDS (k-substep ks)
-__device__ __forceinline__ bf16x8 frag_t(const bf16* S, int ld, int obase, int ks, int lane) {
+// MFMA 32x32x16 fragment of output rows obase .. obase + 31 of an operand kept [token][feature] (rotated chunks, see above)
+template <bool IS_A>
+__device__ __forceinline__ bf16x8 frag_rot(const char* S, int obase, int ks, int lane) {
+  constexpr int ROWB = IS_A ? W8_AROW : W8_BROW, NCH = ROWB / 16;
   const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-  const bf16* a = &S[(ks * 16 + 8 * (g >> 1) + q) * ld + obase + 16 * (g & 1) + 4 * pp];
+  const int row = ks * 16 + 8 * (g >> 1) + q, col = obase + 16 * (g & 1) + 4 * pp;
+  int ch = (col >> 3) + (IS_A ? 4 * ((row >> 1) & 1) : 4 * (row & 3));        // row + 4 has the same rotation
+  if (ch >= NCH) ch -= NCH;
+  const char* a = S + row * ROWB + ch * 16 + (col & 7) * 2;
   const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
-  const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * ld));
+  const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * ROWB));
   const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0), b1 = __builtin_bit_cast(bf16x4, t1);
   bf16x8 r;
   r[0] = b0[0]; r[1] = b0[1]; r[2] = b0[2]; r[3] = b0[3];
@@ -38,18 +49,45 @@ __device__ __forceinline__ bf16x8 frag_t(const bf16* S, int ld, int obase, int k
 }
 
 __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item* __restrict__ items) {
-  __shared__ __attribute__((aligned(16))) bf16 smem[W8_BK * (W8_LDA + W8_LDB)];
-  bf16* As = smem;
-  bf16* Bs = smem + W8_BK * W8_LDA;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * W8_STAGE];
   const csts_wgrad_item it = items[blockIdx.x];
   if (it.A == nullptr) return;          // padding slot (the host equalises the per-XCD lists); block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  const int64_t m0 = it.m0, n0 = it.n0, kbeg = it.kbeg;
+  const int nk = (int)((it.kend - kbeg) / W8_BK);          // whole k-tiles only (host-checked)
+
+  // ---- producer: this lane's source offsets (elements, relative to the k-tile's first token row) of the wave's pieces.
+  // LDS byte `off` of an image holds token row off / ROWB, rotated chunk (off % ROWB) / 16; the lane fetches the chunk that
+  // belongs there.
+  int aoff[W8_NPA], boff[W8_NPB];
+#pragma unroll
+  for (int i = 0; i < W8_NPA; ++i) {
+    const int off = (wave * W8_NPA + i) * 1024 + lane * 16, row = off / W8_AROW, chp = (off % W8_AROW) / 16;
+    int c = chp - 4 * ((row >> 1) & 1);
+    if (c < 0) c += W8_AROW / 16;
+    aoff[i] = row * (int)it.lda + (int)m0 + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < W8_NPB; ++i) {
+    const int off = (wave * W8_NPB + i) * 1024 + lane * 16, row = off / W8_BROW, chp = (off % W8_BROW) / 16;
+    int c = chp - 4 * (row & 3);
+    if (c < 0) c += W8_BROW / 16;
+    boff[i] = row * (int)it.ldb + (int)n0 + c * 8;
+  }
   const bf16* __restrict__ A = reinterpret_cast<const bf16*>(it.A);
   const bf16* __restrict__ B = reinterpret_cast<const bf16*>(it.B);
-  const int64_t m0 = it.m0, n0 = it.n0, kbeg = it.kbeg, kend = it.kend;
-  const int nk = (int)((kend - kbeg + W8_BK - 1) / W8_BK);
+  auto issue = [&](char* st, int64_t k0) {
+    const bf16* a = A + k0 * it.lda;
+    const bf16* b = B + k0 * it.ldb;
+#pragma unroll
+    for (int i = 0; i < W8_NPA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a + aoff[i]), (lptr_t)(st + (wave * W8_NPA + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < W8_NPB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(b + boff[i]), (lptr_t)(st + W8_A_BYTES + (wave * W8_NPB + i) * 1024), 16, 0, 0);
+  };
 
   f32x16 acc[3][3];
 #pragma unroll
@@ -59,44 +97,27 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // this thread's chunks of a k-tile: token row and feature offset are the same for every k-tile
-  int akr[W8_NA], aoc[W8_NA], bkr[W8_NB], boc[W8_NB];
-#pragma unroll
-  for (int i = 0; i < W8_NA; ++i) { const int c = tid + W8_THR * i; akr[i] = c / W8_A_CH; aoc[i] = (c % W8_A_CH) * 8; }
-#pragma unroll
-  for (int i = 0; i < W8_NB; ++i) { const int c = tid + W8_THR * i; bkr[i] = c / W8_B_CH; boc[i] = (c % W8_B_CH) * 8; }
-  uint4 ra[W8_NA], rb[W8_NB];
-  auto load = [&](int64_t k0) {
-#pragma unroll
-    for (int i = 0; i < W8_NA; ++i) {
-      const int64_t k = k0 + akr[i];
-      ra[i] = (k < kend) ? *reinterpret_cast<const uint4*>(A + k * it.lda + m0 + aoc[i]) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < W8_NB; ++i) {
-      const int64_t k = k0 + bkr[i];
-      rb[i] = (k < kend) ? *reinterpret_cast<const uint4*>(B + k * it.ldb + n0 + boc[i]) : make_uint4(0, 0, 0, 0);
-    }
-  };
-
   // fused bias gradient (n0 == 0 tiles): 384 threads own a column pair of the dY tile and a quarter of its 64 token rows
   const bool do_colsum = it.colsum != nullptr && n0 == 0 && tid < 384;
   const int cp = tid % 96, csl = tid / 96;
   float cs0 = 0.f, cs1 = 0.f;
 
-  load(kbeg);
+  if (nk > 0) issue(smem, kbeg);
+  int cs = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();                       // previous k-tile fully consumed
-#pragma unroll
-    for (int i = 0; i < W8_NA; ++i) *reinterpret_cast<uint4*>(&As[akr[i] * W8_LDA + aoc[i]]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < W8_NB; ++i) *reinterpret_cast<uint4*>(&Bs[bkr[i] * W8_LDB + boc[i]]) = rb[i];
-    __syncthreads();
-    if (kt + 1 < nk) load(kbeg + (int64_t)(kt + 1) * W8_BK);      // next k-tile's global loads fly under the MFMAs below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of k-tile kt have landed
+    __builtin_amdgcn_s_barrier();                        // ... everyone's have, and everyone is done with the other stage
+    const char* As = smem + cs * W8_STAGE;
+    const char* Bs = As + W8_A_BYTES;
+    if (kt + 1 < nk) issue(smem + (cs ^ 1) * W8_STAGE, kbeg + (int64_t)(kt + 1) * W8_BK);
+    cs ^= 1;
     if (do_colsum) {
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
-        const bf16x2 t = *reinterpret_cast<const bf16x2*>(&As[(csl * 16 + kk) * W8_LDA + 2 * cp]);
+        const int row = csl * 16 + kk;
+        int ch = ((2 * cp) >> 3) + 4 * ((row >> 1) & 1);
+        if (ch >= W8_AROW / 16) ch -= W8_AROW / 16;
+        const bf16x2 t = *reinterpret_cast<const bf16x2*>(As + row * W8_AROW + ch * 16 + ((2 * cp) & 7) * 2);
         cs0 += (float)t[0];
         cs1 += (float)t[1];
       }
@@ -105,9 +126,9 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
     for (int ks = 0; ks < W8_BK / 16; ++ks) {
       bf16x8 a[3], b[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) a[i] = frag_t(As, W8_LDA, wm * 96 + i * 32, ks, lane);
+      for (int i = 0; i < 3; ++i) a[i] = frag_rot<true>(As, wm * 96 + i * 32, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) b[j] = frag_t(Bs, W8_LDB, wn * 96 + j * 32, ks, lane);
+      for (int j = 0; j < 3; ++j) b[j] = frag_rot<false>(Bs, wn * 96 + j * 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -139,7 +160,8 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 
 }  // namespace
 
-// tile 192 x 384, bf16 dY and X; every item must be a whole tile's origin (M % 8 == 0, N % 8 == 0, 16-byte aligned rows)
+// tile 192 x 384, bf16 dY and X; every item is a whole tile (M % 192 == 0, N % 384 == 0), its token range a multiple of 64,
+// rows 16-byte aligned
 extern "C" int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStream_t stream) {
   CSTS_REQUIRE(device_items != nullptr && nitems > 0, "no items");
   hipLaunchKernelGGL(wgrad8_kernel, dim3((unsigned)nitems), dim3(W8_THR), 0, stream, device_items);

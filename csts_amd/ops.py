@@ -229,13 +229,13 @@ def flush_deferred():
 # forward were measured), so eager steps keep the in-line split-K weight gradients unless CSTS_GROUP_WGRADS=1 forces
 # grouping; CSTS_GROUP_WGRADS=0 switches it off everywhere.
 GROUP_WGRADS = {"0": "never", "1": "always"}.get(os.environ.get("CSTS_GROUP_WGRADS", ""), "capture")
-# 192 x 384 tiles on 8-wave workgroups (wgrad8.hip: half the operand bytes per FLOP through L2 -> CU).  Correct
-# (test_grouped_weight_gradients_match_inline runs it) but measured NEUTRAL in the step on MI355X: 1541 us against the 1497 us
-# the same layers took as 128 x 128 / 256 x 128 items, 25.14-25.17 ms vs 25.19 ms per step, any token chunk from 1024 to 8192
-# (profiles/r2_wgrad8_ab.txt) -- the grouped weight gradients are not bound by operand traffic.  Off unless CSTS_WGRAD8=1.
-WGRAD8 = os.environ.get("CSTS_WGRAD8", "0") == "1"
-WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "4096"))   # tokens per 192 x 384 work item: one workgroup per CU, so the
-#   ~264 whole-layer items of the 384-channel stage (8192 tokens each) would run as two rounds on 256 CUs
+# 192 x 384 tiles on 8-wave workgroups (wgrad8.hip: half the operand bytes per FLOP, k-tiles by LDS-DMA into a 2-stage ring,
+# no ds_write phase) for the layers they divide (the 384- and 768-channel stages).  Measured on MI355X
+# (profiles/r2_wgrad8_ab.txt): the register-staged first version 1541 us against the 1497-1565 us those layers cost as
+# 128 x 128 / 256 x 128 items (neutral); the LDS-DMA version 1472 us (-6 %), 24.38-24.42 vs 24.37-24.48 ms per step over three
+# interleaved pairs.  On by default; CSTS_WGRAD8=0 is the A/B switch.  Token chunk: 8192 (4096 / 2048 measured +0.05 / +0.15 ms).
+WGRAD8 = os.environ.get("CSTS_WGRAD8", "1") != "0"
+WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "8192"))
 WGRAD_CHUNK = int(os.environ.get("CSTS_WGRAD_CHUNK", "8192"))   # tokens per work item (measured per step: 4096 -> 24.93 ms, 8192 -> 24.95, 16384 -> 25.47)
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 _wg_tables = {}
@@ -368,7 +368,7 @@ def flush_wgrads(side: bool = False):
     def tile_class(t):
         if t[0].dtype == torch.float32:
             return (True, 128)
-        if WGRAD8 and t[5] % 192 == 0 and t[6] % 384 == 0:
+        if WGRAD8 and t[5] % 192 == 0 and t[6] % 384 == 0 and t[4] % 64 == 0 and WGRAD8_CHUNK % 64 == 0:
             return (False, 192)
         return (False, 256 if t[5] % 256 == 0 else 128)
     for a_f32, rows in ((False, 192), (False, 256), (False, 128), (True, 128)):
