@@ -14,8 +14,8 @@
 // removed by rotating the 16-byte chunks of a token row -- by 4 chunks x ((row >> 1) & 1) in the 192-wide image (row stride
 // 384 B), by 4 x (row & 3) in the 384-wide one (768 B) -- applied to the per-lane SOURCE address of the DMA and, identically,
 // to the fragment read (checked exhaustively: every 32-lane read group touches 64 distinct banks).
-// Wave grid 2 x 4, wave tile 96 x 96 (9 accumulators).  The fp32 tile goes straight from the accumulators to memory: lane =
-// column, so every store instruction writes two full 128-byte lines.  All Linear layers of the 384- and 768-channel stages
+// Wave grid 2 x 4, wave tile 96 x 96 (9 accumulators).  The fp32 tile goes straight from the accumulators to memory as
+// 16-byte stores (MFMA operands swapped so that a lane owns runs of 4 consecutive columns).  All Linear layers of the 384- and 768-channel stages
 // have output features % 192 == 0 and input features % 384 == 0; token chunks must be multiples of 64 (host-checked).
 #include "common.h"
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // operands swapped: see the epilogue
     }
   }
 
@@ -144,18 +144,23 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
     if (tid < W8_TM && m0 + tid < it.M) it.colsum[m0 + tid] = (red[tid] + red[W8_TM + tid]) + (red[2 * W8_TM + tid] + red[3 * W8_TM + tid]);
   }
 
-  // ---------------- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // ---------------- epilogue.  The MFMA operands are swapped (X as the row operand), so acc[i][j][r] is dW[m][n] with m = the
+  // lane's row (lane & 31) of unit i and n = 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of unit j: four consecutive columns per
+  // register quad -> 16-byte stores (36 per thread instead of 144 dword stores; a 295 KB tile per item is a sixth of a
+  // 2048-token item's life otherwise)
+  const int hi = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 3; ++i) {
+    const int64_t m = m0 + wm * 96 + i * 32 + (lane & 31);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int64_t n = n0 + wn * 96 + j * 32 + (lane & 31);
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 96 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < it.M && n < it.N) it.C[m * it.ldc + n] = acc[i][j][r];
+      for (int t = 0; t < 4; ++t) {
+        const int64_t n = n0 + wn * 96 + j * 32 + 8 * t + 4 * hi;
+        if (m < it.M && n < it.N)
+          *reinterpret_cast<f32x4*>(it.C + m * it.ldc + n) = f32x4{acc[i][j][4 * t], acc[i][j][4 * t + 1], acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]};
       }
-    }
+  }
 }
 
 }  // namespace
