@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--no-loss-check", action="store_true")
     p.add_argument("--rehearse-dist", action="store_true",
                    help="run the N>1 code path (RCCL process group, graph chain + eager collectives) with ONE rank")
+    p.add_argument("--trunk-cut", type=int, default=None,
+                   help="data-parallel graph chain: second autograd cut in front of this video block (default CSTS_AMD.TRUNK_CUT = 3; 0 = off)")
     p.add_argument("--eager-dist", action="store_true",
                    help="N>1: the eager step with hook-driven gradient buckets (GradAllReduce) instead of the graph chain")
     p.add_argument("--no-graph", action="store_true", help="do not capture anything into HIP graphs")
@@ -360,6 +362,8 @@ def main():
     b, S = args.batch_per_gpu, args.crop
     opts = ["NUM_GPUS", min(world, ndev), "TRAIN.BATCH_SIZE", b * world, "MODEL.LOSS_FUNC", "kldiv+egonce", "MODEL.LOSS_ALPHA", 0.05,
             "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute]
+    if args.trunk_cut is not None:
+        opts += ["CSTS_AMD.TRUNK_CUT", args.trunk_cut]
     if S != 256:
         opts += ["DATA.TRAIN_CROP_SIZE", S, "DATA.TEST_CROP_SIZE", S, "CSTS_AMD.FUSION_KERNEL_FROM_GRID", True]
     cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"), opts)
@@ -458,7 +462,7 @@ def main():
     segments = None
     if train and world == 1 and not dist_path and not args.no_segments and not args.no_graph:
         try:
-            seg = T.SegmentedTrainStep(cfg, model, opt, batch, warmup=1)
+            seg = T.SegmentedTrainStep(cfg, model, opt, batch, warmup=1, trunk_cut=0)
             for _ in range(3):
                 seg.run(batch, lr)
             rows = []
@@ -572,6 +576,7 @@ def main():
             "config": {"workload": f"CSTS_Ego4D_Gaze_Forecast.yaml {what}, {args.frames}x{S}^2 video + 24 kHz STFT audio, b={b}/GPU",
                        "mode": args.mode, "global_batch": b * world, "frames": args.frames, "crop": S, "parallelism": f"dp{world}",
                        "step": step_kind, "hip_graph": step_kind != "eager", "rccl_ranks": rccl_ranks,
+                       **({"trunk_cut": int(graphed.trunk_cut)} if hasattr(graphed, "trunk_cut") else {}),
                        "dist_backend": (torch.distributed.get_backend() if dist_path else None),
                        "note": ("256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)" if S == 256 else
                                 "EXTENSION, parity unpinned: 224^2 with (1,7,7) fusion kernels (CSTS_AMD.FUSION_KERNEL_FROM_GRID); "

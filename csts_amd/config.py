@@ -110,6 +110,7 @@ def get_cfg() -> CfgNode:
                        SYNTHETIC_DATA=True,          # the data pipeline is out of scope: synthetic clips
                        STEPS_PER_EPOCH=50,
                        GRAD_BUCKET_MB=64,
+                       TRUNK_CUT=3,                  # data-parallel graph chain: second autograd cut in front of this video block (0 = trunks in one piece)
                        TWO_STREAMS=True,             # audio trunk on a second HIP stream, concurrent with the video trunk
                        SAVE_CHECKPOINTS=False,       # write checkpoints/checkpoint_epoch_XXXXX.pyth (reference wire format) every CHECKPOINT_PERIOD
                        HIP_GRAPH=True,               # single GPU: capture the whole iteration once, replay it (train.GraphedTrainStep)

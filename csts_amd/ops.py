@@ -11,6 +11,7 @@ import contextlib
 import ctypes as C
 import math
 import os
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -67,6 +68,20 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+_host_tables = []       # weak references to every HostTable of the process
+
+
+def refill_capture_pools():
+    """Called by the graph-capturing steps (csts_amd.train) right before a capture pass: every table gets its full set of
+    capture buffers back, so a process may capture any number of steps one after the other."""
+    for r in list(_host_tables):
+        t = r()
+        if t is None:
+            _host_tables.remove(r)
+        else:
+            t.refill()
+
+
 class HostTable:
     """Small host -> device table upload that is safe while the host runs ahead of the GPU (a ring of pinned buffers,
     a slot is reused only after its copy has executed) and under HIP-graph capture (pre-allocated pinned buffers that
@@ -77,9 +92,16 @@ class HostTable:
         self._ring = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(ring)]
         self._ev = [None] * ring
         self._pos = 0
+        self._captures = captures
         self._pool = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(captures)]
         self._captured = []
         self.dev = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _host_tables.append(weakref.ref(self))
+
+    def refill(self):
+        """Top the capture pool up again (outside a capture: pinned allocations are not allowed while one is open)."""
+        while len(self._pool) < self._captures:
+            self._pool.append(torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory())
 
     def upload(self, payload: bytes) -> int:
         n = len(payload)

@@ -8,7 +8,9 @@ slowfast/utils/lr_policy.py's cosine.  Three ways to run the step: eagerly (trai
 between them (SegmentedTrainStep, the data-parallel step)."""
 from __future__ import annotations
 
+import contextlib
 import math
+import time
 from typing import Dict, Optional
 
 import torch
@@ -241,6 +243,7 @@ class GraphedTrainStep:
                     self._step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            ops.refill_capture_pools()
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: a process group's watchdog thread may poll events while this capture is open (see SegmentedTrainStep)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -277,10 +280,15 @@ class GraphedTrainStep:
 
 class SegmentedTrainStep:
     """The training iteration as a CHAIN of HIP graphs -- forward | backward of the fusion/decoder head | backward of the
-    encoder trunks | clip + AdamW -- with the loss and every RCCL collective issued EAGERLY between them:
+    encoder trunks (in one or two parts) | clip + AdamW -- with the loss and every RCCL collective issued EAGERLY between them:
 
         G_fwd -> [EgoNCE all-gather, losses, their backward: ~20 small launches] -> G_bwd_head -> all-reduce(head grads, async)
-              -> G_bwd_trunk -> all-reduce(trunk grads) -> wait -> G_opt
+              -> G_bwd_trunk -> all-reduce(trunk grads, async)
+              [-> G_bwd_trunk_early -> all-reduce(early video trunk grads)]  -> wait -> G_opt
+
+    trunk_cut = k > 0 (CSTS_AMD.TRUNK_CUT, default 3) cuts the trunks once more in front of video block k: the last bucket,
+    the only one whose all-reduce nothing hides, is then the 1.3 M parameters of the 96- / 192-channel stages instead of all
+    44.6 M of the trunks, and the other 43 M travel underneath those stages' backward (a third of the trunk backward).
 
     This is the data-parallel step: the compute runs from graphs exactly as on one GPU (grouped weight gradients, deferred
     reductions, two-stream trunks included), no collective is ever captured, and the head bucket -- the three 37.7 M-parameter
@@ -289,7 +297,8 @@ class SegmentedTrainStep:
     reads them through p.grad views.  With one process it degenerates to the same chain without collectives (used by
     bench.py to time forward / backward / optimizer separately)."""
 
-    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2, use_graphs: bool = True, loss_fn=None):
+    def __init__(self, cfg, model, optimizer, example_batch, warmup: int = 2, use_graphs: bool = True, loss_fn=None,
+                 trunk_cut: Optional[int] = None):
         """use_graphs=False runs the same chain eagerly (any device: the bucket / collective logic is then testable with
         gloo on the CPU); loss_fn(outs, static) -> (loss, kld, nce) replaces the built-in HIP losses (tests)."""
         from . import ops
@@ -305,12 +314,21 @@ class SegmentedTrainStep:
         core = self.core
         self.head_params = [p for p in core.head_parameters() if p.requires_grad]
         hid = {id(p) for p in self.head_params}
+        if trunk_cut is None:
+            trunk_cut = int(getattr(getattr(cfg, "CSTS_AMD", None), "TRUNK_CUT", 0) or 0)
+        if not hasattr(core, "early_trunk_parameters"):
+            trunk_cut = 0
+        self.trunk_cut = trunk_cut
+        self.early_params = [p for p in core.early_trunk_parameters(trunk_cut) if p.requires_grad] if trunk_cut else []
+        hid |= {id(p) for p in self.early_params}
         self.trunk_params = [p for p in core.parameters() if p.requires_grad and id(p) not in hid]
+        # gradient buckets in the order their backward segments finish
+        self.buckets = [self.head_params, self.trunk_params] + ([self.early_params] if trunk_cut else [])
         self._avg = None
         if self.dist:
             import torch.distributed as dist
             self._avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None
-            self.flat = [self._flat_for(self.head_params), self._flat_for(self.trunk_params)]
+            self.flat = [self._flat_for(ps) for ps in self.buckets]
         self.events = None
         self.graphs = {}
         if not use_graphs:
@@ -326,6 +344,9 @@ class SegmentedTrainStep:
                     self._chain(capture=False)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if self.dist:
+                time.sleep(0.5)          # the watchdog drops the (finished) warm-up collectives from its list
+            ops.refill_capture_pools()
             self._chain(capture=True)
             torch.cuda.synchronize()
         finally:
@@ -403,14 +424,26 @@ class SegmentedTrainStep:
         if hasattr(self.opt, "params"):
             self.opt.zero_grad(set_to_none=True)
         else:
-            for p in self.head_params + self.trunk_params:
-                p.grad = None
-        cut = {}
+            for ps in self.buckets:
+                for p in ps:
+                    p.grad = None
+        cut, cut2 = {}, {}
 
-        def boundary(feats):
-            cut["out"] = feats
-            cut["in"] = [f.detach().requires_grad_(True) for f in feats]
-            return cut["in"]
+        class _Cuts:
+            """The autograd cuts of one forward: __call__ = trunks | head, inner = early video trunk | rest of the trunks."""
+            trunk_cut = self.trunk_cut
+
+            def __call__(self_, feats):
+                cut["out"] = feats
+                cut["in"] = [f.detach().requires_grad_(True) for f in feats]
+                return cut["in"]
+
+            def inner(self_, feats):
+                cut2["out"] = feats
+                cut2["in"] = [f.detach().requires_grad_(True) for f in feats]
+                return cut2["in"]
+
+        boundary = _Cuts()
 
         def fwd():
             out = core([self.static["video"]], self.static["audio"], return_embed=with_embed, boundary=boundary)
@@ -419,7 +452,13 @@ class SegmentedTrainStep:
         self.outs = self._segment("fwd", fwd, capture)
         if capture or not hasattr(self, "douts"):
             self.douts = [torch.zeros_like(o) for o in self.outs]
-        res = self._loss_eager()
+        # The capture pass issues NO collective: the graphs are only recorded there, so what the eager parts between them
+        # compute is thrown away anyway -- and RCCL's watchdog thread, which polls the events of unfinished collectives
+        # (hipEventQuery), then has nothing to poll while a capture is open (two different HIP capture errors came out of
+        # that thread otherwise, taking the process down).  Every rank takes the same branch.
+        coll = self.dist and not capture
+        with (du.local_only() if (self.dist and capture) else contextlib.nullcontext()):
+            res = self._loss_eager()
         if capture:
             self.result = res
 
@@ -429,25 +468,60 @@ class SegmentedTrainStep:
                 torch._foreach_copy_(self.flat[0][1], [p.grad for p in self.head_params])
 
         self._segment("bwd_head", bwd_head, capture)
-        works = [self._all_reduce(0)] if self.dist else []
+        works = [self._all_reduce(0)] if coll else []
 
         def bwd_trunk():
-            torch.autograd.backward(cut["out"], [t.grad for t in cut["in"]], inputs=self.trunk_params)
+            # with a second cut, the tensors produced in front of it (encoder features of the early stages) wait for the
+            # early segment: this backward starts from the late trunk's outputs only and ends at the cut's stand-in
+            late = [(o, i.grad) for o, i in zip(cut["out"], cut["in"]) if not self._from_early(o, cut2)]
+            torch.autograd.backward([o for o, _ in late], [g for _, g in late], inputs=self.trunk_params + cut2.get("in", []))
             if self.dist:
                 torch._foreach_copy_(self.flat[1][1], [p.grad for p in self.trunk_params])
 
         self._segment("bwd_trunk", bwd_trunk, capture)
-        if self.dist:
+        if coll:
             works.append(self._all_reduce(1))
+        if self.trunk_cut:
+            def bwd_early():
+                early = [(o, i.grad) for o, i in zip(cut["out"], cut["in"]) if self._from_early(o, cut2)]
+                roots = cut2["out"] + [o for o, _ in early]
+                grads = [t.grad for t in cut2["in"]] + [g for _, g in early]
+                torch.autograd.backward(roots, grads, inputs=self.early_params)
+                if self.dist:
+                    torch._foreach_copy_(self.flat[2][1], [p.grad for p in self.early_params])
+
+            self._segment("bwd_trunk_early", bwd_early, capture)
+            if coll:
+                works.append(self._all_reduce(2))
+        if self.dist:
             for w in works:
                 w.wait()
-            self._raw_grads = [p.grad for p in self.head_params + self.trunk_params]   # graph-owned: keep them alive
-            for k, ps in enumerate((self.head_params, self.trunk_params)):
+            self._raw_grads = [p.grad for ps in self.buckets for p in ps]   # graph-owned: keep them alive
+            for k, ps in enumerate(self.buckets):
                 for p, v in zip(ps, self.flat[k][1]):
                     p.grad = v
         self._segment("opt", lambda: _clip_and_step(cfg, self.model, self.opt), capture)
-        del cut
+        del cut, cut2
         return res
+
+    def _from_early(self, t, cut2):
+        """Is head-boundary tensor t produced in front of the inner cut (the features tapped off the early stages)?  Its
+        autograd history then reaches an early-trunk parameter; the late trunk's outputs end at the cut's stand-in, the audio
+        trunk's at its own parameters."""
+        if not cut2:
+            return False
+        early = {id(p) for p in self.early_params}
+        seen, stack = set(), [t.grad_fn]      # `seen` holds the node objects themselves: ids of dead wrappers get re-used
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            v = getattr(fn, "variable", None)             # AccumulateGrad node of a leaf
+            if v is not None and id(v) in early:
+                return True
+            stack.extend(f for f, _ in fn.next_functions)
+        return False
 
     # ------------------------------------------------------------------ replay
     def run(self, batch=None, lr: Optional[float] = None, timed: bool = False):
@@ -472,8 +546,12 @@ class SegmentedTrainStep:
         self.graphs["bwd_trunk"].replay()
         if self.dist:
             works.append(self._all_reduce(1))
-            for w in works:
-                w.wait()
+        if self.trunk_cut:
+            self.graphs["bwd_trunk_early"].replay()
+            if self.dist:
+                works.append(self._all_reduce(2))
+        for w in works:
+            w.wait()
         mark(4)
         self.graphs["opt"].replay()
         mark(5)
@@ -482,7 +560,8 @@ class SegmentedTrainStep:
         return res
 
     def segment_ms(self):
-        """(forward, loss, backward head, backward trunk [+ exposed all-reduce], optimizer) of the last run(timed=True)."""
+        """(forward, loss, backward head, backward trunks [both parts + exposed all-reduce], optimizer) of the last
+        run(timed=True)."""
         torch.cuda.synchronize()
         e = self.events
         return [e[i].elapsed_time(e[i + 1]) for i in range(5)]

@@ -301,12 +301,14 @@ def test_two_rank_gloo_whole_grad_allreduce_on_csts_shaped_module():
 
 
 class _ToySegModel(torch.nn.Module):
-    """A two-part model with the CSTS segment interface (forward(x, y, return_embed, boundary) / head_parameters) over
-    plain torch CPU ops: trunk = two encoders, head = fusion + 'decoder' + embedding projections."""
+    """A model with the CSTS segment interface (forward(x, y, return_embed, boundary) / head_parameters /
+    early_trunk_parameters) over plain torch CPU ops: trunk = a two-stage video encoder whose first-stage feature is also a
+    decoder skip + an audio encoder, head = fusion + 'decoder' + embedding projections."""
 
     def __init__(self):
         super().__init__()
-        self.enc_v = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 16))
+        self.enc_v0 = torch.nn.Linear(6, 16)
+        self.enc_v1 = torch.nn.Sequential(torch.nn.GELU(), torch.nn.Linear(16, 16))
         self.enc_a = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 16))
         self.fuse = torch.nn.Linear(32, 16)
         self.dec = torch.nn.Linear(16, 5)
@@ -316,12 +318,19 @@ class _ToySegModel(torch.nn.Module):
     def head_parameters(self):
         return [p for m in (self.fuse, self.dec, self.vision_proj, self.audio_proj) for p in m.parameters()]
 
+    def early_trunk_parameters(self, k):
+        return list(self.enc_v0.parameters())
+
     def forward(self, x, y, return_embed=False, boundary=None):
-        feats = [self.enc_v(x[0]), self.enc_a(y)]
+        e = self.enc_v0(x[0])
+        skip = e * 1.0                                     # the early feature the decoder re-uses
+        if getattr(boundary, "trunk_cut", 0):
+            e = boundary.inner([e])[0]
+        feats = [self.enc_v1(e), self.enc_a(y), skip]
         if boundary is not None:
             feats = boundary(feats)
-        v, a = feats
-        logits = self.dec(torch.tanh(self.fuse(torch.cat([v, a], dim=-1))))
+        v, a, skip = feats
+        logits = self.dec(torch.tanh(self.fuse(torch.cat([v, a], dim=-1))) + 0.5 * skip)
         return [logits, self.vision_proj(v.mean(dim=1)), self.audio_proj(a.mean(dim=1))]
 
 
@@ -336,7 +345,7 @@ def _toy_loss(gathered_fn):
     return loss_fn
 
 
-def _dist_worker_segmented(rank, world, port, q):
+def _dist_worker_segmented(rank, world, port, q, trunk_cut=0):
     """csts_amd.train.SegmentedTrainStep (the data-parallel step: forward | eager losses + embedding all-gather | backward
     head | all-reduce(head bucket) | backward trunk | all-reduce(trunk bucket) | optimizer) run WITHOUT graphs on 2 gloo
     ranks: the gradients the optimizer sees must equal those of ONE process on the concatenated batch, p.grad must be
@@ -366,7 +375,9 @@ def _dist_worker_segmented(rank, world, port, q):
         ((l0 + l1) / 2 + 0.05 * nce_ref).backward()
         wrapped = du.GradAllReduce(net, bucket_mb=1)
         opt = torch.optim.SGD(net.parameters(), lr=0.1)
-        seg = T.SegmentedTrainStep(cfg, wrapped, opt, mine, use_graphs=False, loss_fn=_toy_loss(du.all_gather_with_grad))
+        seg = T.SegmentedTrainStep(cfg, wrapped, opt, mine, use_graphs=False, loss_fn=_toy_loss(du.all_gather_with_grad),
+                                   trunk_cut=trunk_cut)
+        assert len(seg.flat) == (3 if trunk_cut else 2) and sum(len(b) for b in seg.buckets) == len(list(net.parameters()))
         before = [p.detach().clone() for p in net.parameters()]
         loss, kld, nce = seg.step_eager(mine, lr=0.1)
         ok_hooks = not wrapped.hooks_enabled
@@ -387,12 +398,14 @@ def _dist_worker_segmented(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_segmented_data_parallel_step():
+@pytest.mark.parametrize("trunk_cut", [0, 1])
+def test_two_rank_gloo_segmented_data_parallel_step(trunk_cut):
+    """trunk_cut = 1: the three-bucket chain (head | late trunks | early video trunk behind a second autograd cut)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_dist_worker_segmented, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + 2500 * trunk_cut
+    procs = [ctx.Process(target=_dist_worker_segmented, args=(r, 2, port, q, trunk_cut)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=90) for _ in range(2)]

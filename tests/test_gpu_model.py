@@ -537,17 +537,24 @@ def test_graphed_train_step_matches_eager():
     _MODELS.clear()
 
 
-def test_segmented_train_step_matches_eager():
-    """The chain of HIP graphs (forward | eager losses | backward head | backward trunk | clip + AdamW: the data-parallel
-    step, here with one process and no collectives) == eager execution: same losses over two steps, same weights after."""
+@pytest.mark.parametrize("trunk_cut", [3, 0])
+def test_segmented_train_step_matches_eager(trunk_cut):
+    """The chain of HIP graphs (forward | eager losses | backward head | backward trunks, in two parts behind a second
+    autograd cut in front of video block 3 or in one | clip + AdamW: the data-parallel step, here with one process and no
+    collectives) == eager execution: same losses over two steps, same weights after."""
     import copy
     m, cfg = make_model("bf16")
+    cfg.CSTS_AMD.TRUNK_CUT = trunk_cut
     m2 = copy.deepcopy(m)
     batch = T.synthetic_batch(2, 8, 256, 99, DEV)
     opt_e = T.construct_optimizer(m, cfg)
     opt_g = T.construct_optimizer(m2, cfg, capturable=True)
     state0 = copy.deepcopy(m2.state_dict())
     g = T.SegmentedTrainStep(cfg, m2, opt_g, batch, warmup=1)
+    assert g.trunk_cut == trunk_cut and ("bwd_trunk_early" in g.graphs) == bool(trunk_cut)
+    if trunk_cut:
+        n_early = sum(p.numel() for p in g.early_params)
+        assert 1.0e6 < n_early < 2.0e6 and len(g.early_params) + len(g.trunk_params) + len(g.head_params) == len(list(m2.parameters()))
     m2.load_state_dict(state0)                                # undo warm-up / capture updates
     opt_g.reset_state()
     le = [float(T.train_step(cfg, m, batch, opt_e, lr=1e-4)[0]) for _ in range(2)]
@@ -556,7 +563,8 @@ def test_segmented_train_step_matches_eager():
     print(f"\n[segmented step, T8 B2] eager losses {le}, graph-chain losses {lg}, segments (fwd, loss, bwd head, bwd trunk, opt) ms {[round(x, 3) for x in ms]}")
     assert abs(le[0] - lg[0]) < 1e-4 and abs(le[1] - lg[1]) < 5e-3, (le, lg)
     for name in ("blocks.5.mlp.fc1.weight", "blocks_audio.2.attn.pool_k.weight", "vision_pool.weight", "decode_block3.norm1.weight",
-                 "pos_embed_spatial", "classifier.weight"):
+                 "pos_embed_spatial", "classifier.weight", "blocks.1.mlp.fc1.weight", "blocks.2.attn.qkv.weight",
+                 "patch_embed.proj.weight", "blocks.3.norm1.weight"):
         w_e, w_g = dict(m.named_parameters())[name], dict(m2.named_parameters())[name]
         assert rel_l2(w_g, w_e) < 1e-3, name
     _MODELS.clear()
@@ -590,6 +598,7 @@ def test_segmented_step_with_rccl_one_rank():
         loss, *_ = g.run(batch, lr=0.0)                      # lr 0: weights stay, gradients can be compared
         torch.cuda.synchronize()
         assert abs(float(loss) - float(ref_loss)) < 1e-4
+        assert len(g.flat) == 3 and g.trunk_cut == 3          # head | late trunks | early video trunk (CSTS_AMD.TRUNK_CUT)
         flat_ptrs = [(f.data_ptr(), f.data_ptr() + f.numel() * 4) for f, _ in g.flat]
         for n, p in m.named_parameters():
             assert any(lo <= p.grad.data_ptr() < hi for lo, hi in flat_ptrs), n
