@@ -326,21 +326,33 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
     plan = _wg_plans.get((sig, rows, cols, CH))
     if plan is not None:
         return plan
+    # (Cutting the layers with the fewest tiles into half-length chunks, so that the 192 x 384 class's 310 full-length items
+    # of the b=4 step do not leave 54 of them for a second, almost empty round on 256 CUs, was measured: kernel 1335 ->
+    # 1276 us, step unchanged -- the partial slabs and their reduction cost what the balance returns.)
+    CHs = [CH] * len(sig)
     groups = []
     for pi, (tokens, N, K) in enumerate(sig):
-        nch = -(-tokens // CH)
+        CHp = CHs[pi]
+        nch = -(-tokens // CHp)
         for c in range(nch):
-            kb, ke = c * CH, min(tokens, (c + 1) * CH)
+            kb, ke = c * CHp, min(tokens, (c + 1) * CHp)
             # one group = ALL tiles of this (layer, token chunk): they run together on one XCD and stream the same
             # token range in near lockstep, so its L2 serves every dY / X panel slice to all the tiles that share it
             # (grouping by tile-row only reused the dY panel: rocprofv3 still counted 18.6 GB per launch)
             groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, rows) for n0 in range(0, K, cols)])
+    # two levels of longest-first: groups go to the least-loaded XCD in order of their total work; inside an XCD's list the
+    # groups with the longest ITEMS start first (a 8192-token item runs 4 x as long as a 2048-token one: started last it
+    # is the tail of the launch, with most CUs idle -- 1448 -> 1317 us for the 192 x 384 class of the b=4 step)
     groups.sort(key=lambda g_: -g_[0][0] * len(g_))
-    lists, load = [[] for _ in range(8)], [0] * 8
+    glists, load = [[] for _ in range(8)], [0] * 8
     for g_ in groups:
         x = load.index(min(load))
-        lists[x].extend(g_)
+        glists[x].append(g_)
         load[x] += g_[0][0] * len(g_)
+    lists = []
+    for gl in glists:
+        gl.sort(key=lambda g_: -g_[0][0])          # stable: equal item lengths keep the by-work order
+        lists.append([it for g_ in gl for it in g_])
     depth = max(len(l_) for l_ in lists)
     n_items = depth * 8
     if n_items > 16384:
@@ -355,7 +367,7 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
             tmpl[i] = (0, 0, 0, 0, N, K, K, kb, ke, N, K, m0, n0)
             pidx[i], chunk[i] = pi, c
     valid = pidx >= 0
-    plan = _wg_plans[(sig, rows, cols, CH)] = (tmpl, valid, pidx[valid], chunk[valid], n_items)
+    plan = _wg_plans[(sig, rows, cols, CH)] = (tmpl, valid, pidx[valid], chunk[valid], n_items, CHs)
     return plan
 
 
@@ -398,12 +410,12 @@ def flush_wgrads(side: bool = False):
         if not probs:
             continue
         CH = WGRAD8_CHUNK if rows == 192 else WGRAD_CHUNK
-        tmpl, valid, pidx, chunk, n_items = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, 384 if rows == 192 else 128, CH)
+        tmpl, valid, pidx, chunk, n_items, CHs = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, 384 if rows == 192 else 128, CH)
         A = np.empty(len(probs), dtype=np.uint64); B = np.empty_like(A); Cb = np.empty_like(A); Cs = np.zeros_like(A)
         cstride = np.zeros(len(probs), dtype=np.uint64); sstride = np.zeros_like(cstride)
         for i, (dY, X, dW, db, tokens, N, K) in enumerate(probs):
             A[i], B[i] = dY.data_ptr(), X.data_ptr()
-            nch = -(-tokens // CH)
+            nch = -(-tokens // CHs[i])
             if nch == 1:
                 Cb[i], Cs[i] = dW.data_ptr(), (db.data_ptr() if db is not None else 0)
             else:          # several token chunks: one partial slab per chunk, summed by the batched reducer
