@@ -288,19 +288,31 @@ __global__ __launch_bounds__(256) void reweight_dw_kernel(const float* __restric
   for (int i = 0; i < HW; ++i) { const int64_t o = (bt * HW + i) * C + c; s += x[o] * dy[o]; }
   dw[idx] = s;
 }
-// out[b,c] = mean_n x[b,n,c]   ;  bwd: dx[b,n,c] = dout[b,c] / N      (block = 64 channels x 4 token lanes)
+// out[b,c] = mean_n x[b,n,c]   ;  bwd: dx[b,n,c] = dout[b,c] / N      (block = 16 channels x 16 token lanes: B * C / 16
+// workgroups -- 192 for the b=4 embeddings instead of the 48 of a 64 x 4 block, each lane with 4 independent partial sums)
 __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t nbc,
                                                          int N, int C) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx;
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
   const int64_t b = blockIdx.y;
-  float s = 0.f;
-  if (c < C)
-    for (int n = ty; n < N; n += 4) s += x[(b * N + n) * C + c];
-  red[ty][tx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* p = x + b * N * C + c;
+    int n = ty;
+    for (; n + 48 < N; n += 64) {
+      s0 += p[(int64_t)n * C]; s1 += p[(int64_t)(n + 16) * C]; s2 += p[(int64_t)(n + 32) * C]; s3 += p[(int64_t)(n + 48) * C];
+    }
+    for (; n < N; n += 16) s0 += p[(int64_t)n * C];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ty == 0 && c < C) out[b * C + c] = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / N;
+  if (ty == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][tx];
+    out[b * C + c] = t / N;
+  }
 }
 __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
                                                              int64_t total, int N, int C) {
@@ -696,7 +708,7 @@ extern "C" int csts_reweight_bwd(const float* x, const float* w, const float* dy
 }
 extern "C" int csts_token_mean_fwd(const float* x, float* out, int64_t B, int N, int C, hipStream_t stream) {
   CSTS_REQUIRE(x && out && B > 0 && N > 0 && C > 0, "bad args");
-  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)B), dim3(256), 0, stream, x, out, B * C, N, C);
+  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)cdiv(C, 16), (unsigned)B), dim3(256), 0, stream, x, out, B * C, N, C);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
