@@ -189,13 +189,34 @@ template <int V> __device__ __forceinline__ void fmav(float (&acc)[V], const flo
 }
 
 // weights staged as wl[28][HD] fp32: 27 taps + one all-zero row (index 27) that invalid taps point to
-__device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, float* wl, int HD) {
-  const int nthr = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
-  for (int i = tid; i < HD * 27; i += nthr) {   // coalesced global reads; the (conflicting) transposition is paid in LDS
-    const int c = i / 27, k = i - c * 27;
-    wl[k * HD + c] = w[i];
+// Coalesced global reads, 12 per thread IN FLIGHT before the first LDS store (a plain load -> store loop waits for every
+// load on its own: 11 round trips in a row for a 96-channel table on 256 threads, and this table is the first thing every
+// workgroup of the stencil kernels needs); the (conflicting) transposition is paid in LDS.
+__device__ __forceinline__ void stage_weight_rows(const float* __restrict__ w, float* wl, int HD, int nthr, int tid) {
+  const int n = HD * 27;
+  // (channel, tap) of element i = tid + u * nthr WITHOUT a division per element (the stencil kernels are bound by VALU
+  // issue, and this table costs every workgroup ~22 elements per thread): one division for the first element, then
+  // i += nthr moves the tap by nthr % 27 and the channel by nthr / 27 (+ 1 on wrap-around)
+  const int dq = nthr / 27, dr = nthr - dq * 27;
+  int c = tid / 27, k = tid - c * 27;
+  for (int base = tid; base < n; base += nthr * 12) {
+    float v[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int i = base + u * nthr;
+      v[u] = i < n ? w[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      if (base + u * nthr < n) wl[k * HD + c] = v[u];
+      k += dr; c += dq;
+      if (k >= 27) { k -= 27; ++c; }
+    }
   }
   for (int i = tid; i < HD; i += nthr) wl[27 * HD + i] = 0.f;
+}
+__device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, float* wl, int HD) {
+  stage_weight_rows(w, wl, HD, blockDim.x * blockDim.y, threadIdx.y * blockDim.x + threadIdx.x);
   __syncthreads();
 }
 
@@ -254,6 +275,9 @@ __global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const v
 // A group of GL lanes owns one (batch, out-token, head, slot) item, 8 channels per lane (HD/8 lanes active), so the
 // LayerNorm statistics are a shuffle reduction inside the group and the pooled row never leaves registers before it is
 // normalised.  Writes the pre-LN row (saved for backward), the normalised row, mean and rstd.
+#ifndef POOL_LN_WGS
+#define POOL_LN_WGS 4      // workgroups per CU the register budget is set for (128 VGPRs: the 1024-workgroup launches run in ONE round)
+#endif
 struct PoolLnSlots {
   const void* fine[2];
   const float* w[2];
@@ -265,21 +289,12 @@ struct PoolLnSlots {
   float* rstd[2];
 };
 template <int GL, bool F32>
-__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlots sl, int nslots, float eps) {
+__global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlots sl, int nslots, float eps) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [nslots][28][HD]
   const Geom& g = rg.g;
   const int HD = g.HD, H = g.C / HD;
   {   // stage both slots' weights (tap-major, one zero row each)
-    const int nthr = blockDim.x, tid = threadIdx.x;
-    for (int s2 = 0; s2 < nslots; ++s2) {
-      float* dst = wl + s2 * 28 * HD;
-      const float* w = sl.w[s2];
-      for (int i = tid; i < HD * 27; i += nthr) {
-        const int c = i / 27, k = i - c * 27;
-        dst[k * HD + c] = w[i];
-      }
-      for (int i = tid; i < HD; i += nthr) dst[27 * HD + i] = 0.f;
-    }
+    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows(sl.w[s2], wl + s2 * 28 * HD, HD, blockDim.x, threadIdx.x);
     __syncthreads();
   }
   const int lane_in = threadIdx.x % GL;
@@ -299,36 +314,40 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(RowGeom rg, PoolLnSlot
     int b, ot, oh, ow;
     decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
     const int c = head * HD + c8;
-    int tof[3], hof[3], xof[3];
-    bool tv[3], hv[3], xv[3];
+    int hof[3], xof[3];
+    bool hv[3], xv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
-      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+      const int h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
       hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
     }
     const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
     const float* wls = wl + slot * 28 * HD + c8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    Raw8<F32> raw[27];                      // all 27 taps in flight at once (one memory round trip per item, not three)
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt)
+    // 9 taps (one temporal slice) in flight at a time: a 128-register budget, FOUR workgroups per CU, so the 1024-workgroup
+    // launches of the 384-channel stages are resident at once.  (All 27 taps at once -- one memory round trip per item
+    // instead of three -- needs 176 registers = two workgroups per CU = two rounds.  Measured alike: 27.9 vs 28.2 us for
+    // those launches, 10-30 % faster for the smaller ones; rocprofv3 kernel trace, profiles/r2_pool_ln_ab.txt.)
+#pragma unroll 1
+    for (int kt = 0; kt < 3; ++kt) {           // a real loop: unrolled, the scheduler hoists all 27 loads again and spills
+      const int t = (ot << rg.lt) - 1 + kt;
+      const bool tvk = (unsigned)t < (unsigned)g.Tf;
+      const int tofk = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+      Raw8<F32> raw[9];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) raw[kt * 9 + kh * 3 + kw] = raw8_load<F32>(fb, tof[kt] + hof[kh] + xof[kw]);
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
+        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw8_load<F32>(fb, tofk + hof[kh] + xof[kw]);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int tap = (tv[kt] && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
+          const int tap = (tvk && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
           const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * HD]);
           const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * HD + 4]);
           float v[8];
-          raw8_cvt<F32>(raw[kt * 9 + kh * 3 + kw], v);
+          raw8_cvt<F32>(raw[kh * 3 + kw], v);
           acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;
           acc[4] += v[4] * w1.x; acc[5] += v[5] * w1.y; acc[6] += v[6] * w1.z; acc[7] += v[7] * w1.w;
         }
