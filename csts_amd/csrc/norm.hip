@@ -83,6 +83,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
   }
 }
 
+// optional bf16 copy of dx (+ per-sample scale applied to the copy only: row r uses scale[r / rps])
+struct Copy16 {
+  bf16* p = nullptr;
+  const float* scale = nullptr;
+  int64_t rps = 1;
+};
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // per-wave partial dgamma/dbeta are summed through LDS and written to ws[block][2*C]
 template <int NV, int R, bool DYF32, bool XF32>
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, void* __restrict__ dx,
                                                      const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
-                                                     int C, const float* __restrict__ gamma1, bf16* __restrict__ dx16) {
+                                                     int C, const float* __restrict__ gamma1, Copy16 dx16) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [LN_BWD_WAVES][2*C]
   // blockIdx.y = segment: a second tensor of the same shape stacked behind the first (rows each), with its own gamma and
   // its own partial rows (the k and v LayerNorms of one attention in one launch)
@@ -147,7 +153,9 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
           if (c < C) {
             const float val = rs[r] * (g[j] - s1 - xh[j] * s2) + ad[r][j];
             stt<XF32>(dx, (ro + row0 + r) * C + c, val);
-            if (dx16) dx16[(ro + row0 + r) * C + c] = (bf16)val;   // the copy the next GEMMs read (they round to bf16 anyway)
+            // the copy the next GEMMs read (they round to bf16 anyway), times the per-sample drop-path scale of the
+            // branch that consumes it when the caller knows it (saves that branch a scale_rows pass over dx)
+            if (dx16.p) dx16.p[(ro + row0 + r) * C + c] = (bf16)(dx16.scale ? val * dx16.scale[(row0 + r) / dx16.rps] : val);
           }
         }
       }
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const void* __restrict_
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, void* __restrict__ dx,
                                                          const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
-                                                         int C, const float* __restrict__ gamma1, bf16* __restrict__ dx16) {
+                                                         int C, const float* __restrict__ gamma1, Copy16 dx16) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [512 / GL groups][2*C]
   const int64_t ro = (int64_t)blockIdx.y * rows;               // segment (second stacked tensor), see ln_bwd_kernel
   if (blockIdx.y == 1) gamma = gamma1;
@@ -341,7 +349,14 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const void* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = rs[r] * (g[i][j] - s1 - xh[i][j] * s2) + ad[r][i][j];
             st8t<XF32>(dx, row * C + c0[i], o);
-            if (dx16) st8t<false>(dx16, row * C + c0[i], o);   // the copy the next GEMMs read (they round to bf16 anyway)
+            if (dx16.p) {                                        // the copy the next GEMMs read (see ln_bwd_kernel)
+              if (dx16.scale) {
+                const float sc = dx16.scale[(row0 + r) / dx16.rps];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] *= sc;
+              }
+              st8t<false>(dx16.p, row * C + c0[i], o);
+            }
           }
       }
     }
@@ -488,7 +503,7 @@ static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const voi
 template <int NV, int R>
 static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
                           const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C,
-                          const float* g1 = nullptr, bf16* dx16 = nullptr) {
+                          const float* g1 = nullptr, Copy16 dx16 = Copy16{}) {
   if (df && xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   else if (df) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, true, false>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   else if (xf) hipLaunchKernelGGL((ln_bwd_kernel<NV, R, false, true>), grid, dim3(64 * LN_BWD_WAVES), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
@@ -505,7 +520,7 @@ static void ln_fwd_vec_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const
 template <int GL, int NCH, int R>
 static void ln_bwd_vec_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
                               const float* mean, const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C,
-                              const float* g1, bf16* dx16) {
+                              const float* g1, Copy16 dx16) {
   if (df && xf) hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, true, true>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   else if (df) hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, true, false>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   else if (xf) hipLaunchKernelGGL((ln_bwd_vec_kernel<GL, NCH, R, false, true>), grid, dim3(512), sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
@@ -521,7 +536,7 @@ static bool ln_vec_ok(int C, std::initializer_list<const void*> ptrs) {
 static int ln_group_lanes(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
 static int64_t ln_fwd_vec_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows * ln_group_lanes(C), 256 * 2), 4096); }
 static bool ln_bwd_vec(bool df, bool xf, dim3 grid, hipStream_t st, const void* dy, const void* x, const float* g, const float* mean,
-                       const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C, const float* g1, bf16* dx16) {
+                       const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C, const float* g1, Copy16 dx16) {
   const size_t sh = (size_t)(512 / ln_group_lanes(C)) * 2 * C * sizeof(float);
   if (sh > 65536) return false;
   if (C <= 128) ln_bwd_vec_launch<16, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
@@ -565,7 +580,19 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
                                   const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
                                   void* dx_bf16, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
                                   int64_t rows, int C, hipStream_t stream) {
+  return csts_layernorm_bwd_scaled_copy(dy, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, addend, dx_bf16, nullptr, 1, dgamma,
+                                        dbeta, workspace, ws_bytes, rows, C, stream);
+}
+
+extern "C" int csts_layernorm_bwd_scaled_copy(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma,
+                                              const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
+                                              void* dx_bf16, const float* copy_row_scale, int64_t rows_per_scale,
+                                              float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int64_t rows,
+                                              int C, hipStream_t stream) {
   CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace, "null pointer");
+  CSTS_REQUIRE(copy_row_scale == nullptr || (dx_bf16 != nullptr && rows_per_scale > 0), "copy scale needs the bf16 copy and rows_per_scale > 0");
+  Copy16 c16;
+  c16.p = reinterpret_cast<bf16*>(dx_bf16); c16.scale = copy_row_scale; c16.rps = rows_per_scale > 0 ? rows_per_scale : 1;
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
   CSTS_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta: both or neither (neither = deferred second stage)");
   CSTS_REQUIRE(dgamma == nullptr || dbeta == dgamma + C, "dgamma/dbeta must be one contiguous [2*C] buffer");
@@ -577,7 +604,7 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
   if (ln_vec_ok(C, {dy, x, dx, addend, dx_bf16, gamma}) &&
-      ln_bwd_vec(df, xf, grid, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16))) {
+      ln_bwd_vec(df, xf, grid, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, c16)) {
     CSTS_LAUNCH_CHECK();
     if (dgamma != nullptr) {
       csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
@@ -585,10 +612,10 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
     }
     return 0;
   }
-  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
-  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
-  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
-  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, reinterpret_cast<bf16*>(dx_bf16));
+  if (C <= 128) ln_bwd_launch<2, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, c16);
+  else if (C <= 192) ln_bwd_launch<3, 4>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, c16);
+  else if (C <= 384) ln_bwd_launch<6, 2>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, c16);
+  else ln_bwd_launch<12, 1>(df, xf, grid, sh, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, c16);
   CSTS_LAUNCH_CHECK();
   if (dgamma != nullptr) {
     csts_reduce_rows_launch(ws, dgamma, nb, 2 * C, 1.f, stream);
@@ -613,7 +640,7 @@ extern "C" int csts_layernorm_bwd2(const void* dy, int dy_dt, const void* x, int
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
   if (ln_vec_ok(C, {dy, x, dx, gamma0, gamma1}) && ((rows * C) % 8 == 0) &&
-      ln_bwd_vec(df, xf, grid, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1, nullptr)) {
+      ln_bwd_vec(df, xf, grid, stream, dy, x, gamma0, mean, rstd, dx, nullptr, ws, rows, C, gamma1, Copy16{})) {
     CSTS_LAUNCH_CHECK();
     if (dgb0 != nullptr) {
       csts_reduce_rows_launch(ws, dgb0, nb, 2 * C, 1.f, stream);

@@ -554,7 +554,7 @@ def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: i
 BF16_GRAD_COPY = os.environ.get("CSTS_BF16_GRAD_COPY", "1") != "0"
 
 
-def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False, params=None):
+def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False, params=None, copy_scale=None):
     """dx (+ addend) and the [2*C] dgamma|dbeta buffer.  params = (gamma, beta) leaf parameters: inside a backward pass
     the second stage is then deferred and the flush assigns the two halves itself -- the returned buffer is None.
     want16: also emit a bf16 copy of dx, attached as dx._csts_bf16, for the weight/data-gradient GEMMs that read it next
@@ -565,38 +565,61 @@ def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False,
     nbytes = _lib().csts_layernorm_bwd_workspace(rows, Cc)
     ws = _ws(nbytes, x.device)
     defer = params is not None and _can_defer(*params)
-    L.check(_lib().csts_layernorm_bwd(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
-                                      _p(addend), _p(dx16), None if defer else _p(dgb), None if defer else _p(dgb, Cc), _p(ws),
-                                      ws.numel(), rows, Cc, _stream()), what)
+    if dx16 is None or copy_scale is None or rows % copy_scale[1] != 0 or copy_scale[0].numel() * copy_scale[1] != rows:
+        copy_scale = None
+    cs, rps = (copy_scale[0], copy_scale[1]) if copy_scale is not None else (None, 1)
+    L.check(_lib().csts_layernorm_bwd_scaled_copy(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
+                                                  _p(addend), _p(dx16), _p(cs), rps, None if defer else _p(dgb),
+                                                  None if defer else _p(dgb, Cc), _p(ws), ws.numel(), rows, Cc, _stream()), what)
     if defer:
         _defer(ws, dgb, nbytes // (2 * Cc * 4), 2 * Cc)
         _assign_later(params[0], dgb[:Cc])
         _assign_later(params[1], dgb[Cc:])
         dgb = None
     if dx16 is not None:
-        _attach16(dx, dx16)
+        _attach16(dx, dx16, copy_scale)
     return dx, dgb
 
 
-def _attach16(dx: torch.Tensor, dx16: torch.Tensor):
+def _scale_key(scale):
+    """Identity of a (row_scale tensor, rows_per_scale) pair: saved tensors come back as new Python objects, so the storage
+    address stands for the tensor."""
+    if scale is None:
+        return None
+    return (scale[0].data_ptr(), scale[0].numel(), int(scale[1]))
+
+
+def _attach16(dx: torch.Tensor, dx16: torch.Tensor, scale=None):
     """Remember the bf16 copy of the fp32 gradient `dx` on the tensor object, together with dx's version counter: autograd
     accumulates the gradients of a tensor with several consumers IN PLACE into the first one that arrives, which keeps
-    the Python object (and this attribute) but bumps the version -- the copy is then stale and must not be used."""
-    dx._csts_bf16 = (dx16, dx._version)
+    the Python object (and this attribute) but bumps the version -- the copy is then stale and must not be used.
+    scale = (row_scale, rows_per_scale): the copy holds dx times that per-sample scale (csts_layernorm_bwd_scaled_copy)."""
+    dx._csts_bf16 = (dx16, dx._version, _scale_key(scale))
 
 
-def _grad16(dy: torch.Tensor, compute: int):
-    """The bf16 copy of a residual-stream gradient left by the kernel that produced it (or None: no copy, or `dy` was
-    modified since the copy was made)."""
+def _grad16(dy: torch.Tensor, compute: int, scale=None):
+    """The bf16 copy of a residual-stream gradient left by the kernel that produced it (or None: no copy, `dy` was
+    modified since the copy was made, or the copy was not made with the per-sample scale the caller needs)."""
     if compute != BF16 or dy.dtype != torch.float32:
         return None
     tag = getattr(dy, "_csts_bf16", None)
     if tag is None:
         return None
-    d16, ver = tag
-    if dy._version != ver or d16.shape != dy.shape or d16.device != dy.device:
+    d16, ver, key = tag
+    if dy._version != ver or d16.shape != dy.shape or d16.device != dy.device or key != _scale_key(scale):
         return None
     return d16
+
+
+def _mark_scaled_output(y, row_scale, rows_per_scale):
+    """y = f(...) * row_scale + residual: remember the scale on the output tensor, so that the LayerNorm that reads y next can
+    leave the bf16 copy of dL/dy already multiplied by it (LayerNormFn / _ln_bwd_call)."""
+    if row_scale is not None and SCALED_GRAD_COPY:
+        y._csts_prod_scale = (row_scale, int(rows_per_scale))
+    return y
+
+
+SCALED_GRAD_COPY = os.environ.get("CSTS_SCALED_GRAD_COPY", "1") != "0"
 
 
 class LayerNormFn(Function):
@@ -621,6 +644,7 @@ class LayerNormFn(Function):
                                           eps, _stream()), "csts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.params = (gamma, beta)
+        ctx.copy_scale = getattr(x, "_csts_prod_scale", None) if passthrough else None
         ctx.set_materialize_grads(False)
         if passthrough:
             return y, x
@@ -639,7 +663,8 @@ class LayerNormFn(Function):
             if dpass.dtype != x.dtype:
                 dpass = dpass.to(x.dtype)
         dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd",
-                               want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16), params=ctx.params)
+                               want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16), params=ctx.params,
+                               copy_scale=ctx.copy_scale)
         if dgb is None:                     # finished and assigned by the end-of-backward flush
             return dx, None, None, None, None, None
         return dx, dgb[:Cc], dgb[Cc:], None, None, None
@@ -681,12 +706,15 @@ class LinearFn(Function):
     def backward(ctx, dy):
         x, W, row_scale = ctx.saved_tensors
         M, N, K, rps, compute, has_b, has_res, res_dtype = ctx.meta
-        d16 = _grad16(dy, compute) if dy.is_contiguous() else None
+        sc = (row_scale, rps) if row_scale is not None else None
+        d16 = _grad16(dy, compute, sc) if dy.is_contiguous() else None     # with drop-path: the copy pre-multiplied by it
         dy = dy.contiguous()
-        if row_scale is not None:          # drop-path: the scaled copy goes straight to bf16 when the GEMMs run in bf16
+        if d16 is not None:
+            dys = d16
+        elif row_scale is not None:        # drop-path: the scaled copy goes straight to bf16 when the GEMMs run in bf16
             dys = scale_rows(dy, row_scale, rps, M, N, out_dt=BF16 if (compute == BF16 and BF16_GRAD_COPY) else None)
         else:
-            dys = d16 if d16 is not None else dy
+            dys = dy
         dx = dW = db = dres = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -742,7 +770,8 @@ class _TransposeSet:
 
 
 def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32, w16=None, w16t=None):
-    return LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16, w16t)
+    y = LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16, w16t)
+    return _mark_scaled_output(y, row_scale if residual is not None else None, rows_per_scale)
 
 
 class MlpFn(Function):
@@ -779,12 +808,15 @@ class MlpFn(Function):
     def backward(ctx, dy):
         x, W1, W2, h, g, row_scale = ctx.saved_tensors
         M, K, Hd, N, rps, compute, has_res = ctx.meta
-        d16 = _grad16(dy, compute) if dy.is_contiguous() else None
+        sc = (row_scale, rps) if row_scale is not None else None
+        d16 = _grad16(dy, compute, sc) if dy.is_contiguous() else None     # with drop-path: the copy pre-multiplied by it
         dy = dy.contiguous()
-        if row_scale is not None:
+        if d16 is not None:
+            dys = d16
+        elif row_scale is not None:
             dys = scale_rows(dy, row_scale, rps, M, N, out_dt=BF16 if (compute == BF16 and BF16_GRAD_COPY) else None)
         else:
-            dys = d16 if d16 is not None else dy
+            dys = dy
         P1, pb1, P2, pb2 = ctx.params
         dW2, db2 = _wgrad(dys, g, M, N, Hd, compute, want_bias=True, params=(P2, pb2))
         dh = torch.empty_like(h)
@@ -799,8 +831,9 @@ class MlpFn(Function):
 
 def mlp(x, W1, b1, W2, b2, *, residual=None, row_scale=None, rows_per_scale=1, act_dt=F32, out_dt=F32, compute=F32,
         w16_1=None, w16_2=None, w16t_1=None, w16t_2=None):
-    return MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute, w16_1, w16_2,
-                       w16t_1, w16t_2)
+    y = MlpFn.apply(x, W1, b1, W2, b2, residual, row_scale, rows_per_scale, act_dt, out_dt, compute, w16_1, w16_2,
+                    w16t_1, w16t_2)
+    return _mark_scaled_output(y, row_scale if residual is not None else None, rows_per_scale)
 
 
 # ----------------------------------------------------------------------------------------- attention inner
