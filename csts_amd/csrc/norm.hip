@@ -83,11 +83,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
   }
 }
 
-// optional bf16 copy of dx (+ per-sample scale applied to the copy only: row r uses scale[r / rps])
+// optional extras of the backward kernels: a bf16 copy of dx (+ per-sample scale applied to the copy only: row r uses
+// scale[r / rps]) and a second incoming gradient (LayerNorm output with two consumers)
 struct Copy16 {
   bf16* p = nullptr;
   const float* scale = nullptr;
   int64_t rps = 1;
+  const void* dy2 = nullptr;     // a second incoming gradient of the same shape / dtype as dy: the kernel reads dy + dy2
 };
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // per-wave partial dgamma/dbeta are summed through LDS and written to ws[block][2*C]
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
       for (int j = 0; j < NV; ++j) {
         const int64_t i = row * C + min(lane + 64 * j, C - 1);
         d[r][j] = ldt<DYF32>(dy, i);
+        if (dx16.dy2) d[r][j] += ldt<DYF32>(dx16.dy2, i);    // wave-uniform test
         xv[r][j] = ldt<XF32>(x, i);
         ad[r][j] = addend ? ldt<XF32>(addend, i) : 0.f;     // residual-branch gradient folded into dx (wave-uniform test)
       }
@@ -311,6 +314,12 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const void* __restrict_
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         ld8t<DYF32>(dy, row * C + c0[i], d[r][i]);
+        if (dx16.dy2) {
+          float d2[8];
+          ld8t<DYF32>(dx16.dy2, row * C + c0[i], d2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[r][i][j] += d2[j];
+        }
         ld8t<XF32>(x, row * C + c0[i], xv[r][i]);
         if (addend) ld8t<XF32>(addend, row * C + c0[i], ad[r][i]);
         else {
@@ -580,19 +589,20 @@ extern "C" int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int 
                                   const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
                                   void* dx_bf16, float* dgamma, float* dbeta, void* workspace, size_t ws_bytes,
                                   int64_t rows, int C, hipStream_t stream) {
-  return csts_layernorm_bwd_scaled_copy(dy, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, addend, dx_bf16, nullptr, 1, dgamma,
-                                        dbeta, workspace, ws_bytes, rows, C, stream);
+  return csts_layernorm_bwd_ex(dy, nullptr, dy_dt, x, x_dt, gamma, mean, rstd, dx, dx_dt, addend, dx_bf16, nullptr, 1, dgamma,
+                               dbeta, workspace, ws_bytes, rows, C, stream);
 }
 
-extern "C" int csts_layernorm_bwd_scaled_copy(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma,
-                                              const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
-                                              void* dx_bf16, const float* copy_row_scale, int64_t rows_per_scale,
-                                              float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int64_t rows,
-                                              int C, hipStream_t stream) {
+extern "C" int csts_layernorm_bwd_ex(const void* dy, const void* dy2, int dy_dt, const void* x, int x_dt, const float* gamma,
+                                     const float* mean, const float* rstd, void* dx, int dx_dt, const void* addend,
+                                     void* dx_bf16, const float* copy_row_scale, int64_t rows_per_scale,
+                                     float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int64_t rows,
+                                     int C, hipStream_t stream) {
   CSTS_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace, "null pointer");
   CSTS_REQUIRE(copy_row_scale == nullptr || (dx_bf16 != nullptr && rows_per_scale > 0), "copy scale needs the bf16 copy and rows_per_scale > 0");
   Copy16 c16;
   c16.p = reinterpret_cast<bf16*>(dx_bf16); c16.scale = copy_row_scale; c16.rps = rows_per_scale > 0 ? rows_per_scale : 1;
+  c16.dy2 = dy2;
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
   CSTS_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "dgamma and dbeta: both or neither (neither = deferred second stage)");
   CSTS_REQUIRE(dgamma == nullptr || dbeta == dgamma + C, "dgamma/dbeta must be one contiguous [2*C] buffer");
@@ -603,7 +613,7 @@ extern "C" int csts_layernorm_bwd_scaled_copy(const void* dy, int dy_dt, const v
   const size_t sh = (size_t)LN_BWD_WAVES * 2 * C * sizeof(float);
   float* ws = reinterpret_cast<float*>(workspace);
   const bool df = dy_dt == CSTS_F32, xf = x_dt == CSTS_F32;
-  if (ln_vec_ok(C, {dy, x, dx, addend, dx_bf16, gamma}) &&
+  if (ln_vec_ok(C, {dy, dy2, x, dx, addend, dx_bf16, gamma}) &&
       ln_bwd_vec(df, xf, grid, stream, dy, x, gamma, mean, rstd, dx, addend, ws, rows, C, nullptr, c16)) {
     CSTS_LAUNCH_CHECK();
     if (dgamma != nullptr) {

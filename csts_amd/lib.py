@@ -114,7 +114,7 @@ SYMBOLS = {
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, sz, i64, _I, vp]),
-    "csts_layernorm_bwd_scaled_copy": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, i64, vp, vp, vp, sz, i64, _I, vp]),
+    "csts_layernorm_bwd_ex": (_I, [vp, vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, i64, vp, vp, vp, sz, i64, _I, vp]),
     "csts_reduce_rows_batched": (_I, [vp, _I, i64, vp]),
     "csts_reduce_rows_wide": (_I, [vp, _I, i64, vp]),
     "csts_layernorm_bwd2": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, vp, _I, vp, vp, vp, sz, i64, _I, vp]),

@@ -185,11 +185,13 @@ class Block(nn.Module):
         s_attn, s_mlp = self._drop_scales(B, x.device, keep_masks)
         x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x_res, row_scale=s_attn, rows_per_scale=Nq, out_dt=L.F32,
                         compute=rt.compute, w16=w16(a.proj), w16t=w16t(a.proj))
-        xn2, x1 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt, passthrough=True)
-        base = x1
-        if self.dim != self.dim_out:
-            base = ops.linear(xn2, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj),
+        if self.dim != self.dim_out:        # norm2's output feeds fc1 AND the skip projection (attention.py:243-246)
+            xn2, xn2b, x1 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt, passthrough=True, fanout=True)
+            base = ops.linear(xn2b, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj),
                               w16t=w16t(self.proj))
+        else:
+            xn2, x1 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt, passthrough=True)
+            base = x1
         out = ops.mlp(xn2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=base,
                       row_scale=s_mlp, rows_per_scale=Nq, act_dt=rt.act_dt, out_dt=L.F32, compute=rt.compute,
                       w16_1=w16(self.mlp.fc1), w16_2=w16(self.mlp.fc2), w16t_1=w16t(self.mlp.fc1), w16t_2=w16t(self.mlp.fc2))

@@ -554,7 +554,7 @@ def _wgrad(dY: torch.Tensor, X: torch.Tensor, M: int, N: int, K: int, compute: i
 BF16_GRAD_COPY = os.environ.get("CSTS_BF16_GRAD_COPY", "1") != "0"
 
 
-def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False, params=None, copy_scale=None):
+def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False, params=None, copy_scale=None, dy2=None):
     """dx (+ addend) and the [2*C] dgamma|dbeta buffer.  params = (gamma, beta) leaf parameters: inside a backward pass
     the second stage is then deferred and the flush assigns the two halves itself -- the returned buffer is None.
     want16: also emit a bf16 copy of dx, attached as dx._csts_bf16, for the weight/data-gradient GEMMs that read it next
@@ -568,9 +568,9 @@ def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False,
     if dx16 is None or copy_scale is None or rows % copy_scale[1] != 0 or copy_scale[0].numel() * copy_scale[1] != rows:
         copy_scale = None
     cs, rps = (copy_scale[0], copy_scale[1]) if copy_scale is not None else (None, 1)
-    L.check(_lib().csts_layernorm_bwd_scaled_copy(_p(dy), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
-                                                  _p(addend), _p(dx16), _p(cs), rps, None if defer else _p(dgb),
-                                                  None if defer else _p(dgb, Cc), _p(ws), ws.numel(), rows, Cc, _stream()), what)
+    L.check(_lib().csts_layernorm_bwd_ex(_p(dy), _p(dy2), _dt(dy), _p(x), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _dt(dx),
+                                         _p(addend), _p(dx16), _p(cs), rps, None if defer else _p(dgb),
+                                         None if defer else _p(dgb, Cc), _p(ws), ws.numel(), rows, Cc, _stream()), what)
     if defer:
         _defer(ws, dgb, nbytes // (2 * Cc * 4), 2 * Cc)
         _assign_later(params[0], dgb[:Cc])
@@ -593,7 +593,7 @@ def _attach16(dx: torch.Tensor, dx16: torch.Tensor, scale=None):
     """Remember the bf16 copy of the fp32 gradient `dx` on the tensor object, together with dx's version counter: autograd
     accumulates the gradients of a tensor with several consumers IN PLACE into the first one that arrives, which keeps
     the Python object (and this attribute) but bumps the version -- the copy is then stale and must not be used.
-    scale = (row_scale, rows_per_scale): the copy holds dx times that per-sample scale (csts_layernorm_bwd_scaled_copy)."""
+    scale = (row_scale, rows_per_scale): the copy holds dx times that per-sample scale (csts_layernorm_bwd_ex)."""
     dx._csts_bf16 = (dx16, dx._version, _scale_key(scale))
 
 
@@ -630,7 +630,7 @@ class LayerNormFn(Function):
     dx = LN'(d_xn) + d_residual in one pass instead of leaving the sum to a separate autograd add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, out_dt: int, passthrough: bool):
+    def forward(ctx, x, gamma, beta, eps: float, out_dt: int, passthrough: bool, fanout: bool = False):
         _need_gpu(x, gamma, beta)
         if passthrough and not x.is_contiguous():
             raise L.CstsError("layer_norm(passthrough=True) needs a contiguous input")
@@ -646,16 +646,33 @@ class LayerNormFn(Function):
         ctx.params = (gamma, beta)
         ctx.copy_scale = getattr(x, "_csts_prod_scale", None) if passthrough else None
         ctx.set_materialize_grads(False)
+        ctx.fanout = bool(fanout)
+        if fanout:                          # two aliases of y, one per consumer: backward receives both gradients
+            if not passthrough:
+                raise L.CstsError("layer_norm(fanout=True) comes with passthrough=True")
+            return y, y.view_as(y), x
         if passthrough:
             return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy, dpass=None):
+    def backward(ctx, dy, *rest):
         x, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = None
+        if ctx.fanout:
+            dy2, dpass = rest
+            if dy is None:
+                dy, dy2 = dy2, None
+        else:
+            dpass = rest[0] if rest else None
+        nret = 7
         if dy is None:                      # only the residual branch carried a gradient
-            return dpass, None, None, None, None, None
+            return (dpass,) + (None,) * (nret - 1)
         dy = dy.contiguous()
+        if dy2 is not None:
+            dy2 = dy2.contiguous()
+            if dy2.dtype != dy.dtype or dy2.shape != dy.shape:
+                dy, dy2 = dy + dy2, None
         Cc = x.shape[-1]
         rows = x.numel() // Cc
         if dpass is not None:
@@ -664,15 +681,17 @@ class LayerNormFn(Function):
                 dpass = dpass.to(x.dtype)
         dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd",
                                want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16), params=ctx.params,
-                               copy_scale=ctx.copy_scale)
+                               copy_scale=ctx.copy_scale, dy2=dy2)
         if dgb is None:                     # finished and assigned by the end-of-backward flush
-            return dx, None, None, None, None, None
-        return dx, dgb[:Cc], dgb[Cc:], None, None, None
+            return (dx,) + (None,) * (nret - 1)
+        return (dx, dgb[:Cc], dgb[Cc:]) + (None,) * (nret - 3)
 
 
-def layer_norm(x, gamma, beta, eps, out_dt, passthrough: bool = False):
-    """passthrough=False: y.  passthrough=True: (y, x_alias) -- use x_alias wherever x is used afterwards."""
-    return LayerNormFn.apply(x, gamma, beta, eps, out_dt, passthrough)
+def layer_norm(x, gamma, beta, eps, out_dt, passthrough: bool = False, fanout: bool = False):
+    """passthrough=False: y.  passthrough=True: (y, x_alias) -- use x_alias wherever x is used afterwards.
+    fanout=True (with passthrough): (y_a, y_b, x_alias) for a LayerNorm output with TWO consumers -- the backward kernel reads
+    both incoming gradients itself (csts_layernorm_bwd_ex) instead of autograd adding them first."""
+    return LayerNormFn.apply(x, gamma, beta, eps, out_dt, passthrough, fanout)
 
 
 # ----------------------------------------------------------------------------------------- Linear

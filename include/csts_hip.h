@@ -95,13 +95,16 @@ size_t csts_layernorm_bwd_workspace(int64_t rows, int C);
 int csts_layernorm_bwd(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
                        const float* rstd, void* dx, int dx_dt, const void* addend, void* dx_bf16, float* dgamma,
                        float* dbeta, void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
-/* same, with the bf16 copy multiplied by a per-sample scale (row r: copy_row_scale[r / rows_per_scale]; dx itself is not
- * scaled): the stochastic-depth factor of the residual branch that consumes this gradient next (drop_path, common.py:46-59;
- * x + drop_path(f(x)) at attention.py:242,247) -- that branch then needs no pass of its own over dx.  NULL scale = plain copy. */
-int csts_layernorm_bwd_scaled_copy(const void* dy, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
-                                   const float* rstd, void* dx, int dx_dt, const void* addend, void* dx_bf16,
-                                   const float* copy_row_scale, int64_t rows_per_scale, float* dgamma, float* dbeta,
-                                   void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
+/* same with two extras.  dy2 (optional, dtype and shape of dy): the LayerNorm output had a second consumer (a block that
+ * changes the channel count feeds norm2's output to fc1 AND to its skip projection, attention.py:243-246) -- the kernel reads
+ * dy + dy2 instead of autograd adding the two first.  copy_row_scale (optional): the bf16 copy is multiplied by a per-sample
+ * scale (row r: copy_row_scale[r / rows_per_scale]; dx itself is not scaled) -- the stochastic-depth factor of the residual
+ * branch that consumes this gradient next (drop_path, common.py:46-59; x + drop_path(f(x)) at attention.py:242,247), which then
+ * needs no pass of its own over dx. */
+int csts_layernorm_bwd_ex(const void* dy, const void* dy2, int dy_dt, const void* x, int x_dt, const float* gamma, const float* mean,
+                          const float* rstd, void* dx, int dx_dt, const void* addend, void* dx_bf16,
+                          const float* copy_row_scale, int64_t rows_per_scale, float* dgamma, float* dbeta,
+                          void* workspace, size_t ws_bytes, int64_t rows, int C, hipStream_t stream);
 /* two stacked tensors of `rows` rows each (dy, x, dx, mean, rstd contiguous: [2][rows]...) with their own gammas in one
  * launch (norm_k and norm_v of one attention); dgb0/dgb1 = [2*C] dgamma|dbeta of each, or both NULL to defer the second
  * stage: workspace = 2 x csts_layernorm_bwd_workspace(rows, C), tensor i's partial rows at offset i * that size */
