@@ -80,6 +80,11 @@ class FusedAdamW:
         self._grads_dev = torch.zeros(len(params), dtype=torch.int64, device=self.device)
         self.n_total = n_total
 
+    def refill_capture_pool(self):
+        """Top the pinned capture buffers up again (outside a capture): one process may capture step() any number of times."""
+        while len(self._capture_pool) < 4:
+            self._capture_pool.append(torch.zeros(len(self.params), dtype=torch.int64).pin_memory())
+
     # ------------------------------------------------------------------ torch.optim-like surface
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -108,7 +113,7 @@ class FusedAdamW:
             ptrs.append(g.data_ptr())
         if torch.cuda.is_current_stream_capturing():
             if not self._capture_pool:
-                raise L.CstsError("FusedAdamW: more than 4 graph captures of step(); build a new optimizer")
+                raise L.CstsError("FusedAdamW: out of pinned capture buffers (call refill_capture_pool() outside the capture)")
             host = self._capture_pool.pop()      # pre-allocated: no host allocation while a capture is open
             host.copy_(torch.tensor(ptrs, dtype=torch.int64))
             self._captured_hosts.append(host)

@@ -244,6 +244,8 @@ class GraphedTrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             ops.refill_capture_pools()
+            if hasattr(optimizer, "refill_capture_pool"):
+                optimizer.refill_capture_pool()
             self.graph = torch.cuda.CUDAGraph()
             # thread_local: a process group's watchdog thread may poll events while this capture is open (see SegmentedTrainStep)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -347,6 +349,8 @@ class SegmentedTrainStep:
             if self.dist:
                 time.sleep(0.5)          # the watchdog drops the (finished) warm-up collectives from its list
             ops.refill_capture_pools()
+            if hasattr(optimizer, "refill_capture_pool"):
+                optimizer.refill_capture_pool()
             self._chain(capture=True)
             torch.cuda.synchronize()
         finally:
