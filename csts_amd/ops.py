@@ -186,6 +186,33 @@ def _defer(ws: torch.Tensor, out: torch.Tensor, nrows: int, ncols: int):
     _deferred.append((ws, out, int(nrows), int(ncols)))
 
 
+# Gradient targets (csts_amd.train.SegmentedTrainStep, data-parallel chain): parameter storage address -> a view of a flat
+# all-reduce bucket shaped like the parameter.  A producer that allocates a parameter gradient (queued Linear weight gradients,
+# the fusion convs' TN GEMM) writes it THERE, so the bucket needs no copy afterwards.  One use per backward pass: a second
+# gradient for the same parameter (a module applied twice) gets an ordinary buffer and is accumulated as before.
+_grad_targets = {}
+_grad_targets_used = set()
+
+
+def set_grad_targets(pairs=None):
+    _grad_targets.clear()
+    _grad_targets_used.clear()
+    for p_, v_ in (pairs or []):
+        if v_.dtype == torch.float32 and v_.is_contiguous() and v_.numel() == p_.numel():
+            _grad_targets[p_.data_ptr()] = v_
+
+
+def _grad_buffer(param_like, shape, device):
+    """fp32 buffer for the gradient of `param_like` (a Parameter or a saved alias of it): its bucket view if one is registered,
+    unused in this backward pass and the parameter has no gradient yet; else a fresh tensor."""
+    key = param_like.data_ptr()
+    v = _grad_targets.get(key)
+    if v is not None and key not in _grad_targets_used and getattr(param_like, "grad", None) is None and v.device == device:
+        _grad_targets_used.add(key)
+        return v.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
 def _assign_later(param, grad):
     if param is not None and grad is not None:
         _assign.append((param, grad))
@@ -199,6 +226,11 @@ def _hand_over():
         else:
             p_.grad.add_(g_)
     _assign.clear()
+    _grad_targets_used.clear()
+
+
+def _targets_reset():
+    _grad_targets_used.clear()
 
 
 def flush_deferred():
@@ -286,8 +318,8 @@ def queue_wgrad(dY, X, tokens, N, K, Wp, bp):
         return False
     if Wp is None or Wp.dtype != torch.float32 or tuple(Wp.shape) != (N, K) or not _can_defer(Wp, bp):
         return False
-    dW = torch.empty(N, K, dtype=torch.float32, device=dY.device)
-    db = torch.empty(N, dtype=torch.float32, device=dY.device) if bp is not None else None
+    dW = _grad_buffer(Wp, (N, K), dY.device)
+    db = _grad_buffer(bp, (N,), dY.device) if bp is not None else None
     _wgq.append((dY, X, dW, db, tokens, N, K))
     _assign_later(Wp, dW)
     _assign_later(bp, db)
@@ -1373,7 +1405,7 @@ class FusionConvFn(Function):
         BT, K = B * T, Cc * HW
         dy = dy.contiguous()
         Wv = W.reshape(Cout, K)
-        dW = torch.empty(Cout, K, dtype=torch.float32, device=dy.device)
+        dW = _grad_buffer(W, (Cout, K), dy.device)        # the data-parallel chain: straight into its all-reduce bucket
         gemm(L.GEMM_TN, dy, 0, Cout, A, 0, K, dW, K, Cout, K, BT, compute=compute)
         db = colsum(dy, 1, BT, Cout)
         dx = None

@@ -423,6 +423,26 @@ class SegmentedTrainStep:
         return self._chain(capture=False)
 
     def _chain(self, capture):
+        from . import ops
+        if self.dist and self.use_graphs:
+            # parameter gradients are produced straight inside the flat buckets where the producer allocates them (ops._grad_buffer)
+            ops.set_grad_targets([(p, v) for k, ps in enumerate(self.buckets) for p, v in zip(ps, self.flat[k][1])])
+        try:
+            return self._chain_body(capture)
+        finally:
+            ops.set_grad_targets(None)
+
+    def _copy_into_bucket(self, k):
+        """Gradients of bucket k that were not produced in place -> their slices of the flat buffer (one multi-tensor copy)."""
+        dst, src = [], []
+        for p, v in zip(self.buckets[k], self.flat[k][1]):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def _chain_body(self, capture):
         core, cfg = self.core, self.cfg
         with_embed = cfg.MODEL.LOSS_FUNC == "kldiv+egonce"
         if hasattr(self.opt, "params"):
@@ -469,7 +489,7 @@ class SegmentedTrainStep:
         def bwd_head():
             torch.autograd.backward(self.outs, self.douts, inputs=self.head_params + cut["in"])
             if self.dist:
-                torch._foreach_copy_(self.flat[0][1], [p.grad for p in self.head_params])
+                self._copy_into_bucket(0)
 
         self._segment("bwd_head", bwd_head, capture)
         works = [self._all_reduce(0)] if coll else []
@@ -480,7 +500,7 @@ class SegmentedTrainStep:
             late = [(o, i.grad) for o, i in zip(cut["out"], cut["in"]) if not self._from_early(o, cut2)]
             torch.autograd.backward([o for o, _ in late], [g for _, g in late], inputs=self.trunk_params + cut2.get("in", []))
             if self.dist:
-                torch._foreach_copy_(self.flat[1][1], [p.grad for p in self.trunk_params])
+                self._copy_into_bucket(1)
 
         self._segment("bwd_trunk", bwd_trunk, capture)
         if coll:
@@ -492,7 +512,7 @@ class SegmentedTrainStep:
                 grads = [t.grad for t in cut2["in"]] + [g for _, g in early]
                 torch.autograd.backward(roots, grads, inputs=self.early_params)
                 if self.dist:
-                    torch._foreach_copy_(self.flat[2][1], [p.grad for p in self.early_params])
+                    self._copy_into_bucket(2)
 
             self._segment("bwd_trunk_early", bwd_early, capture)
             if coll:
