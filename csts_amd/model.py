@@ -334,16 +334,22 @@ class CSTS(nn.Module):
             lins = [m for blk in self.modules() if isinstance(blk, Block)
                     for m in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2, getattr(blk, "proj", None)) if m is not None]
             self._w16_lins = lins
-        stale = [l for l in lins if getattr(l, "_w16", None) is None or l._w16.device != l.weight.device]
+            # + the three (1,8,8) fusion convs (37.7 M parameters each): their skinny GEMMs are pure weight streams, and a
+            # bf16 shadow halves the bytes of the forward and of the data gradient (same values: the GEMM rounds the fp32
+            # weights to bf16 while staging anyway).  No [in][out] twins for these.
+            self._w16_all = lins + [m for m in (getattr(self, n, None) for n in ("vision_pool", "audio_pool", "audio_pool2"))
+                                    if m is not None]
+        shadowed = self._w16_all
+        stale = [l for l in shadowed if getattr(l, "_w16", None) is None or l._w16.device != l.weight.device]
         for l in stale:
             l._w16 = torch.empty(l.weight.shape, dtype=torch.bfloat16, device=l.weight.device)
             l._w16_ver = -1
         # With csts_amd.optim.FusedAdamW the optimizer kernel itself rewrites the shadows (w16_external): only an
         # out-of-band weight change (load_state_dict, manual edit: bumps _version) needs a refresh here.
-        if (self.training and not getattr(self, "w16_external", False)) or any(l._w16_ver != l.weight._version for l in lins):
+        if (self.training and not getattr(self, "w16_external", False)) or any(l._w16_ver != l.weight._version for l in shadowed):
             with torch.no_grad():
-                torch._foreach_copy_([l._w16 for l in lins], [l.weight.detach() for l in lins])
-            for l in lins:
+                torch._foreach_copy_([l._w16 for l in shadowed], [l.weight.detach() for l in shadowed])
+            for l in shadowed:
                 l._w16_ver = l.weight._version
         # [in][out] twins for the data-gradient GEMMs: one multi-tensor transpose per forward that records a backward graph
         # (refreshed in the same forward whose backward reads them: never stale)
@@ -486,7 +492,9 @@ class CSTS(nn.Module):
         B, Nv, Cc = xt.shape
         Tn, HW = thw[0], thw[1] * thw[2]
         HWa = thw_a[1] * thw_a[2]
-        y_sp = ops.fusion_conv(yt, self.audio_pool.weight, self.audio_pool.bias, thw_a[0], HWa, rt.act_dt, rt.compute)
+        c16 = lambda m: getattr(m, "_w16", None) if rt.compute == L.BF16 else None     # bf16 shadow (CSTS._refresh_w16)
+        y_sp = ops.fusion_conv(yt, self.audio_pool.weight, self.audio_pool.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
+                               w16=c16(self.audio_pool))
         av_sp = torch.cat([xt, y_sp], dim=1)
         av_sp, _, sp_extra = self.spatial_fusion(av_sp, thw, want_attn=return_spatial_attn,
                                                  spatial_audio_attn=self.spatial_audio_attn)
@@ -495,8 +503,10 @@ class CSTS(nn.Module):
         x_t = xt
         if self.spatial_audio_attn:                             # :438-440
             x_t = ops.row_weight(xt, sp_extra[1])
-        x_tmp = ops.fusion_conv(x_t, self.vision_pool.weight, self.vision_pool.bias, Tn, HW, rt.act_dt, rt.compute)
-        y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute)
+        x_tmp = ops.fusion_conv(x_t, self.vision_pool.weight, self.vision_pool.bias, Tn, HW, rt.act_dt, rt.compute,
+                                w16=c16(self.vision_pool))
+        y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
+                                w16=c16(self.audio_pool2))
         av_t = torch.cat([x_tmp, y_tmp], dim=1)
         av_t, _, t_extra = self.temporal_fusion(av_t, (2, 2, 2), want_attn=return_temporal_attn)
         # ---- re-weight (:454-461)

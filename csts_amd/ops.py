@@ -1381,7 +1381,7 @@ class FusionConvFn(Function):
     that streams the 37.7 M-parameter weight once, in its native (Cout, Cin*H*W) layout."""
 
     @staticmethod
-    def forward(ctx, x, W, b, T: int, HW: int, act_dt: int, compute: int):
+    def forward(ctx, x, W, b, T: int, HW: int, act_dt: int, compute: int, w16=None):
         _need_gpu(x, W)
         x = x.contiguous()
         B, N, Cc = x.shape
@@ -1391,20 +1391,21 @@ class FusionConvFn(Function):
         A = torch.empty(BT, K, dtype=torch_dtype(act_dt), device=x.device)
         L.check(_lib().csts_transpose_batched(_p(x), _dt(x), _p(A), act_dt, BT, HW, Cc, _stream()), "csts_transpose_batched")
         y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
-        Wv = W.reshape(Cout, K)
+        Wop = w16 if (w16 is not None and compute == BF16 and w16.numel() == W.numel()) else W     # bf16 shadow: half the stream
+        Wv = Wop.reshape(Cout, K)
         split = max(1, min(128, K // 256))
         gemm(L.GEMM_NT, A, 0, K, Wv, 0, K, y, Cout, BT, Cout, K, compute=compute, bias=b, split_k=split)
-        ctx.save_for_backward(A, W)
+        ctx.save_for_backward(A, W, Wop)
         ctx.meta = (B, T, HW, Cc, Cout, compute, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        A, W = ctx.saved_tensors
+        A, W, Wop = ctx.saved_tensors
         B, T, HW, Cc, Cout, compute, xdtype = ctx.meta
         BT, K = B * T, Cc * HW
         dy = dy.contiguous()
-        Wv = W.reshape(Cout, K)
+        Wv = Wop.reshape(Cout, K)
         dW = _grad_buffer(W, (Cout, K), dy.device)        # the data-parallel chain: straight into its all-reduce bucket
         gemm(L.GEMM_TN, dy, 0, Cout, A, 0, K, dW, K, Cout, K, BT, compute=compute)
         db = colsum(dy, 1, BT, Cout)
@@ -1415,11 +1416,11 @@ class FusionConvFn(Function):
             dx = torch.empty(B, T * HW, Cc, dtype=xdtype, device=dy.device)
             L.check(_lib().csts_transpose_batched(_p(dA), _dt(dA), _p(dx), _dt(dx), BT, Cc, HW, _stream()),
                     "csts_transpose_batched(bwd)")
-        return dx, dW.view(W.shape), db, None, None, None, None
+        return dx, dW.view(W.shape), db, None, None, None, None, None
 
 
-def fusion_conv(x, W, b, T, HW, act_dt, compute):
-    return FusionConvFn.apply(x, W, b, T, HW, act_dt, compute)
+def fusion_conv(x, W, b, T, HW, act_dt, compute, w16=None):
+    return FusionConvFn.apply(x, W, b, T, HW, act_dt, compute, w16)
 
 
 # ----------------------------------------------------------------------------------------- glue

@@ -75,7 +75,7 @@ def construct_optimizer(model, cfg, capturable: bool = False, device_fused: bool
         shadows = {}
         if hasattr(core, "_refresh_w16"):
             core._refresh_w16()
-            shadows = {id(l.weight): l._w16 for l in getattr(core, "_w16_lins", [])}
+            shadows = {id(l.weight): l._w16 for l in (getattr(core, "_w16_all", None) or getattr(core, "_w16_lins", []))}
             core.w16_external = True
         return FusedAdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, max_grad_norm=float(cfg.SOLVER.CLIP_GRAD_L2NORM or 0.0),
                           shadows=shadows)
