@@ -522,7 +522,7 @@ class CSTS(nn.Module):
                 feat = ops.add(feat, inter[-1 - i][0])
         # ---- head (:476-481)
         en, en_thw = inter[0]
-        logits = ops.classifier_head(feat, en, self.classifier.weight, self.classifier.bias, en_thw)
+        logits = ops.classifier_head(feat, en, self.classifier.weight, self.classifier.bias, en_thw, rt.compute)
 
         if not return_embed and not return_spatial_attn and not return_temporal_attn:
             return logits

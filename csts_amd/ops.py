@@ -1546,8 +1546,9 @@ class ClassifierFn(Function):
     (custom_multimodal_builder.py:476-481)."""
 
     @staticmethod
-    def forward(ctx, feat, en_feat, w, b, thw_en):
+    def forward(ctx, feat, en_feat, w, b, thw_en, compute: int = F32):
         _need_gpu(feat, en_feat)
+        ctx.compute = compute
         feat = feat.contiguous()
         en_feat = en_feat.contiguous()
         B, N2, Cc = feat.shape
@@ -1572,15 +1573,21 @@ class ClassifierFn(Function):
         M = B * N2
         dz = torch.empty_like(z)
         L.check(_lib().csts_rowdot_dx(_p(dl), _p(wf), _p(dz), _dt(dz), M, Cc, _stream()), "csts_rowdot_dx")
+        if ctx.compute == BF16 and BF16_GRAD_COPY and dz.dtype == torch.float32:
+            # the last decoder block has no drop-path and nothing else would give its GEMMs a bf16 copy of this gradient:
+            # without one its two data-gradient GEMMs and its weight gradients stream the fp32 tensor (M = 262 k rows)
+            dz16 = torch.empty(dz.shape, dtype=torch.bfloat16, device=dz.device)
+            L.check(_lib().csts_rowdot_dx(_p(dl), _p(wf), _p(dz16), BF16, M, Cc, _stream()), "csts_rowdot_dx(bf16)")
+            _attach16(dz, dz16)
         dw = colsum(z, 1, M, Cc, row_weight=dl).view(wshape)
         db = colsum(dl, 1, M, 1)
         den = torch.empty(enshape, dtype=endtype, device=dl.device)
         L.check(_lib().csts_trilinear_bwd(C.byref(ctx.g), _p(dz), _dt(dz), _p(den), _dt(den), _stream()), "csts_trilinear_bwd(head)")
-        return dz, den, dw, db, None
+        return dz, den, dw, db, None, None
 
 
-def classifier_head(feat, en_feat, w, b, thw_en):
-    return ClassifierFn.apply(feat, en_feat, w, b, list(thw_en))
+def classifier_head(feat, en_feat, w, b, thw_en, compute: int = F32):
+    return ClassifierFn.apply(feat, en_feat, w, b, list(thw_en), compute)
 
 
 class FrameSoftmaxFn(Function):
