@@ -1085,6 +1085,60 @@ void launch(const Params& p, int compute, dim3 grid, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false>), grid, dim3(NT_), 0, s, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- tiny problems
+// fp32 GEMMs with a handful of outputs or a handful of reduction steps (the EgoNCE path: 256-d projections of B = 4 token
+// means, their weight / data gradients, the B x B similarity matrix -- losses.py:26-56, custom_multimodal_builder.py:483-497)
+// cost 16-41 us each through the tiled MFMA kernel (LDS staging, 64 x 128 tiles, split-K slabs + a finishing pass for
+// ~1 k outputs).  Here: THREAD mode (K <= 16: one thread per output, K FMAs) or WAVE mode (one wave per output, lanes stride
+// over K, fixed-order butterfly reduction).  Plain fp32 FMAs in a fixed order: reproducible run to run; bias only.
+template <int LAYOUT>
+__device__ __forceinline__ float tiny_a(const float* A, int64_t lda, int64_t m, int64_t k) {
+  return LAYOUT == CSTS_GEMM_TN ? A[k * lda + m] : A[m * lda + k];
+}
+template <int LAYOUT>
+__device__ __forceinline__ float tiny_b(const float* B, int64_t ldb, int64_t n, int64_t k) {
+  return LAYOUT == CSTS_GEMM_NT ? B[n * ldb + k] : B[k * ldb + n];
+}
+template <int LAYOUT, bool PER_WAVE>
+__global__ __launch_bounds__(256) void gemm_tiny_kernel(Params p) {
+  const float* A = reinterpret_cast<const float*>(p.A);
+  const float* B = reinterpret_cast<const float*>(p.B);
+  float* Cm = reinterpret_cast<float*>(p.C);
+  const int64_t total = p.M * p.N;
+  if (PER_WAVE) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= total) return;                       // wave-uniform
+    const int64_t m = o / p.N, n = o - m * p.N;
+    float s = 0.f;
+    for (int64_t k = lane; k < p.K; k += 64) s = __builtin_fmaf(tiny_a<LAYOUT>(A, p.lda, m, k), tiny_b<LAYOUT>(B, p.ldb, n, k), s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) Cm[m * p.ldc + n] = s + (p.bias ? p.bias[n] : 0.f);
+  } else {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int64_t m = o / p.N, n = o - m * p.N;
+    float s = 0.f;
+    for (int64_t k = 0; k < p.K; ++k) s = __builtin_fmaf(tiny_a<LAYOUT>(A, p.lda, m, k), tiny_b<LAYOUT>(B, p.ldb, n, k), s);
+    Cm[m * p.ldc + n] = s + (p.bias ? p.bias[n] : 0.f);
+  }
+}
+static bool tiny_ok(const csts_gemm_args* a) {
+  static const bool off = getenv("CSTS_GEMM_TINY") != nullptr && getenv("CSTS_GEMM_TINY")[0] == '0';
+  if (off || a->compute != CSTS_F32 || a->a_dt != CSTS_F32 || a->b_dt != CSTS_F32 || a->c_dt != CSTS_F32) return false;
+  if (a->epilogue != CSTS_EPI_NONE || a->residual || a->row_scale || a->aux || a->colsum || a->algo != 0) return false;
+  const int64_t outs = a->M * a->N;
+  return (a->K <= 16 && outs <= (1 << 20)) || (outs <= 8192 && a->K <= 8192);
+}
+template <int LAYOUT>
+static void tiny_launch(const Params& p, hipStream_t s) {
+  const int64_t outs = p.M * p.N;
+  if (p.K <= 16) hipLaunchKernelGGL((gemm_tiny_kernel<LAYOUT, false>), dim3((unsigned)cdiv(outs, 256)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_tiny_kernel<LAYOUT, true>), dim3((unsigned)cdiv(outs, 4)), dim3(256), 0, s, p);
+}
+
 }  // namespace
 
 extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
@@ -1100,6 +1154,16 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
     CSTS_REQUIRE(a->epilogue == CSTS_EPI_NONE && !a->residual && !a->row_scale, "atomic split-k allows bias only");
   }
   if (a->epilogue == CSTS_EPI_DGELU) CSTS_REQUIRE(a->aux != nullptr, "DGELU needs aux (pre-activation)");
+  if (tiny_ok(a)) {
+    Params q{};
+    q.A = a->A; q.B = a->B; q.C = a->C; q.bias = a->bias;
+    q.lda = a->lda; q.ldb = a->ldb; q.ldc = a->ldc; q.M = a->M; q.N = a->N; q.K = a->K;
+    if (a->layout == CSTS_GEMM_NT) tiny_launch<CSTS_GEMM_NT>(q, stream);
+    else if (a->layout == CSTS_GEMM_NN) tiny_launch<CSTS_GEMM_NN>(q, stream);
+    else tiny_launch<CSTS_GEMM_TN>(q, stream);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   Params p;
   p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.aux = a->aux; p.residual = a->residual;
   p.row_scale = a->row_scale;
@@ -1203,7 +1267,7 @@ extern "C" int csts_gemm_v2_eligible(const csts_gemm_args* a) { return a != null
 
 // Which kernel csts_gemm would launch for these arguments (host-only; used by bench.py to name the kernel a timed call
 // ran, exactly as rocprofv3 prints it): v2 = 1 -> gemm2_kernel<A_KC, B_KC, A_F32, B_F32, tile_rows / 64, 2>; v2 = 30 + stages ->
-// gemm3_kernel<tile_rows / 64, stages>; 0 -> gemm_kernel.
+// gemm3_kernel<tile_rows / 64, stages>; 0 -> gemm_kernel; -1 -> gemm_tiny_kernel.
 extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, int* nsplit) {
   CSTS_REQUIRE(a != nullptr && v2 && tile_rows && nsplit, "null pointer");
   const int split = a->split_k > 1 ? a->split_k : 1;
@@ -1212,6 +1276,12 @@ extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, 
   const int64_t k_chunk = cdiv(cdiv(a->K, bk), split) * bk;
   const int64_t ns = cdiv(a->K, k_chunk);
   int mt3, st3, v4;
+  if (tiny_ok(a)) {                     // gemm_tiny_kernel<layout, wave mode>
+    *v2 = -1;
+    *nsplit = 1;
+    *tile_rows = 0;
+    return 0;
+  }
   if (pick4(a, split, &v4)) {          // gemm4 variant v4 (name: csts_gemm_kernel_name)
     *v2 = 400 + v4;
     *nsplit = 1;
@@ -1239,6 +1309,10 @@ extern "C" int csts_gemm_kernel_name(const csts_gemm_args* a, char* buf, int buf
   if (a->algo % 1000 >= 400 && a->algo % 1000 < 500) {
     *nsplit = 1;
     return csts_gemm4_name(a->algo % 1000 - 400, buf, buflen) ? 0 : -1;
+  }
+  if (v2 < 0) {
+    snprintf(buf, buflen, "gemm_tiny_kernel<%d, %s>", a->layout, tf(a->K > 16));
+    return 0;
   }
   if (v2 >= 400) return csts_gemm4_name(v2 - 400, buf, buflen) ? 0 : -1;
   if (v2 >= 30) snprintf(buf, buflen, "gemm3_kernel<%d, %d>", rows / 64, v2 - 30);
