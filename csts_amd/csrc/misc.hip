@@ -143,6 +143,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ X,
     ws[((int64_t)blockIdx.y * gridDim.z + batch) * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
+// narrow matrices (N % 4 == 0, N <= 256: the classifier's weight gradient over 262 k rows of 96 channels): N / 4 lanes read
+// one row as 16-byte (fp32) / 8-byte (bf16) pieces, 256 / (N / 4) rows per pass -- whole rows are contiguous reads, where the
+// 64-column blocks of colsum_kernel touch 256 of a row's 384 bytes per x-block with half of the second block's lanes idle
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const void* __restrict__ X, int dt, const float* __restrict__ rw,
+                                                            float* __restrict__ ws, int64_t M, int N, int64_t chunk) {
+  __shared__ float red[256][4];
+  const int L4 = N >> 2, R = 256 / L4;
+  const int tx = threadIdx.x % L4, ty = threadIdx.x / L4;
+  const int64_t batch = blockIdx.z;
+  const int64_t mbeg = (int64_t)blockIdx.y * chunk, mend = min(M, mbeg + chunk);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ty < R) {
+    for (int64_t m = mbeg + ty; m < mend; m += R) {
+      const int64_t at = (batch * M + m) * N + 4 * tx;
+      f32x4 v;
+      if (dt == CSTS_F32) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(X) + at);
+      else {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(X) + at);
+        v = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
+      const float wgt = rw ? rw[batch * M + m] : 1.f;
+      s[0] += v[0] * wgt; s[1] += v[1] * wgt; s[2] += v[2] * wgt; s[3] += v[3] * wgt;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+  __syncthreads();
+  if (ty == 0) {
+    for (int r = 1; r < R; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += red[r * L4 + tx][j];
+    float* o = ws + ((int64_t)blockIdx.y * gridDim.z + batch) * N + 4 * tx;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+  }
+}
+
 // ------------------------------------------------------------------ row softmax with temperature (frame_softmax)
 // slowfast/utils/utils.py:5-12 ; one workgroup per (b,t) row of H*W logits
 template <bool BWD>
@@ -409,6 +445,23 @@ __global__ __launch_bounds__(256) void rowdot_dx_kernel(const float* __restrict_
     st_from_f32(dx, dx_dt, idx, dout[idx / C] * w[idx % C]);
 }
 
+// the same, 4 channels per thread (C % 4 == 0, fewer than 2^31 elements): 32-bit indices, 16-byte fp32 / 8-byte bf16 stores
+__global__ __launch_bounds__(256) void rowdot_dx4_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                         void* __restrict__ dx, int dx_dt, int total4, int C4) {
+  for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
+    const int m = i4 / C4, c = (i4 - m * C4) * 4;
+    const float d = dout[m];
+    const float4 wv = *reinterpret_cast<const float4*>(w + c);
+    if (dx_dt == CSTS_F32) {
+      reinterpret_cast<float4*>(dx)[i4] = make_float4(d * wv.x, d * wv.y, d * wv.z, d * wv.w);
+    } else {
+      bf16x4 o;
+      o[0] = (bf16)(d * wv.x); o[1] = (bf16)(d * wv.y); o[2] = (bf16)(d * wv.z); o[3] = (bf16)(d * wv.w);
+      reinterpret_cast<bf16x4*>(dx)[i4] = o;
+    }
+  }
+}
+
 // c[m] = sum_n a[m,n] * b[m,n]   (gradient of a per-row weight: d w[m] = <dy[m,:], x[m,:]>); 32 lanes per row
 __global__ __launch_bounds__(256) void rowdot2_kernel(const void* __restrict__ a, int a_dt, const void* __restrict__ b, int b_dt,
                                                       float* __restrict__ out, int64_t M, int C) {
@@ -624,8 +677,13 @@ extern "C" int csts_colsum(const void* X, int dt, const float* row_weight, float
   colsum_plan(M, chunk, nchunk);
   CSTS_REQUIRE(ws_bytes >= (size_t)nchunk * batch * N * sizeof(float), "workspace too small");
   float* ws = reinterpret_cast<float*>(workspace);
-  dim3 grid((unsigned)cdiv(N, 64), (unsigned)nchunk, (unsigned)batch);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, dt, row_weight, ws, M, N, chunk);
+  if (N % 4 == 0 && N >= 16 && N <= 256 && M >= 4096 && aligned16(X)) {
+    hipLaunchKernelGGL(colsum_narrow_kernel, dim3(1, (unsigned)nchunk, (unsigned)batch), dim3(256), 0, stream, X, dt, row_weight, ws,
+                       M, (int)N, chunk);
+  } else {
+    dim3 grid((unsigned)cdiv(N, 64), (unsigned)nchunk, (unsigned)batch);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, X, dt, row_weight, ws, M, N, chunk);
+  }
   CSTS_LAUNCH_CHECK();
   csts_reduce_rows_launch(ws, out, nchunk, batch * N, 1.f, stream);
   CSTS_LAUNCH_CHECK();
@@ -743,7 +801,10 @@ extern "C" int csts_rowdot_fwd(const void* x, int x_dt, const float* w, const fl
 }
 extern "C" int csts_rowdot_dx(const float* dout, const float* w, void* dx, int dx_dt, int64_t M, int C, hipStream_t stream) {
   CSTS_REQUIRE(dout && w && dx && M > 0 && C > 0, "bad args");
-  hipLaunchKernelGGL(rowdot_dx_kernel, dim3(grid_for(M * C)), dim3(256), 0, stream, dout, w, dx, dx_dt, M * C, C);
+  if (C % 4 == 0 && M * C < ((int64_t)1 << 31) && aligned16(w) && aligned16(dx))
+    hipLaunchKernelGGL(rowdot_dx4_kernel, dim3(grid_for(M * C / 4)), dim3(256), 0, stream, dout, w, dx, dx_dt, (int)(M * C / 4), C / 4);
+  else
+    hipLaunchKernelGGL(rowdot_dx_kernel, dim3(grid_for(M * C)), dim3(256), 0, stream, dout, w, dx, dx_dt, M * C, C);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
