@@ -368,21 +368,28 @@ __global__ __launch_bounds__(256) void axpby_kernel(const void* __restrict__ a, 
   }
 }
 // out = a + b in fp32 and, optionally, its bf16 copy (gradient of a residual-stream tensor with two consumers); 4 per thread
+// copy_scale (optional): the bf16 copy (only the copy) is multiplied by copy_scale[i / elems_per_scale] -- the per-sample
+// drop-path scale of the branch that consumes this gradient next (see csts_layernorm_bwd_ex); elems_per_scale % 4 == 0
 __global__ __launch_bounds__(256) void add2_kernel(const void* __restrict__ a, int a_dt, const void* __restrict__ b, int b_dt,
-                                                   float* __restrict__ out, bf16* __restrict__ out16, int64_t total) {
+                                                   float* __restrict__ out, bf16* __restrict__ out16, int64_t total,
+                                                   const float* __restrict__ copy_scale, int64_t elems_per_scale) {
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
     float v[4];
+    const float sc = copy_scale ? copy_scale[i / elems_per_scale] : 1.f;
     if (i + 4 <= total && a_dt == CSTS_F32 && b_dt == CSTS_F32) {
       const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a) + i);
       const float4 y = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(b) + i);
       v[0] = x.x + y.x; v[1] = x.y + y.y; v[2] = x.z + y.z; v[3] = x.w + y.w;
       *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
-      if (out16) { const bf16x4 w = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *reinterpret_cast<bf16x4*>(out16 + i) = w; }
+      if (out16) {
+        const bf16x4 w = {(bf16)(v[0] * sc), (bf16)(v[1] * sc), (bf16)(v[2] * sc), (bf16)(v[3] * sc)};
+        *reinterpret_cast<bf16x4*>(out16 + i) = w;
+      }
     } else {
       for (int j = 0; j < 4 && i + j < total; ++j) {
         const float s_ = ld_as_f32(a, a_dt, i + j) + ld_as_f32(b, b_dt, i + j);
         out[i + j] = s_;
-        if (out16) out16[i + j] = (bf16)s_;
+        if (out16) out16[i + j] = (bf16)(s_ * sc);
       }
     }
   }
@@ -835,11 +842,17 @@ extern "C" int csts_audio_attn_bwd(const void* qkv, int dt, const float* d_wmap,
 }
 
 extern "C" int csts_add2(const void* a, int a_dt, const void* b, int b_dt, float* out, void* out_bf16, int64_t n, hipStream_t stream) {
+  return csts_add2_scaled_copy(a, a_dt, b, b_dt, out, out_bf16, nullptr, 4, n, stream);
+}
+extern "C" int csts_add2_scaled_copy(const void* a, int a_dt, const void* b, int b_dt, float* out, void* out_bf16,
+                                     const float* copy_scale, int64_t elems_per_scale, int64_t n, hipStream_t stream) {
   CSTS_REQUIRE(a && b && out && n > 0, "bad args");
   CSTS_REQUIRE((aligned16(a) && aligned16(b) && aligned16(out) && (!out_bf16 || (reinterpret_cast<uintptr_t>(out_bf16) & 7) == 0)),
                "operands must be 16-byte aligned");
+  CSTS_REQUIRE(copy_scale == nullptr || (out_bf16 != nullptr && elems_per_scale > 0 && elems_per_scale % 4 == 0),
+               "copy scale needs the bf16 copy and elems_per_scale % 4 == 0");
   hipLaunchKernelGGL(add2_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, stream, a, a_dt, b, b_dt, out,
-                     reinterpret_cast<bf16*>(out_bf16), n);
+                     reinterpret_cast<bf16*>(out_bf16), n, copy_scale, elems_per_scale > 0 ? elems_per_scale : 4);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

@@ -143,6 +143,7 @@ SYMBOLS = {
     "csts_axpby": (_I, [vp, _I, vp, _I, vp, _I, i64, _F, _F, vp]),
     "csts_scale_rows": (_I, [vp, _I, vp, i64, vp, _I, i64, i64, vp]),
     "csts_add2": (_I, [vp, _I, vp, _I, vp, vp, i64, vp]),
+    "csts_add2_scaled_copy": (_I, [vp, _I, vp, _I, vp, vp, vp, i64, i64, vp]),
     "csts_rowdot2": (_I, [vp, _I, vp, _I, vp, i64, _I, vp]),
     "csts_audio_attn_fwd": (_I, [vp, _I, vp, vp, _I, _I, _I, _I, _I, _F, vp]),
     "csts_audio_attn_bwd": (_I, [vp, _I, vp, vp, _I, _I, _I, _I, _I, _F, vp]),

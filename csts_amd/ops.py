@@ -1499,6 +1499,7 @@ class TapFn(Function):
     def forward(ctx, x, compute: int):
         _need_gpu(x)
         ctx.compute = compute
+        ctx.copy_scale = getattr(x, "_csts_prod_scale", None)     # x = f(...) * s + residual: its gradient's next reader wants s * dx
         ctx.set_materialize_grads(False)
         return x.view_as(x), x.view_as(x)
 
@@ -1510,9 +1511,15 @@ class TapFn(Function):
         out = torch.empty(da.shape, dtype=torch.float32, device=da.device)
         want16 = ctx.compute == BF16 and BF16_GRAD_COPY
         out16 = torch.empty(da.shape, dtype=torch.bfloat16, device=da.device) if want16 else None
-        L.check(_lib().csts_add2(_p(da), _dt(da), _p(db), _dt(db), _p(out), _p(out16), da.numel(), _stream()), "csts_add2")
+        cs = ctx.copy_scale if out16 is not None else None
+        if cs is not None:
+            rows = da.numel() // da.shape[-1]
+            if rows % cs[1] != 0 or cs[0].numel() * cs[1] != rows or (cs[1] * da.shape[-1]) % 4 != 0:
+                cs = None
+        L.check(_lib().csts_add2_scaled_copy(_p(da), _dt(da), _p(db), _dt(db), _p(out), _p(out16), _p(cs[0]) if cs else None,
+                                             cs[1] * da.shape[-1] if cs else 4, da.numel(), _stream()), "csts_add2")
         if out16 is not None:
-            _attach16(out, out16)
+            _attach16(out, out16, cs)
         return out, None
 
 

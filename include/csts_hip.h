@@ -214,7 +214,11 @@ int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void* out, int 
                hipStream_t stream);
 
 int csts_add2(const void* a, int a_dt, const void* b, int b_dt, float* out, void* out_bf16, int64_t n,
-              hipStream_t stream);   /* out = a + b (fp32) and optionally its bf16 copy: the two gradients of an encoder
+              hipStream_t stream);
+/* same; the bf16 copy (only the copy) is multiplied by copy_scale[i / elems_per_scale]: the per-sample stochastic-depth scale of
+ * the residual branch that consumes this gradient next (see csts_layernorm_bwd_ex) */
+int csts_add2_scaled_copy(const void* a, int a_dt, const void* b, int b_dt, float* out, void* out_bf16, const float* copy_scale,
+                          int64_t elems_per_scale, int64_t n, hipStream_t stream);   /* out = a + b (fp32) and optionally its bf16 copy: the two gradients of an encoder
                                       * feature that the decoder skip re-uses (custom_multimodal_builder.py:467-479) */
 
 int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
