@@ -725,3 +725,90 @@ def test_attention_bf16_backward_many_key_tiles(B, H, Nq, Nk, hd):
     assert rel_l2(dk.float(), back(kf.grad, Nk)) < 2e-2, "dk"
     assert rel_l2(dv.float(), back(vf.grad, Nk)) < 2e-2, "dv"
     assert (dqkv[:, Nq] == 7).all() and (dqkv[:, :Nq, Cc:] == 7).all()
+
+
+# ------------------------------------------------------------------------------------------------ round-2 additions
+@pytest.mark.parametrize("M,N,K", [(4, 256, 768), (4, 768, 256), (256, 768, 4), (4, 4, 256), (7, 33, 5), (61, 130, 16), (3, 2000, 100)])
+def test_tiny_fp32_gemm_path(M, N, K):
+    """fp32 GEMMs with few outputs or few reduction steps (EgoNCE projections / similarity: gemm_tiny_kernel) in all three
+    layouts, with bias, against torch fp64."""
+    A, Bt, Bn, At = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(K, N, seed=3), rnd(K, M, seed=4)
+    bias = rnd(N, seed=5)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(L.GEMM_NT, A, 0, K, Bt, 0, K, out, N, M, N, K, compute=L.F32, bias=bias)
+    assert rel_l2(out, (A.double() @ Bt.double().t() + bias.double()).float()) < 2e-6
+    ops.gemm(L.GEMM_NN, A, 0, K, Bn, 0, N, out, N, M, N, K, compute=L.F32)
+    assert rel_l2(out, (A.double() @ Bn.double()).float()) < 2e-6
+    ops.gemm(L.GEMM_TN, At, 0, M, Bn, 0, N, out, N, M, N, K, compute=L.F32, split_k=3)      # a split request is ignored here
+    assert rel_l2(out, (At.double().t() @ Bn.double()).float()) < 2e-6
+    out_b = out.clone()
+    ops.gemm(L.GEMM_TN, At, 0, M, Bn, 0, N, out, N, M, N, K, compute=L.F32)
+    assert torch.equal(out, out_b)                                                        # fixed summation order
+
+
+@pytest.mark.parametrize("Cc", [96, 384, 768])
+def test_layernorm_backward_two_gradients_and_scaled_copy(Cc):
+    """csts_layernorm_bwd_ex: dy + dy2 read by the kernel == LayerNorm backward of the summed gradient; the bf16 copy times
+    a per-sample scale == what csts_scale_rows makes of dx, bit for bit; dx itself stays unscaled."""
+    B, N = 3, 70
+    x = rnd(B, N, Cc, seed=1)
+    gamma, beta = rnd(Cc, seed=2) * 0.1 + 1.0, rnd(Cc, seed=3) * 0.1
+    dya, dyb = rnd(B, N, Cc, seed=4, dt=torch.bfloat16), rnd(B, N, Cc, seed=5, dt=torch.bfloat16)
+    dpass = rnd(B, N, Cc, seed=6)
+    xr = x.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (Cc,), gamma, beta, 1e-6)
+    y.backward(dya.float() + dyb.float())
+    ref_dx = xr.grad + dpass
+    mean = x.mean(-1).reshape(-1).contiguous()
+    rstd = (1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6)).reshape(-1).contiguous()
+    scale = torch.tensor([0.0, 1.0 / 0.8, 1.0 / 0.8], device=DEV)
+    dx, dgb = ops._ln_bwd_call(dya, x, gamma, mean, rstd, dpass, B * N, Cc, "csts_layernorm_bwd_ex", want16=True,
+                               copy_scale=(scale, N), dy2=dyb)
+    assert rel_l2(dx, ref_dx) < 2e-5
+    assert rel_l2(dgb[:Cc], (((dya.float() + dyb.float()) * ((x - x.mean(-1, keepdim=True)) * rstd.view(B, N, 1))).sum((0, 1)))) < 2e-5
+    d16 = ops._grad16(dx, L.BF16, (scale, N))
+    assert d16 is not None and ops._grad16(dx, L.BF16) is None and ops._grad16(dx, L.BF16, (scale, N + 1)) is None
+    assert torch.equal(d16, ops.scale_rows(dx, scale, N, B * N, Cc, out_dt=L.BF16))
+
+
+def test_tap_copy_scaled_for_the_consumer_branch():
+    """csts_add2_scaled_copy: fp32 sum unscaled, bf16 copy = bf16(sum * per-sample scale) == csts_scale_rows of the sum."""
+    B, N, Cc = 4, 130, 96
+    a, b = rnd(B, N, Cc, seed=1), rnd(B, N, Cc, seed=2)
+    s = torch.tensor([0.0, 1.25, 1.25, 0.0], device=DEV)
+    out = torch.empty_like(a)
+    out16 = torch.empty(B, N, Cc, device=DEV, dtype=torch.bfloat16)
+    L.check(L.load().csts_add2_scaled_copy(a.data_ptr(), L.F32, b.data_ptr(), L.F32, out.data_ptr(), out16.data_ptr(), s.data_ptr(),
+                                           N * Cc, a.numel(), torch.cuda.current_stream().cuda_stream), "csts_add2_scaled_copy")
+    assert torch.equal(out, a + b)
+    assert torch.equal(out16, ops.scale_rows(out, s, N, B * N, Cc, out_dt=L.BF16))
+
+
+def test_narrow_colsum_and_token_mean():
+    """colsum_narrow_kernel (N <= 256, many rows; weighted = the classifier's weight gradient) and the 16 x 16 token_mean."""
+    M, N = 40000, 96
+    X, w = rnd(M, N, seed=1), rnd(M, seed=2)
+    assert rel_l2(ops.colsum(X, 1, M, N, row_weight=w).view(-1), (X.double() * w.double()[:, None]).sum(0).float()) < 1e-5
+    Xb = X.to(torch.bfloat16)
+    assert rel_l2(ops.colsum(Xb, 1, M, N).view(-1), Xb.double().sum(0).float()) < 1e-5
+    t = rnd(4, 2048, 768, seed=3)
+    assert rel_l2(ops.token_mean(t), t.double().mean(1).float()) < 1e-5
+    t2 = rnd(3, 77, 40, seed=4)
+    assert rel_l2(ops.token_mean(t2), t2.double().mean(1).float()) < 1e-5
+
+
+def test_fusion_conv_bf16_shadow_is_bit_identical():
+    """The fusion convs read a bf16 shadow of their 37.7 M-parameter weight in bf16 mode: same output and gradients as reading
+    the fp32 master (the GEMM rounds the operand to bf16 while staging either way)."""
+    B, T, HW, Cc, Cout = 2, 4, 16, 96, 64
+    x = rnd(B, T * HW, Cc, seed=1)
+    W = (rnd(Cout, Cc, 1, 4, 4, seed=2) * 0.05)
+    b = rnd(Cout, seed=3)
+    outs = []
+    for w16 in (None, W.to(torch.bfloat16)):
+        xr, Wr = x.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        y = ops.fusion_conv(xr, Wr, b, T, HW, L.BF16, L.BF16, w16=w16)
+        y.backward(rnd(*y.shape, seed=4))
+        outs.append((y.detach(), xr.grad, Wr.grad))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
