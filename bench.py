@@ -384,7 +384,26 @@ def main():
         use_graph = not args.no_graph and not (dist_path and args.eager_dist)
         opt = T.construct_optimizer(model, cfg, capturable=use_graph)
         if use_graph and dist_path:
-            graphed, step_kind = T.SegmentedTrainStep(cfg, model, opt, batch), "hip_graph_chain+eager_collectives"
+            # The graph chain has never run on more than one physical GPU.  If building it fails on ANY rank,
+            # every rank falls back to the eager hook-driven step, so that a scaling run still produces its line.
+            ok, why = 1, ""
+            try:
+                if os.environ.get("CSTS_BENCH_FAIL_CHAIN"):           # test hook for the fallback below
+                    raise RuntimeError("forced by CSTS_BENCH_FAIL_CHAIN")
+                graphed, step_kind = T.SegmentedTrainStep(cfg, model, opt, batch), "hip_graph_chain+eager_collectives"
+            except Exception as e:                                    # noqa: BLE001 -- anything: the fallback is the point
+                ok, why, graphed = 0, repr(e), None
+                print(f"[bench] rank {rank}: graph chain failed ({why}); falling back to the eager data-parallel step", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                torch.cuda.synchronize()
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                graphed, step_kind = None, "eager+hook_buckets (graph chain unavailable)"
+                if isinstance(model, GradAllReduce):
+                    model.hooks_enabled = True
+                    _ops.GROUP_WGRADS = "never"
+                _ops.reset_deferred()
         elif use_graph:
             graphed, step_kind = T.GraphedTrainStep(cfg, model, opt, batch), "hip_graph"
 
