@@ -21,10 +21,17 @@
 
 namespace {
 
-constexpr int W8_TM = 192, W8_TN = 384, W8_BK = 64, W8_THR = 512;
+constexpr int W8_TM = 192, W8_TN = 384, W8_THR = 512;
 constexpr int W8_AROW = W8_TM * 2, W8_BROW = W8_TN * 2;                  // bytes per token row: 384, 768
-constexpr int W8_A_BYTES = W8_BK * W8_AROW, W8_B_BYTES = W8_BK * W8_BROW, W8_STAGE = W8_A_BYTES + W8_B_BYTES;   // 24 + 48 = 72 KiB
-constexpr int W8_NPA = W8_A_BYTES / 1024 / 8, W8_NPB = W8_B_BYTES / 1024 / 8;                                   // 1-KiB pieces per wave: 3, 6
+// ring geometry: BK tokens per stage, S stages.  <64, 2> (default): 72 KiB stages, one k-tile in flight beside the one being
+// consumed; <32, 4>: 36 KiB stages, three in flight (108 KiB) -- measured slower, see csts_wgrad_grouped8.
+template <int BK, int S> struct W8 {
+  static constexpr int A_BYTES = BK * W8_AROW, B_BYTES = BK * W8_BROW, STAGE = A_BYTES + B_BYTES;
+  static constexpr int NPIECE = STAGE / 1024;                              // 1-KiB LDS-DMA pieces per stage: 72 / 36
+  static constexpr int NPW = (NPIECE + 7) / 8;                             // pieces per wave (the last one only for waves < NPIECE % 8)
+  static constexpr int REM = NPIECE % 8;                                   // 0: every wave issues NPW; else waves >= REM issue NPW - 1
+  static_assert(S * STAGE <= 160 * 1024, "ring exceeds the CU's LDS");
+};
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -48,33 +55,40 @@ __device__ __forceinline__ bf16x8 frag_rot(const char* S, int obase, int ks, int
   return r;
 }
 
+template <int N> __device__ __forceinline__ void w8_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BK, int S>
 __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item* __restrict__ items) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * W8_STAGE];
+  typedef W8<BK, S> G;
+  constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE, NPW = G::NPW, REM = G::REM;
+  __shared__ __attribute__((aligned(1024))) char smem[S * STAGE];
   const csts_wgrad_item it = items[blockIdx.x];
   if (it.A == nullptr) return;          // padding slot (the host equalises the per-XCD lists); block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int64_t m0 = it.m0, n0 = it.n0, kbeg = it.kbeg;
-  const int nk = (int)((it.kend - kbeg) / W8_BK);          // whole k-tiles only (host-checked)
+  const int nk = (int)((it.kend - kbeg) / BK);             // whole k-tiles only (host-checked: token ranges are multiples of 64)
+  const bool short_wave = REM != 0 && wave >= REM;         // wave-uniform: this wave issues NPW - 1 pieces per stage
 
-  // ---- producer: this lane's source offsets (elements, relative to the k-tile's first token row) of the wave's pieces.
-  // LDS byte `off` of an image holds token row off / ROWB, rotated chunk (off % ROWB) / 16; the lane fetches the chunk that
-  // belongs there.
-  int aoff[W8_NPA], boff[W8_NPB];
+  // ---- producer: piece p = wave + 8 i of the stage image (A rows first, then B rows) belongs to this wave; this lane's
+  // source offset (elements, relative to the k-tile's first token row) of each.  LDS byte `off` of an image holds token row
+  // off / ROWB, rotated chunk (off % ROWB) / 16; the lane fetches the chunk that belongs there.
+  int soff[NPW];
 #pragma unroll
-  for (int i = 0; i < W8_NPA; ++i) {
-    const int off = (wave * W8_NPA + i) * 1024 + lane * 16, row = off / W8_AROW, chp = (off % W8_AROW) / 16;
-    int c = chp - 4 * ((row >> 1) & 1);
-    if (c < 0) c += W8_AROW / 16;
-    aoff[i] = row * (int)it.lda + (int)m0 + c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < W8_NPB; ++i) {
-    const int off = (wave * W8_NPB + i) * 1024 + lane * 16, row = off / W8_BROW, chp = (off % W8_BROW) / 16;
-    int c = chp - 4 * (row & 3);
-    if (c < 0) c += W8_BROW / 16;
-    boff[i] = row * (int)it.ldb + (int)n0 + c * 8;
+  for (int i = 0; i < NPW; ++i) {
+    const int p = min(wave + 8 * i, G::NPIECE - 1);
+    if (p * 1024 < A_BYTES) {
+      const int off = p * 1024 + lane * 16, row = off / W8_AROW, chp = (off % W8_AROW) / 16;
+      int c = chp - 4 * ((row >> 1) & 1);
+      if (c < 0) c += W8_AROW / 16;
+      soff[i] = row * (int)it.lda + (int)m0 + c * 8;
+    } else {
+      const int off = p * 1024 - A_BYTES + lane * 16, row = off / W8_BROW, chp = (off % W8_BROW) / 16;
+      int c = chp - 4 * (row & 3);
+      if (c < 0) c += W8_BROW / 16;
+      soff[i] = row * (int)it.ldb + (int)n0 + c * 8;
+    }
   }
   const bf16* __restrict__ A = reinterpret_cast<const bf16*>(it.A);
   const bf16* __restrict__ B = reinterpret_cast<const bf16*>(it.B);
@@ -82,11 +96,18 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
     const bf16* a = A + k0 * it.lda;
     const bf16* b = B + k0 * it.ldb;
 #pragma unroll
-    for (int i = 0; i < W8_NPA; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a + aoff[i]), (lptr_t)(st + (wave * W8_NPA + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < W8_NPB; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(b + boff[i]), (lptr_t)(st + W8_A_BYTES + (wave * W8_NPB + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < NPW; ++i) {
+      if (i == NPW - 1 && short_wave) break;
+      const int p = wave + 8 * i;                              // scalar
+      const bf16* src = (p * 1024 < A_BYTES) ? a : b;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + soff[i]), (lptr_t)(st + p * 1024), 16, 0, 0);
+    }
+  };
+  // k-tile kt has landed once at most `ahead` younger k-tiles of this wave's pieces are outstanding
+  auto wait_tile = [&](int ahead) {
+    if (S >= 4 && ahead >= 2) { if (short_wave) w8_wait<2 * (NPW - 1)>(); else w8_wait<2 * NPW>(); }
+    else if (S >= 3 && ahead == 1) { if (short_wave) w8_wait<NPW - 1>(); else w8_wait<NPW>(); }
+    else w8_wait<0>();
   };
 
   f32x16 acc[3][3];
@@ -97,24 +118,28 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fused bias gradient (n0 == 0 tiles): 384 threads own a column pair of the dY tile and a quarter of its 64 token rows
+  // fused bias gradient (n0 == 0 tiles): 384 threads own a column pair of the dY tile and a quarter of a stage's token rows
   const bool do_colsum = it.colsum != nullptr && n0 == 0 && tid < 384;
   const int cp = tid % 96, csl = tid / 96;
   float cs0 = 0.f, cs1 = 0.f;
 
-  if (nk > 0) issue(smem, kbeg);
-  int cs = 0;
+  // prologue: S - 1 stages in flight
+#pragma unroll
+  for (int s2 = 0; s2 < S - 1; ++s2)
+    if (s2 < nk) issue(smem + s2 * STAGE, kbeg + (int64_t)s2 * BK);
+  int cs = 0, ps = (S - 1) % S;                               // consumer stage, producer stage
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of k-tile kt have landed
-    __builtin_amdgcn_s_barrier();                        // ... everyone's have, and everyone is done with the other stage
-    const char* As = smem + cs * W8_STAGE;
-    const char* Bs = As + W8_A_BYTES;
-    if (kt + 1 < nk) issue(smem + (cs ^ 1) * W8_STAGE, kbeg + (int64_t)(kt + 1) * W8_BK);
-    cs ^= 1;
+    wait_tile(min(S - 2, nk - 1 - kt));                      // this wave's pieces of k-tile kt have landed
+    __builtin_amdgcn_s_barrier();                            // ... everyone's have, and everyone is done with the stage refilled next
+    const char* As = smem + cs * STAGE;
+    const char* Bs = As + A_BYTES;
+    if (kt + S - 1 < nk) issue(smem + ps * STAGE, kbeg + (int64_t)(kt + S - 1) * BK);
+    cs = (cs + 1 == S) ? 0 : cs + 1;
+    ps = (ps + 1 == S) ? 0 : ps + 1;
     if (do_colsum) {
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = csl * 16 + kk;
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        const int row = csl * (BK / 4) + kk;
         int ch = ((2 * cp) >> 3) + 4 * ((row >> 1) & 1);
         if (ch >= W8_AROW / 16) ch -= W8_AROW / 16;
         const bf16x2 t = *reinterpret_cast<const bf16x2*>(As + row * W8_AROW + ch * 16 + ((2 * cp) & 7) * 2);
@@ -123,7 +148,7 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < W8_BK / 16; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 a[3], b[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) a[i] = frag_rot<true>(As, wm * 96 + i * 32, ks, lane);
@@ -169,7 +194,12 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 // rows 16-byte aligned
 extern "C" int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStream_t stream) {
   CSTS_REQUIRE(device_items != nullptr && nitems > 0, "no items");
-  hipLaunchKernelGGL(wgrad8_kernel, dim3((unsigned)nitems), dim3(W8_THR), 0, stream, device_items);
+  // CSTS_WGRAD8_RING=4: four stages of 32 tokens (three in flight: 108 KiB instead of 72) -- measured 20 % SLOWER on MI355X
+  // (tools/wgrad8_bench.py: 862-877 us against 720-733 us for the 44 Linear layers of the 384-channel stage; a barrier every 18
+  // MFMAs per wave costs more than the extra bytes in flight return).  Default: two stages of 64 tokens.
+  static const bool ring4 = [] { const char* e = getenv("CSTS_WGRAD8_RING"); return e && e[0] == '4'; }();
+  if (ring4) hipLaunchKernelGGL((wgrad8_kernel<32, 4>), dim3((unsigned)nitems), dim3(W8_THR), 0, stream, device_items);
+  else hipLaunchKernelGGL((wgrad8_kernel<64, 2>), dim3((unsigned)nitems), dim3(W8_THR), 0, stream, device_items);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
