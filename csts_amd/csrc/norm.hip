@@ -21,11 +21,17 @@ template <bool F32> __device__ __forceinline__ void stt(void* p, int64_t i, floa
 }
 
 // one wave handles R rows per iteration (R*NV independent loads), two-pass statistics in registers
+// optional input of the forward kernels: x + addend is what gets normalised, and the sum is written to `sum` (dtype of x):
+// the decoder's `feat + en_feat` skip (custom_multimodal_builder.py:467-479) folded into the next block's norm1
+struct FwdAdd {
+  const void* addend = nullptr;
+  void* sum = nullptr;
+};
 template <int NV, int R, bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                     int C, float eps) {
+                                                     int C, float eps, FwdAdd fa) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -46,6 +52,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
       for (int j = 0; j < NV; ++j) {
         const int c = lane + 64 * j;
         v[r][j] = ldt<XF32>(x, row * C + min(c, C - 1));
+        if (fa.addend) {                                         // wave-uniform
+          v[r][j] += ldt<XF32>(fa.addend, row * C + min(c, C - 1));
+          if (c < C && row0 + r < rows) stt<XF32>(fa.sum, row * C + c, v[r][j]);
+        }
       }
     }
     float mu[R], rs[R];
@@ -218,7 +228,7 @@ template <int GL, int NCH, int R, bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, void* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                         int C, float eps) {
+                                                         int C, float eps, FwdAdd fa) {
   const int sub = threadIdx.x % GL;
   const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GL, ngrp = (int64_t)gridDim.x * 256 / GL;
   int c0[NCH];
@@ -239,7 +249,16 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict_
     for (int r = 0; r < R; ++r) {
       const int64_t row = min(row0 + r, rows - 1);
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) ld8t<XF32>(x, row * C + c0[i], v[r][i]);
+      for (int i = 0; i < NCH; ++i) {
+        ld8t<XF32>(x, row * C + c0[i], v[r][i]);
+        if (fa.addend) {
+          float a2[8];
+          ld8t<XF32>(fa.addend, row * C + c0[i], a2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[r][i][j] += a2[j];
+          if (act[i] && row0 + r < rows) st8t<XF32>(fa.sum, row * C + c0[i], v[r][i]);
+        }
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -503,11 +522,11 @@ extern "C" int csts_reduce_rows(const float* ws, float* out, int64_t nrows, int6
 
 template <int NV, int R>
 static void ln_fwd_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const void* x, const float* g, const float* b, void* y,
-                          float* mean, float* rstd, int64_t rows, int C, float eps) {
-  if (xf && yf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, true, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
-  else if (xf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, true, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
-  else if (yf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, false, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
-  else hipLaunchKernelGGL((ln_fwd_kernel<NV, R, false, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+                          float* mean, float* rstd, int64_t rows, int C, float eps, FwdAdd fa) {
+  if (xf && yf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, true, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
+  else if (xf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, true, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
+  else if (yf) hipLaunchKernelGGL((ln_fwd_kernel<NV, R, false, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
+  else hipLaunchKernelGGL((ln_fwd_kernel<NV, R, false, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
 }
 template <int NV, int R>
 static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
@@ -520,11 +539,11 @@ static void ln_bwd_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st
 }
 template <int GL, int NCH, int R>
 static void ln_fwd_vec_launch(bool xf, bool yf, dim3 grid, hipStream_t st, const void* x, const float* g, const float* b, void* y,
-                              float* mean, float* rstd, int64_t rows, int C, float eps) {
-  if (xf && yf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, true, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
-  else if (xf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, true, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
-  else if (yf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, false, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
-  else hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, false, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+                              float* mean, float* rstd, int64_t rows, int C, float eps, FwdAdd fa) {
+  if (xf && yf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, true, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
+  else if (xf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, true, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
+  else if (yf) hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, false, true>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
+  else hipLaunchKernelGGL((ln_fwd_vec_kernel<GL, NCH, R, false, false>), grid, dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, fa);
 }
 template <int GL, int NCH, int R>
 static void ln_bwd_vec_launch(bool df, bool xf, dim3 grid, size_t sh, hipStream_t st, const void* dy, const void* x, const float* g,
@@ -560,23 +579,32 @@ static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdi
 
 extern "C" int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt,
                                   float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t stream) {
+  return csts_layernorm_fwd_add(x, nullptr, nullptr, x_dt, gamma, beta, y, y_dt, mean, rstd, rows, C, eps, stream);
+}
+
+extern "C" int csts_layernorm_fwd_add(const void* x, const void* addend, void* sum_out, int x_dt, const float* gamma,
+                                      const float* beta, void* y, int y_dt, float* mean, float* rstd, int64_t rows, int C,
+                                      float eps, hipStream_t stream) {
   CSTS_REQUIRE(x && gamma && beta && y, "null pointer");
+  CSTS_REQUIRE((addend == nullptr) == (sum_out == nullptr), "addend and sum_out: both or neither");
   CSTS_REQUIRE(rows > 0 && C > 0 && C <= 64 * MAXV, "C must be in (0, 768]");
   const bool xf = x_dt == CSTS_F32, yf = y_dt == CSTS_F32;
-  if (ln_vec_ok(C, {x, y, gamma, beta})) {
+  FwdAdd fa;
+  fa.addend = addend; fa.sum = sum_out;
+  if (ln_vec_ok(C, {x, y, gamma, beta, addend, sum_out})) {
     const dim3 vgrid((unsigned)ln_fwd_vec_blocks(rows, C));
-    if (C <= 128) ln_fwd_vec_launch<16, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
-    else if (C <= 256) ln_fwd_vec_launch<32, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
-    else if (C <= 512) ln_fwd_vec_launch<64, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
-    else ln_fwd_vec_launch<64, 2, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+    if (C <= 128) ln_fwd_vec_launch<16, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+    else if (C <= 256) ln_fwd_vec_launch<32, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+    else if (C <= 512) ln_fwd_vec_launch<64, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+    else ln_fwd_vec_launch<64, 2, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
     CSTS_LAUNCH_CHECK();
     return 0;
   }
   const dim3 grid((unsigned)ln_fwd_blocks(rows, C));
-  if (C <= 128) ln_fwd_launch<2, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
-  else if (C <= 192) ln_fwd_launch<3, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
-  else if (C <= 384) ln_fwd_launch<6, 2>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
-  else ln_fwd_launch<12, 1>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  if (C <= 128) ln_fwd_launch<2, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+  else if (C <= 192) ln_fwd_launch<3, 4>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+  else if (C <= 384) ln_fwd_launch<6, 2>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+  else ln_fwd_launch<12, 1>(xf, yf, grid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

@@ -112,6 +112,7 @@ SYMBOLS = {
     "csts_gemm_kernel_name": (_I, [C.POINTER(GemmArgs), C.c_char_p, _I, C.POINTER(_I)]),
     "csts_gemm_plan": (_I, [C.POINTER(GemmArgs), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
+    "csts_layernorm_fwd_add": (_I, [vp, vp, vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),
     "csts_layernorm_bwd_workspace": (sz, [i64, _I]),
     "csts_layernorm_bwd": (_I, [vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, vp, vp, sz, i64, _I, vp]),
     "csts_layernorm_bwd_ex": (_I, [vp, vp, _I, vp, _I, vp, vp, vp, vp, _I, vp, vp, vp, i64, vp, vp, vp, sz, i64, _I, vp]),

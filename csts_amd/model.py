@@ -145,14 +145,17 @@ class Block(nn.Module):
             m2 = torch.floor(keep + torch.rand(B, dtype=torch.float32, device=device))
         return (m1 / keep).contiguous(), (m2 / keep).contiguous()
 
-    def forward(self, x, thw, keep_masks=None, want_attn=False, spatial_audio_attn=False):
+    def forward(self, x, thw, keep_masks=None, want_attn=False, spatial_audio_attn=False, x_add=None):
+        """x_add (optional): a skip tensor to be added to x first (the decoder's `feat + en_feat`,
+        custom_multimodal_builder.py:467-479): folded into norm1's kernel, which then also writes the sum."""
         rt = self.rt
         a = self.attn
         B, N, Cc = x.shape
         H = self.heads
         thw = list(thw)
         # x + f(LN(x)): LN returns an alias of x whose gradient (the residual branch) is folded into its backward kernel
-        xn, x = ops.layer_norm(x.contiguous(), self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt, passthrough=True)
+        xn, x = ops.layer_norm(x.contiguous(), self.norm1.weight, self.norm1.bias, 1e-6, rt.act_dt, passthrough=True,
+                               addend=x_add)
         w16 = lambda lin: getattr(lin, "_w16", None)      # bf16 shadow maintained by CSTS._refresh_w16 (bf16 mode)
         w16t = lambda lin: getattr(lin, "_w16t", None)    # its [in][out] twin (training): the data gradients run as NT GEMMs
         qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv), w16t=w16t(a.qkv))
@@ -515,11 +518,11 @@ class CSTS(nn.Module):
         y_rw = ops.reweight(yt, y_w, thw_a[0], HWa)
         # ---- decoder (:466-475)
         feat, dthw = x_rw, list(thw)
+        skip = None                              # feat = feat + inter[...] (:469-475) happens inside the next block's norm1
         for i in range(4):
             blk = getattr(self, f"decode_block{i + 1}")
-            feat, dthw, _ = blk(feat, dthw, km.get(f"decode_block{i + 1}"))
-            if i < 3:
-                feat = ops.add(feat, inter[-1 - i][0])
+            feat, dthw, _ = blk(feat, dthw, km.get(f"decode_block{i + 1}"), x_add=skip)
+            skip = inter[-1 - i][0] if i < 3 else None
         # ---- head (:476-481)
         en, en_thw = inter[0]
         logits = ops.classifier_head(feat, en, self.classifier.weight, self.classifier.bias, en_thw, rt.compute)

@@ -662,21 +662,32 @@ class LayerNormFn(Function):
     dx = LN'(d_xn) + d_residual in one pass instead of leaving the sum to a separate autograd add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, out_dt: int, passthrough: bool, fanout: bool = False):
+    def forward(ctx, x, gamma, beta, eps: float, out_dt: int, passthrough: bool, fanout: bool = False, addend=None):
         _need_gpu(x, gamma, beta)
         if passthrough and not x.is_contiguous():
             raise L.CstsError("layer_norm(passthrough=True) needs a contiguous input")
+        x_in = x
         x = x.contiguous()
         Cc = x.shape[-1]
         rows = x.numel() // Cc
         y = torch.empty(x.shape, dtype=torch_dtype(out_dt), device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        L.check(_lib().csts_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), out_dt, _p(mean), _p(rstd), rows, Cc,
-                                          eps, _stream()), "csts_layernorm_fwd")
+        ctx.has_add = addend is not None
+        if addend is not None:              # LN(x + addend); the sum (the new residual stream) is the pass-through output
+            if not passthrough or addend.shape != x.shape or addend.dtype != x.dtype:
+                raise L.CstsError("layer_norm(addend=...) needs passthrough=True and an addend like x")
+            addend = addend.contiguous()
+            xs = torch.empty_like(x)
+            L.check(_lib().csts_layernorm_fwd_add(_p(x), _p(addend), _p(xs), _dt(x), _p(gamma), _p(beta), _p(y), out_dt, _p(mean),
+                                                  _p(rstd), rows, Cc, eps, _stream()), "csts_layernorm_fwd_add")
+            x = xs
+        else:
+            L.check(_lib().csts_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), out_dt, _p(mean), _p(rstd), rows, Cc,
+                                              eps, _stream()), "csts_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.params = (gamma, beta)
-        ctx.copy_scale = getattr(x, "_csts_prod_scale", None) if passthrough else None
+        ctx.copy_scale = getattr(x_in, "_csts_prod_scale", None) if passthrough else None
         ctx.set_materialize_grads(False)
         ctx.fanout = bool(fanout)
         if fanout:                          # two aliases of y, one per consumer: backward receives both gradients
@@ -697,9 +708,11 @@ class LayerNormFn(Function):
                 dy, dy2 = dy2, None
         else:
             dpass = rest[0] if rest else None
-        nret = 7
+        nret = 8
+        # LN(x + addend): x and the addend receive the same gradient (d(x + a)/dx = d(x + a)/da = 1)
+        both = (lambda g_: (g_,) + (None,) * (nret - 2) + (g_,)) if ctx.has_add else (lambda g_: (g_,) + (None,) * (nret - 1))
         if dy is None:                      # only the residual branch carried a gradient
-            return (dpass,) + (None,) * (nret - 1)
+            return both(dpass)
         dy = dy.contiguous()
         if dy2 is not None:
             dy2 = dy2.contiguous()
@@ -715,15 +728,17 @@ class LayerNormFn(Function):
                                want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16), params=ctx.params,
                                copy_scale=ctx.copy_scale, dy2=dy2)
         if dgb is None:                     # finished and assigned by the end-of-backward flush
-            return (dx,) + (None,) * (nret - 1)
-        return (dx, dgb[:Cc], dgb[Cc:]) + (None,) * (nret - 3)
+            return both(dx)
+        return (dx, dgb[:Cc], dgb[Cc:]) + (None,) * (nret - 4) + ((dx,) if ctx.has_add else (None,))
 
 
-def layer_norm(x, gamma, beta, eps, out_dt, passthrough: bool = False, fanout: bool = False):
+def layer_norm(x, gamma, beta, eps, out_dt, passthrough: bool = False, fanout: bool = False, addend=None):
     """passthrough=False: y.  passthrough=True: (y, x_alias) -- use x_alias wherever x is used afterwards.
     fanout=True (with passthrough): (y_a, y_b, x_alias) for a LayerNorm output with TWO consumers -- the backward kernel reads
-    both incoming gradients itself (csts_layernorm_bwd_ex) instead of autograd adding them first."""
-    return LayerNormFn.apply(x, gamma, beta, eps, out_dt, passthrough, fanout)
+    both incoming gradients itself (csts_layernorm_bwd_ex) instead of autograd adding them first.
+    addend (with passthrough): LayerNorm(x + addend), and x_alias is that sum (csts_layernorm_fwd_add) -- a skip connection
+    folded into the norm that follows it."""
+    return LayerNormFn.apply(x, gamma, beta, eps, out_dt, passthrough, fanout, addend)
 
 
 # ----------------------------------------------------------------------------------------- Linear

@@ -87,6 +87,10 @@ int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStre
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */
 int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt, float* mean,
                        float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
+/* same, normalising x + addend (dtype of x) and writing that sum to sum_out: the decoder's skip `feat + en_feat`
+ * (custom_multimodal_builder.py:467-479) folded into the next block's norm1 (attention.py:192,238) */
+int csts_layernorm_fwd_add(const void* x, const void* addend, void* sum_out, int x_dt, const float* gamma, const float* beta,
+                           void* y, int y_dt, float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t stream);
 size_t csts_layernorm_bwd_workspace(int64_t rows, int C);
 /* addend (optional, dtype of dx): dx = LN'(dy) + addend -- the residual-branch gradient of x + f(LN(x)) (attention.py:242,247)
  * folded in.  dx_bf16 (optional): a bf16 copy of dx for the GEMMs that consume it next (they round to bf16 while staging
