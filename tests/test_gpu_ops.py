@@ -812,3 +812,22 @@ def test_fusion_conv_bf16_shadow_is_bit_identical():
         outs.append((y.detach(), xr.grad, Wr.grad))
     for u, v in zip(*outs):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("Cc", [96, 200, 768])
+def test_layernorm_with_folded_skip_add(Cc):
+    """layer_norm(x, addend=a): LayerNorm(x + a), the sum as the pass-through output, the same gradient for x and a."""
+    B, N = 2, 45
+    x, a = rnd(B, N, Cc, seed=1).requires_grad_(True), rnd(B, N, Cc, seed=2).requires_grad_(True)
+    gamma, beta = (rnd(Cc, seed=3) * 0.1 + 1.0).requires_grad_(True), (rnd(Cc, seed=4) * 0.1).requires_grad_(True)
+    y, xs = ops.layer_norm(x, gamma, beta, 1e-6, L.F32, passthrough=True, addend=a)
+    xr, ar = x.detach().clone().requires_grad_(True), a.detach().clone().requires_grad_(True)
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    sr = xr + ar
+    yr = F.layer_norm(sr, (Cc,), gr, br, 1e-6)
+    assert torch.equal(xs, sr) and rel_l2(y, yr) < 2e-6
+    gy, gs = rnd(B, N, Cc, seed=5), rnd(B, N, Cc, seed=6)
+    ((y * gy).sum() + (xs * gs).sum()).backward()
+    ((yr * gy).sum() + (sr * gs).sum()).backward()
+    assert rel_l2(x.grad, xr.grad) < 2e-5 and torch.equal(x.grad, a.grad)
+    assert rel_l2(gamma.grad, gr.grad) < 2e-5 and rel_l2(beta.grad, br.grad) < 2e-5
