@@ -313,16 +313,19 @@ __global__ __launch_bounds__(256) void reweight_kernel(const float* __restrict__
     y[idx] = x[idx] * w[bt * C + c];
   }
 }
-// dw[b,t,c] = sum_s dy * x
+// dw[b,t,c] = sum_s dy * x       (block = 64 channels x 4 lanes over the HW positions of one (b, t); fixed-order fold in LDS)
 __global__ __launch_bounds__(256) void reweight_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dw, int64_t nbtc, int HW, int C) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nbtc) return;
-  const int c = (int)(idx % C);
-  const int64_t bt = idx / C;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int64_t bt = blockIdx.y;
   float s = 0.f;
-  for (int i = 0; i < HW; ++i) { const int64_t o = (bt * HW + i) * C + c; s += x[o] * dy[o]; }
-  dw[idx] = s;
+  if (c < C)
+    for (int i = ty; i < HW; i += 4) { const int64_t o = (bt * HW + i) * C + c; s += x[o] * dy[o]; }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) dw[bt * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 // out[b,c] = mean_n x[b,n,c]   ;  bwd: dx[b,n,c] = dout[b,c] / N      (block = 16 channels x 16 token lanes: B * C / 16
 // workgroups -- 192 for the b=4 embeddings instead of the 48 of a 64 x 4 block, each lane with 4 independent partial sums)
@@ -767,7 +770,7 @@ extern "C" int csts_reweight_bwd(const float* x, const float* w, const float* dy
   CSTS_REQUIRE(x && w && dy && BT > 0 && HW > 0 && C > 0, "bad args");
   const int64_t total = BT * HW * C;
   if (dx) hipLaunchKernelGGL(reweight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, w, dx, total, HW, C);
-  if (dw) hipLaunchKernelGGL(reweight_dw_kernel, dim3((unsigned)cdiv(BT * C, 256)), dim3(256), 0, stream, x, dy, dw, BT * C, HW, C);
+  if (dw) hipLaunchKernelGGL(reweight_dw_kernel, dim3((unsigned)cdiv(C, 64), (unsigned)BT), dim3(256), 0, stream, x, dy, dw, BT * C, HW, C);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
