@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- CSTS throughput on MI355X (BASELINE.json metric: clips/s, training step; --mode fwd: forward only).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks, self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -321,8 +321,65 @@ def loss_check(cfg, model, frames, b, crop, dev, T):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): THIS process becomes the
+    launcher.  It has not touched the GPU (torch.cuda.device_count() does not initialise HIP on this image) and never will:
+    it starts N fresh children -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the same
+    command line -- waits for them and exits with the worst of their codes.  No exec from a process that holds the GPU.
+    Fewer than N devices -> exit 2 with a message instead of a one-GPU number under an N-GPU label (the gloo rehearsal
+    backend alone may stack ranks on one device)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    if ndev < n and args.dist_backend != "gloo":
+        print(f"bench.py: --gpus {n} but this machine exposes {ndev} GPU(s): refusing to measure fewer ranks than asked "
+              f"(use --dist-backend gloo for a control-flow rehearsal with several ranks on one GPU)", file=sys.stderr)
+        return 2
+    if ndev < 1:
+        print("bench.py needs an MI355X (the HIP path has no CPU fallback)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n))))
+        # rank 0 inherits stdout (it prints the ONE JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    try:
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    print(f"bench.py launcher: rank {procs.index(p)} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:         # exactly the children started above
+                        q.terminate()
+    finally:
+        for q in alive:
+            try:
+                q.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                q.kill()
+    return rc if rc >= 0 else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # stdout carries exactly ONE line (the JSON): native libraries print there too (RCCL writes a five-line version banner
     # to stdout when its first communicator comes up), so fd 1 points at stderr until the result is printed
     sys.stdout.flush()
@@ -334,6 +391,9 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     ndev = torch.cuda.device_count()
+    if world > ndev and args.dist_backend != "gloo":
+        print(f"bench.py: WORLD_SIZE {world} but {ndev} GPU(s) visible: one rank per GPU or nothing", file=sys.stderr)
+        sys.exit(2)
     local_rank = local_rank % max(ndev, 1)          # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -350,7 +410,7 @@ def main():
             torch.distributed.init_process_group(backend="gloo")
         else:
             torch.distributed.init_process_group(backend="nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     rccl_ranks = torch.distributed.get_world_size() if dist_path else 1
 
     from csts_amd.config import load_yaml

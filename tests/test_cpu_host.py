@@ -501,3 +501,29 @@ def test_mixed_precision_key_is_mapped_not_ignored(caplog):
         assert resolve_compute(cfg) == "fp32"
     assert "explicit compute mode wins" in caplog.text
     assert resolve_compute(load_yaml(YAML, ["NUM_GPUS", 0])) == "bf16"      # the shipped YAMLs name their mode
+
+
+def test_bench_gpus_n_without_launcher_never_measures_fewer_ranks():
+    """`python bench.py --gpus 2` with no launcher and fewer than 2 GPUs: non-zero exit, nothing on stdout (it
+    used to fall through to a one-rank run under an N-GPU label)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and p.stdout.strip() == "" and "refusing" in p.stderr
+
+
+def test_act_checkpoint_key_is_logged_not_ignored(caplog):
+    """MODEL.ACT_CHECKPOINT (custom_multimodal_builder.py:154,178,214: fairscale checkpoint_wrapper) changes memory, not
+    values: accepted, and the decision is logged when the key is set."""
+    import logging
+    from csts_amd.config import load_yaml
+    from csts_amd.registry import MODEL_REGISTRY
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "MODEL.ACT_CHECKPOINT", True])
+    with caplog.at_level(logging.WARNING, logger="csts_amd"):
+        MODEL_REGISTRY.get("CSTS")(cfg)
+    assert any("ACT_CHECKPOINT" in r.message for r in caplog.records)
