@@ -72,6 +72,10 @@ def parse():
                    help="gloo: control-flow rehearsal of the N>1 path with several ranks on ONE GPU (RCCL refuses two ranks per device)")
     p.add_argument("--op-breakdown", default=None, help="write per-C-ABI-entry device time of one eager step to this file")
     p.add_argument("--dump-gemm", default=None, help="write a per-shape GEMM timing table to this file")
+    p.add_argument("--dump-gemm-order", default=None,
+                   help="write the ORDERED list of one step's GEMM launches (kernel name, shape, event-timed us) as JSON: "
+                        "tools/trace_gemm_map.py zips it with a rocprofv3 kernel trace of the graph replay")
+    p.add_argument("--one-stream", action="store_true", help="audio trunk on the video trunk's stream (CSTS_AMD.TWO_STREAMS False)")
     return p.parse_args()
 
 
@@ -137,6 +141,16 @@ class GemmTimer:
             a[4] = a[4] or ns > 1
             a[5] += ext
         return agg
+
+    def dump_order(self, path, steps):
+        """The launches of the LAST instrumented step, in issue order."""
+        torch.cuda.synchronize()
+        n = len(self.records) // steps
+        rows = [{"kernel": name, "split": ns, "layout": "NT NN TN".split()[shape[0]], "M": shape[1], "N": shape[2], "K": shape[3],
+                 "flop": fl, "bytes": by, "epilogue_bytes": ext, "us_eager_events": round(e0.elapsed_time(e1) * 1e3, 2)}
+                for name, ns, fl, by, e0, e1, shape, ext in self.records[-n:]]
+        with open(path, "w") as f:
+            json.dump(rows, f)
 
     def dump_shapes(self, path):
         torch.cuda.synchronize()
@@ -424,6 +438,8 @@ def main():
             "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute]
     if args.trunk_cut is not None:
         opts += ["CSTS_AMD.TRUNK_CUT", args.trunk_cut]
+    if args.one_stream:
+        opts += ["CSTS_AMD.TWO_STREAMS", False]
     if S != 256:
         opts += ["DATA.TRAIN_CROP_SIZE", S, "DATA.TEST_CROP_SIZE", S, "CSTS_AMD.FUSION_KERNEL_FROM_GRID", True]
     cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"), opts)
@@ -604,6 +620,8 @@ def main():
         agg = gt.summary()
         if args.dump_gemm and rank == 0:
             gt.dump_shapes(args.dump_gemm)
+        if args.dump_gemm_order and rank == 0:
+            gt.dump_order(args.dump_gemm_order, 2)
         # dominant kernel = the single-kernel GEMM variant (no split-K finishing pass inside the event pair) with the most time
         single = {k: v for k, v in agg.items() if not v[4]}
         name = max(single, key=lambda k: single[k][3]) if single else None
