@@ -217,8 +217,14 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
         }
         if (p.row_scale != nullptr) v *= p.row_scale[m / p.rows_per_scale];
         if (p.residual != nullptr) {
-          const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-          v += ld_as_f32(p.residual, p.r_dt, rm * p.ldr + n);
+          if (p.ru_To > 0) {
+            float up[1];
+            res_up_load<1>(p, res_up_row(p, m), n, up);
+            v += up[0];
+          } else {
+            const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+            v += ld_as_f32(p.residual, p.r_dt, rm * p.ldr + n);
+          }
         }
         st_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
       }
@@ -574,9 +580,13 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
         for (int j = 0; j < 8; ++j) v[j] *= sc;
       }
       if (p.residual != nullptr) {
-        const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
         float rr[8];
-        ld8_as_f32(p.residual, p.r_dt, rm * p.ldr + n, rr);
+        if (p.ru_To > 0) {
+          res_up_load<8>(p, res_up_row(p, m), n, rr);
+        } else {
+          const int64_t rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+          ld8_as_f32(p.residual, p.r_dt, rm * p.ldr + n, rr);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += rr[j];
       }
@@ -1020,7 +1030,7 @@ bool v3_ok(const csts_gemm_args* a, int split) {
 }
 // Library heuristic for the persistent LDS-DMA kernel (64-row tiles, 3-stage ring, 2 workgroups per CU).
 bool pick3(const csts_gemm_args* a, int split, int* mt, int* stages) {
-  if (a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->M < 256) return false;
+  if (a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->M < 256 || a->res_up[3] > 0) return false;
   // Measured inside the train step (profiles/r1_v7_gemm_shapes.txt vs r1_v6): the ring wins where a workgroup's k-loop is
   // long and the grid is small (< 2 128-row tiles per CU, K >= 768: fc2 / qkv of the 384- and 768-channel stages,
   // 20-40 % faster); on the large-M short-K shapes the register-staged kernel at 3-4 workgroups per CU stays ahead.
@@ -1039,7 +1049,7 @@ bool pick3(const csts_gemm_args* a, int split, int* mt, int* stages) {
 // not FLOP per staged byte, decide.  CSTS_GEMM4=0 switches the family off (A/B runs).
 bool pick4(const csts_gemm_args* a, int split, int* variant) {
   static const bool enabled = [] { const char* e = getenv("CSTS_GEMM4"); return !(e && e[0] == '0'); }();
-  if (!enabled || a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->K % 64 != 0 || a->M < 2048) return false;
+  if (!enabled || a->algo != 0 || a->tile_rows != 0 || !v3_ok(a, split) || a->K % 64 != 0 || a->M < 2048 || a->res_up[3] > 0) return false;
   // Inside the train step (bench.py --dump-gemm, same-box A/B, profiles/r2_gemm4_instep_ab.txt) the family wins 5-23 % on
   // the GEMMs with a bf16 output (qkv, fc1 + GELU, the data gradients that feed bf16) and LOSES 5-15 % on the fp32
   // residual-stream outputs (proj, fc2: C and the residual are 4 bytes per element and the register epilogue reaches them in
@@ -1175,6 +1185,18 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   p.rows_per_scale = a->rows_per_scale > 0 ? a->rows_per_scale : 1;
   p.a_dt = a->a_dt; p.b_dt = a->b_dt; p.c_dt = a->c_dt; p.aux_dt = a->aux_dt; p.r_dt = a->r_dt;
   p.epilogue = a->epilogue; p.split_k = split;
+  p.ru_Ti = p.ru_Hi = p.ru_Wi = p.ru_To = p.ru_Ho = p.ru_Wo = p.ru_lw = p.ru_lh = p.ru_lt = 0;
+  if (a->res_up[3] > 0) {
+    const int Ti = a->res_up[0], Hi = a->res_up[1], Wi = a->res_up[2], To = a->res_up[3], Ho = a->res_up[4], Wo = a->res_up[5];
+    auto p2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    CSTS_REQUIRE(a->residual != nullptr && a->res_row_mod == 0 && split == 1, "res_up needs a residual, no res_row_mod, split_k == 1");
+    CSTS_REQUIRE(Ti > 0 && Hi > 0 && Wi > 0 && p2(To) && p2(Ho) && p2(Wo), "res_up: fine grid sizes must be powers of two");
+    CSTS_REQUIRE(To >= Ti && Ho >= Hi && Wo >= Wi && a->M % ((int64_t)To * Ho * Wo) == 0, "res_up: M must be B * To * Ho * Wo");
+    CSTS_REQUIRE(a->algo % 1000 < 300, "res_up is not available in the persistent LDS-DMA kernels");
+    p.ru_Ti = Ti; p.ru_Hi = Hi; p.ru_Wi = Wi; p.ru_To = To; p.ru_Ho = Ho; p.ru_Wo = Wo;
+    p.ru_lw = lg(Wo); p.ru_lh = lg(Ho); p.ru_lt = lg(To);
+  }
   auto vec_ok = [](const void* ptr, int dt, int64_t ld) {
     return aligned16(ptr) && (ld % (dt == CSTS_F32 ? 4 : 8) == 0);
   };

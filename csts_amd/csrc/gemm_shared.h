@@ -11,6 +11,8 @@ struct csts_gemm_params {
   int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
   int64_t ntiles;   // gemm3 (persistent): output tiles of the whole problem
   unsigned long long* stamps;   // gemm3 built with -DCSTS_GEMM3_STAMPS: cycle stamps of two workgroups (diagnostics)
+  // trilinear-upsampled residual (csts_gemm_args.res_up): coarse / fine grids, log2 of the (power-of-two) fine sizes
+  int ru_Ti, ru_Hi, ru_Wi, ru_To, ru_Ho, ru_Wo, ru_lw, ru_lh, ru_lt;
 };
 
 namespace {
@@ -63,6 +65,66 @@ __device__ __forceinline__ void st4x4(void* base, int dt, int64_t at, const f32x
       const int64_t cfirst = c0 - 4 * hi + 16 * pr + 8 * hi;
       if (rowok && cfirst < N)
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(base) + at - 4 * hi + 16 * pr + 8 * hi) = make_uint4(a.x, a.y, b.x, b.y);
+    }
+  }
+}
+
+// ---- residual = nn.Upsample(trilinear, align_corners=False) of a coarse token grid, evaluated in the epilogue.
+// The arithmetic is csts_trilinear_fwd's (stencil.hip), term for term: per axis the source cell and weights of torch's
+// area_pixel_compute_source_index, products tl * hl * wl, accumulation over (t, h, w) taps in that order from 0.f,
+// zero-weight taps skipped -- so a GEMM with res_up set equals trilinear -> GEMM with a plain residual bit for bit.
+struct ResUpRow {
+  int64_t base;          // first coarse row of the batch element
+  int ti[2], hi[2], wi[2];
+  float tl[2], hl[2], wl[2];
+};
+__device__ __forceinline__ void res_up_axis(int o, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+  const float scale = (float)in / (float)out;
+  float s = ((float)o + 0.5f) * scale - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+__device__ __forceinline__ ResUpRow res_up_row(const Params& p, int64_t m) {
+  ResUpRow r;
+  const int ow = (int)(m & (p.ru_Wo - 1));
+  const int oh = (int)((m >> p.ru_lw) & (p.ru_Ho - 1));
+  const int ot = (int)((m >> (p.ru_lw + p.ru_lh)) & (p.ru_To - 1));
+  const int64_t b = m >> (p.ru_lw + p.ru_lh + p.ru_lt);
+  r.base = b * ((int64_t)p.ru_Ti * p.ru_Hi * p.ru_Wi);
+  res_up_axis(ot, p.ru_Ti, p.ru_To, r.ti[0], r.ti[1], r.tl[0], r.tl[1]);
+  res_up_axis(oh, p.ru_Hi, p.ru_Ho, r.hi[0], r.hi[1], r.hl[0], r.hl[1]);
+  res_up_axis(ow, p.ru_Wi, p.ru_Wo, r.wi[0], r.wi[1], r.wl[0], r.wl[1]);
+  return r;
+}
+// NV consecutive columns n .. n + NV - 1 of the upsampled residual of the row described by r
+template <int NV>
+__device__ __forceinline__ void res_up_load(const Params& p, const ResUpRow& r, int64_t n, float (&acc)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    if (r.tl[a] == 0.f) continue;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (r.hl[e] == 0.f) continue;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        if (r.wl[f] == 0.f) continue;
+        const float wgt = r.tl[a] * r.hl[e] * r.wl[f];
+        const int64_t at = (r.base + (int64_t)(r.ti[a] * p.ru_Hi + r.hi[e]) * p.ru_Wi + r.wi[f]) * p.ldr + n;
+        if constexpr (NV == 8) {
+          float v[8];
+          ld8_as_f32(p.residual, p.r_dt, at, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += wgt * v[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < NV; ++j) acc[j] += wgt * ld_as_f32(p.residual, p.r_dt, at + j);
+        }
+      }
     }
   }
 }

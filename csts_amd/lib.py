@@ -32,7 +32,8 @@ class GemmArgs(C.Structure):
                 ("residual", vp), ("r_dt", C.c_int), ("ldr", i64), ("res_row_mod", i64),
                 ("row_scale", vp), ("rows_per_scale", i64),
                 ("compute", C.c_int), ("split_k", C.c_int),
-                ("workspace", vp), ("ws_bytes", sz), ("colsum", vp), ("tile_rows", C.c_int), ("algo", C.c_int)]
+                ("workspace", vp), ("ws_bytes", sz), ("colsum", vp), ("tile_rows", C.c_int), ("algo", C.c_int),
+                ("res_up", C.c_int * 6)]
 
 
 class DwconvGeom(C.Structure):

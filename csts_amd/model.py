@@ -175,9 +175,13 @@ class Block(nn.Module):
             pk.weight if pk is not None else None, nk.weight if nk is not None else None, nk.bias if nk is not None else None,
             pv.weight if pv is not None else None, nv.weight if nv is not None else None, nv.bias if nv is not None else None,
             meta)
+        res_up = None
         if self.kind == "dec":
             q_thw = [t * s for t, s in zip(thw, self.stride_q)]
-            x_res = ops.trilinear(x, thw, self.stride_q)
+            if ops.res_up_ok(q_thw) and x.dtype == torch.float32:
+                x_res, res_up = x, (list(thw), q_thw)     # the proj GEMM's epilogue up-samples the skip itself
+            else:
+                x_res = ops.trilinear(x, thw, self.stride_q)
         elif self.kind == "enc" and self.has_pool_q:
             q_thw = [(t - 1) // s + 1 for t, s in zip(thw, self.stride_q)]
             x_res = ops.maxpool_skip(x, thw, self.stride_q)
@@ -187,7 +191,7 @@ class Block(nn.Module):
         Nq = o.shape[1]
         s_attn, s_mlp = self._drop_scales(B, x.device, keep_masks)
         x1 = ops.linear(o, a.proj.weight, a.proj.bias, residual=x_res, row_scale=s_attn, rows_per_scale=Nq, out_dt=L.F32,
-                        compute=rt.compute, w16=w16(a.proj), w16t=w16t(a.proj))
+                        compute=rt.compute, w16=w16(a.proj), w16t=w16t(a.proj), res_up=res_up)
         if self.dim != self.dim_out:        # norm2's output feeds fc1 AND the skip projection (attention.py:243-246)
             xn2, xn2b, x1 = ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, 1e-6, rt.act_dt, passthrough=True, fanout=True)
             base = ops.linear(xn2b, self.proj.weight, self.proj.bias, out_dt=L.F32, compute=rt.compute, w16=w16(self.proj),

@@ -505,8 +505,10 @@ def _auto_split(layout, M, N, K, compute):
 
 def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bias=None, epilogue=L.EPI_NONE, aux=None,
          residual=None, ldr=0, res_row_mod=0, row_scale=None, rows_per_scale=1, split_k=1, deterministic=True, tile_rows=0,
-         want_colsum=False, algo=0, debug_ws=None):
-    if split_k == 1 and AUTO_SPLIT_SMALL_M and not want_colsum and algo == 0 and tile_rows == 0:
+         want_colsum=False, algo=0, debug_ws=None, res_up=None):
+    """res_up = (coarse thw, fine thw): `residual` is the coarse token grid and the epilogue adds its trilinear up-sampling
+    (csts_gemm_args.res_up)."""
+    if split_k == 1 and AUTO_SPLIT_SMALL_M and not want_colsum and algo == 0 and tile_rows == 0 and res_up is None:
         split_k = _auto_split(layout, M, N, K, compute)
     a = L.GemmArgs()
     a.layout = layout
@@ -523,6 +525,9 @@ def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bia
     a.compute, a.split_k = compute, split_k
     a.tile_rows = tile_rows
     a.algo = algo
+    if res_up is not None:
+        for i, v in enumerate(list(res_up[0]) + list(res_up[1])):
+            a.res_up[i] = int(v)
     ws = None
     if debug_ws is not None:   # diagnostics builds only (gemm3 cycle stamps)
         a.workspace, a.ws_bytes = _p(debug_ws), debug_ws.numel() * debug_ws.element_size()
@@ -747,7 +752,9 @@ class LinearFn(Function):
     of attention.py:242,247 folded into the epilogue)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int, w16, w16t=None):
+    def forward(ctx, x, W, b, residual, row_scale, rows_per_scale: int, out_dt: int, compute: int, w16, w16t=None, res_up=None):
+        """res_up = (coarse thw, fine thw): `residual` is the decoder skip on the COARSE grid and the GEMM epilogue adds
+        nn.Upsample(scale_factor=stride_q, mode='trilinear')(residual) (attention.py:463-471) -- x_res is never written."""
         _need_gpu(x, W)
         x = x.contiguous()
         W = W.contiguous()
@@ -759,7 +766,12 @@ class LinearFn(Function):
             residual = residual.contiguous()
         Wop = w16 if (w16 is not None and compute == BF16) else W     # bf16 shadow of the fp32 master weight
         gemm(L.GEMM_NT, x, 0, K, Wop, 0, K, y, N, M, N, K, compute=compute, bias=b, residual=residual, ldr=N,
-             row_scale=row_scale, rows_per_scale=rows_per_scale)
+             row_scale=row_scale, rows_per_scale=rows_per_scale, res_up=res_up)
+        ctx.res_up = None
+        if res_up is not None:
+            thw_c, thw_f = list(res_up[0]), list(res_up[1])
+            Bc = residual.shape[0]
+            ctx.res_up = (_pool_geom(Bc, N, thw_c, thw_f, [f // c for f, c in zip(thw_f, thw_c)]), tuple(residual.shape))
         ctx.save_for_backward(x, Wop, row_scale)
         ctx.wdtype = W.dtype
         ctx.params = (W, b)
@@ -795,8 +807,13 @@ class LinearFn(Function):
         elif has_b and ctx.needs_input_grad[2]:
             db = colsum(dys, 1, M, N)
         if has_res and ctx.needs_input_grad[3]:
-            dres = dy if dy.dtype == res_dtype else dy.to(res_dtype)
-        return dx, dW, db, dres, None, None, None, None, None, None
+            if ctx.res_up is not None:      # adjoint of the up-sampling the epilogue applied to the coarse skip
+                g, shape = ctx.res_up
+                dres = torch.empty(shape, dtype=res_dtype, device=dy.device)
+                L.check(_lib().csts_trilinear_bwd(C.byref(g), _p(dy), _dt(dy), _p(dres), _dt(dres), _stream()), "csts_trilinear_bwd(res_up)")
+            else:
+                dres = dy if dy.dtype == res_dtype else dy.to(res_dtype)
+        return dx, dW, db, dres, None, None, None, None, None, None, None
 
 
 def _dgrad(dy, W, Wt, dx, M, N, K, compute, epilogue=L.EPI_NONE, aux=None):
@@ -835,8 +852,17 @@ class _TransposeSet:
         L.check(_lib().csts_transpose_multi(self.table.data_ptr(), self.n, _stream()), "csts_transpose_multi")
 
 
-def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32, w16=None, w16t=None):
-    y = LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16, w16t)
+RES_UP_FUSE = os.environ.get("CSTS_RES_UP_FUSE", "1") != "0"     # decoder skip up-sampled inside the proj GEMM's epilogue
+
+
+def res_up_ok(thw_fine) -> bool:
+    """The fused form needs power-of-two fine grid sizes (csts_gemm_args.res_up)."""
+    return RES_UP_FUSE and all(v > 0 and (v & (v - 1)) == 0 for v in thw_fine)
+
+
+def linear(x, W, b=None, *, residual=None, row_scale=None, rows_per_scale=1, out_dt=F32, compute=F32, w16=None, w16t=None,
+           res_up=None):
+    y = LinearFn.apply(x, W, b, residual, row_scale, rows_per_scale, out_dt, compute, w16, w16t, res_up)
     return _mark_scaled_output(y, row_scale if residual is not None else None, rows_per_scale)
 
 

@@ -40,6 +40,11 @@ int csts_abi_version(void);
  *      NT: C = A[M,K] B[N,K]^T ; NN: C = A[M,K] B[K,N] ; TN: C = A[K,M]^T B[K,N].
  *      epilogue: v = acc + bias[n]; GELU: aux[m,n] = v, v = gelu_erf(v); DGELU: v *= gelu'(aux[m,n]);
  *                v *= row_scale[m / rows_per_scale] (drop-path, common.py:46-59); v += residual[m % res_row_mod, n].
+ *      res_up = {Ti, Hi, Wi, To, Ho, Wo} (To > 0): `residual` is the COARSE token grid [B * Ti*Hi*Wi][ldr] of the decoder's
+ *                skip and row m of C is fine token (b, to, ho, wo) of [B * To*Ho*Wo]: the epilogue adds
+ *                nn.Upsample(mode='trilinear', align_corners=False)(residual)[m, n] (attention.py:463-471), computed with the
+ *                arithmetic of csts_trilinear_fwd -- the upsampled skip never goes through HBM.  To, Ho, Wo powers of two,
+ *                split_k == 1, res_row_mod == 0; not for the persistent LDS-DMA kernels (the library picks accordingly).
  *      split_k > 1: with a workspace, deterministic partial slabs + finishing pass (full epilogue);
  *                   without, fp32 atomic accumulation into a pre-zeroed f32 C (bias only). */
 typedef struct {
@@ -59,6 +64,7 @@ typedef struct {
   float* colsum;   /* optional, TN + bf16 v2 kernel only: colsum[m] = sum_k A[k,m] (the bias gradient of a Linear) */
   int tile_rows;   /* 0 = library heuristic; 64 / 128 / 256 force the bf16 kernel's row tile (tuning sweeps) */
   int algo;        /* 0 = library heuristic; 2 = register-staged kernel; 1000 * wg_per_cu + 300 + 10 * (tile_rows / 64) + stages = persistent LDS-DMA NT kernel (tuning sweeps) */
+  int res_up[6];   /* {Ti, Hi, Wi, To, Ho, Wo}; all 0 = plain residual */
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
 size_t csts_gemm_splitk_workspace(int64_t M, int64_t N, int64_t K, int split_k);

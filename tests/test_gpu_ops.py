@@ -831,3 +831,46 @@ def test_layernorm_with_folded_skip_add(Cc):
     ((yr * gy).sum() + (sr * gs).sum()).backward()
     assert rel_l2(x.grad, xr.grad) < 2e-5 and torch.equal(x.grad, a.grad)
     assert rel_l2(gamma.grad, gr.grad) < 2e-5 and rel_l2(beta.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+@pytest.mark.parametrize("thw,stride,Cin,Cout", [((2, 4, 8), (1, 2, 2), 64, 96), ((4, 8, 8), (2, 1, 1), 96, 192), ((1, 2, 4), (2, 2, 2), 32, 200)])
+def test_linear_with_upsampled_residual_in_the_epilogue(compute, thw, stride, Cin, Cout):
+    """Decoder skip (attention.py:463-471: x_res = Upsample(trilinear)(x), x = x_res + proj(attn)): the proj GEMM's epilogue
+    up-samples the coarse skip itself (csts_gemm_args.res_up).  Forward == trilinear kernel -> GEMM with a plain residual BIT
+    FOR BIT (same arithmetic, term for term) and == torch's F.interpolate within the op tolerance; backward: the skip's
+    gradient is the adjoint up-sampling of dy, the other gradients are unchanged."""
+    B = 2
+    out = [t * s for t, s in zip(thw, stride)]
+    Nc, Nf = thw[0] * thw[1] * thw[2], out[0] * out[1] * out[2]
+    dt = tdt(compute)
+    o = rnd(B, Nf, Cin, seed=1).to(dt).requires_grad_(True)
+    W = rnd(Cout, Cin, seed=2, scale=0.1).requires_grad_(True)
+    b = rnd(Cout, seed=3).requires_grad_(True)
+    skip = rnd(B, Nc, Cout, seed=4).requires_grad_(True)
+    rs = torch.tensor([0.0, 1.25], device=DEV)
+    dy = rnd(B, Nf, Cout, seed=5)
+
+    def run(fused):
+        for t in (o, W, b, skip):
+            t.grad = None
+        if fused:
+            y = ops.linear(o, W, b, residual=skip, row_scale=rs, rows_per_scale=Nf, out_dt=L.F32, compute=compute, res_up=(list(thw), out))
+        else:
+            y = ops.linear(o, W, b, residual=ops.trilinear(skip, thw, stride), row_scale=rs, rows_per_scale=Nf, out_dt=L.F32, compute=compute)
+        y.backward(dy)
+        ops.flush_deferred()
+        torch.cuda.synchronize()
+        return y.detach().clone(), [t.grad.detach().clone() for t in (o, W, b, skip)]
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert torch.equal(y1, y0)
+    for a, c in zip(g1, g0):
+        assert torch.equal(a, c)
+    up = F.interpolate(skip.detach().view(B, *thw, Cout).permute(0, 4, 1, 2, 3), scale_factor=tuple(float(s) for s in stride), mode="trilinear",
+                       align_corners=False).permute(0, 2, 3, 4, 1).reshape(B, Nf, Cout)
+    ref = (o.detach().float() @ W.detach().t() + b.detach()) * rs.repeat_interleave(Nf).view(B, Nf, 1) + up
+    assert rel_l2(y1, ref) < TOL[compute]
+    with pytest.raises(L.CstsError):       # fine grid sizes must be powers of two
+        ops.linear(o, W, b, residual=skip, out_dt=L.F32, compute=compute, res_up=(list(thw), [out[0], out[1], out[2] + 1]))
