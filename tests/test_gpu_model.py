@@ -163,8 +163,9 @@ def test_full_model_bf16_mode_reported_tolerances():
     e_logits, e_heat = rel_l2(logits, g["logits"]), rel_l2(heat, g["heat"])
     agree = float((heat.reshape(2, 8, -1).argmax(-1).cpu().numpy() == g["argmax"]).mean())
     print(f"\n[bf16 mode] logits rel-L2 {e_logits:.3e}  heatmap rel-L2 {e_heat:.3e}  argmax agreement {agree:.3f}")
-    assert e_logits < 3e-2 and e_heat < 5e-3     # bf16 operands, fp32 accumulate / residual stream / softmax
-    assert agree >= 0.75
+    # measured 4.7e-3 / 1.7e-3 / 1.0: bars at ~2 x (bf16 operands, fp32 accumulate / residual stream / softmax)
+    assert e_logits < 1e-2 and e_heat < 3.5e-3
+    assert agree >= 0.9375
 
 
 def test_droppath_train_mode_fp32():
@@ -316,18 +317,20 @@ def test_train_T16_fp32_vs_reference_golden():
 
 @pytest.mark.parametrize("T_,fixture,seed", [(8, "model_T8_B2.npz", 1000), (16, "model_T16_B2_train.npz", 1004)])
 def test_train_bf16_vs_reference_golden(T_, fixture, seed):
-    """bf16 mode (the benchmarked one) at MODEL level, forward AND backward, against the reference fixture.  Stated bars:
-    |loss - ref| / ref < 1e-2; per-tensor gradient-norm error < 5e-2; total gradient norm within 2e-2; per-frame argmax
-    agreement >= 0.95; on the stored 64-element gradient slices: rms error < 0.15 x max(slice rms, tensor rms), and
-    cosine >= 0.97 where the slice carries signal (slice rms >= half the tensor rms).  Whole-tensor cosines of bf16-mode
+    """bf16 mode (the benchmarked one) at MODEL level, forward AND backward, against the reference fixture.  Stated bars
+    (round 3: set at ~2 x what this build measures -- T8 / T16: loss error 2e-6 / 6e-6, worst gradient-norm error 8.5e-3 / 1.8e-2,
+    total norm 2.2e-3 / 4.2e-3, worst informative slice cosine 0.9929 / 0.9917, argmax 1.0 / 31 of 32 frames):
+    |loss - ref| / ref < 1e-3; per-tensor gradient-norm error < 3.6e-2; total gradient norm within 1e-2; per-frame argmax
+    agreement >= 0.9375 (30 of 32 frames); on the stored 64-element gradient slices: rms error < 0.15 x max(slice rms, tensor
+    rms), and cosine >= 0.983 where the slice carries signal (slice rms >= half the tensor rms).  Whole-tensor cosines of bf16-mode
     gradients are 0.98-0.998 (test_bf16_mode_gradients_all_tensors_vs_fp32_mode): bf16 operands with fp32 accumulation /
     residual stream / statistics / softmax / losses -- what torch.autocast gives the reference -- so a
     64-element sample sits around 0.99 and cannot be held to >= 0.99 tensor by tensor."""
     m, cfg = make_model("bf16", T_)
     g = _load(fixture)
     loss, kld, nce, preds = _train_pass(m, cfg, dev_batch(2, T_, seed))
-    _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-2, norm_tol=5e-2, cos_min=0.97, total_tol=2e-2,
-                         argmax_min=0.95, label=f"bf16 T{T_} B2")
+    _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-3, norm_tol=3.6e-2, cos_min=0.983, total_tol=1e-2,
+                         argmax_min=0.9375, label=f"bf16 T{T_} B2")
 
 
 def test_bf16_mode_gradients_all_tensors_vs_fp32_mode():
@@ -377,8 +380,10 @@ def test_train_T32_aria_vs_reference_golden():
             _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-4, norm_tol=2e-3, slice_tol=1e-2, total_tol=1e-3,
                                  argmax_min=1.0, label="fp32 T32 B1 aria")
         else:
-            _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-2, norm_tol=5e-2, cos_min=0.97, total_tol=2e-2,
-                                 argmax_min=0.9, label="bf16 T32 B1 aria")
+            # measured: loss error 5e-6, worst gradient-norm error 9.4e-3, total norm 2.6e-4, worst informative slice cosine
+            # 0.9878, argmax 31 of 32 frames; bars at ~2 x that
+            _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-3, norm_tol=2e-2, cos_min=0.975, total_tol=2e-3,
+                                 argmax_min=0.9375, label="bf16 T32 B1 aria")
         del m
     torch.cuda.empty_cache()
 
