@@ -851,6 +851,150 @@ __global__ __launch_bounds__(256) void trilinear_bwd_kernel(UpGeom g, const void
   }
 }
 
+// ------------------------------------------------------------------ specialised resampling kernels (scale factors 1 and 2)
+// The generic kernels above recover (b, t, h, w, channel group) from a flat 64-bit index with runtime divisions and walk
+// runtime-sized candidate windows, testing each candidate with `%` / `/` (max-pool) or re-deriving its interpolation weights
+// from torch's source-index formula (trilinear backward: 108 candidates for 16 contributing taps at scale (1, 2, 2)) -- they
+// are bound by vector-instruction issue (~1200 instructions per 16 output bytes), not by the tensors they move.  CSTS only
+// ever resamples by 1 or 2 per axis: here the contributing taps and their weights are closed forms, a workgroup row is one
+// (b, t, h) line of the tensor being written (its decomposition is wave-uniform), and (w, channel group) comes from one
+// reciprocal multiply.  Same taps, same weights (exact binary fractions), same order of accumulation as the generic forms:
+// bit-identical results (tests/test_gpu_ops.py::test_resampling_specialisations_match_generic).
+struct FastRow { int wq; int cq; float inv_cq; };      // wq = (row length in tokens) * cq work items per row
+
+// taps of the trilinear ADJOINT along one axis: coarse index i of n receives output o with weight w (ascending o)
+template <int R> __device__ __forceinline__ int up_adj_taps(int i, int n, int (&o)[4], float (&w)[4]) {
+  if constexpr (R == 1) { o[0] = i; w[0] = 1.f; return 1; }
+  else {
+    int k = 0;
+    if (i >= 1) { o[k] = 2 * i - 1; w[k] = 0.25f; ++k; }
+    o[k] = 2 * i; w[k] = i >= 1 ? 0.75f : 1.f; ++k;
+    o[k] = 2 * i + 1; w[k] = i == n - 1 ? 1.f : 0.75f; ++k;       // the last cell: l0 + l1 of the clamped pair
+    if (i <= n - 2) { o[k] = 2 * i + 2; w[k] = 0.25f; ++k; }
+    return k;
+  }
+}
+
+template <int RT, int RH, int RW>
+__global__ __launch_bounds__(256) void trilinear_bwd_fast_kernel(UpGeom g, FastRow fr, const void* __restrict__ dy, int dy_dt,
+                                                                 void* __restrict__ dx, int dx_dt) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= fr.wq) return;
+  const int w = (int)(((float)idx + 0.5f) * fr.inv_cq), c = (idx - w * fr.cq) * VEC;
+  const int row = blockIdx.y;                                     // (b * Ti + t) * Hi + h, wave-uniform
+  const int h = row % g.Hi, bt = row / g.Hi, t = bt % g.Ti, b = bt / g.Ti;
+  int ot[4], oh[4], ow[4];
+  float wt[4], wh[4], ww[4];
+  const int nt = up_adj_taps<RT>(t, g.Ti, ot, wt), nh = up_adj_taps<RH>(h, g.Hi, oh, wh), nw = up_adj_taps<RW>(w, g.Wi, ow, ww);
+  const int64_t obase = (int64_t)b * g.To * g.Ho * g.Wo;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < (RT == 1 ? 1 : 4); ++a) {
+    if (a >= nt) break;
+#pragma unroll
+    for (int e = 0; e < (RH == 1 ? 1 : 4); ++e) {
+      if (e >= nh) break;
+#pragma unroll
+      for (int f = 0; f < (RW == 1 ? 1 : 4); ++f) {
+        if (f >= nw) break;
+        const float wgt = wt[a] * wh[e] * ww[f];
+        float v[4];
+        ld4(dy, dy_dt, (obase + (int64_t)(ot[a] * g.Ho + oh[e]) * g.Wo + ow[f]) * g.C + c, v);
+        s[0] += wgt * v[0]; s[1] += wgt * v[1]; s[2] += wgt * v[2]; s[3] += wgt * v[3];
+      }
+    }
+  }
+  st4(dx, dx_dt, ((int64_t)row * g.Wi + w) * g.C + c, s);
+}
+
+// MaxPool3d kernel (1, 3, 3), stride (1, 2, 2), padding (0, 1, 1): the only geometry pool_skip takes in CSTS
+__global__ __launch_bounds__(256) void maxpool133_fwd_kernel(PoolGeom g, FastRow fr, const void* __restrict__ x, int dt,
+                                                             void* __restrict__ y, uint8_t* __restrict__ arg) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= fr.wq) return;
+  const int ow = (int)(((float)idx + 0.5f) * fr.inv_cq), c = (idx - ow * fr.cq) * VEC;
+  const int row = blockIdx.y;                                     // (b * To + ot) * Ho + oh  (To == Ti)
+  const int oh = row % g.Ho, bt = row / g.Ho;                     // bt = b * Ti + t
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {0, 0, 0, 0};
+  bool first = true;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int h = 2 * oh - 1 + e;
+    if (h < 0 || h >= g.Hi) continue;                             // wave-uniform
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      const int w = 2 * ow - 1 + f;
+      if (w < 0 || w >= g.Wi) continue;
+      float v[4];
+      ld4(x, dt, (((int64_t)bt * g.Hi + h) * g.Wi + w) * g.C + c, v);
+      const int tap = e * 3 + f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (first || v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = tap; }   // first max wins; NaN propagates
+      first = false;
+    }
+  }
+  const int64_t o = ((int64_t)row * g.Wo + ow) * g.C + c;
+  st4(y, dt, o, best);
+  if (arg) *reinterpret_cast<uchar4*>(arg + o) = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
+}
+
+__global__ __launch_bounds__(256) void maxpool133_bwd_kernel(PoolGeom g, FastRow fr, const void* __restrict__ dy, int dt,
+                                                             const uint8_t* __restrict__ arg, void* __restrict__ dx) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= fr.wq) return;
+  const int w = (int)(((float)idx + 0.5f) * fr.inv_cq), c = (idx - w * fr.cq) * VEC;
+  const int row = blockIdx.y;                                     // (b * Ti + t) * Hi + h
+  const int h = row % g.Hi, bt = row / g.Hi;
+  // windows that contain (h, w), in the generic kernel's order (tap index ascending): h even -> oh = h / 2 through tap row 1;
+  // h odd -> oh = (h + 1) / 2 through tap row 0, then oh = (h - 1) / 2 through tap row 2
+  int oh[2], eh[2], ow[2], fw[2];
+  int nh = 0, nw = 0;
+  if ((h & 1) == 0) { oh[0] = h >> 1; eh[0] = 1; nh = 1; }
+  else {
+    if (((h + 1) >> 1) < g.Ho) { oh[nh] = (h + 1) >> 1; eh[nh] = 0; ++nh; }
+    oh[nh] = (h - 1) >> 1; eh[nh] = 2; ++nh;
+  }
+  if ((w & 1) == 0) { ow[0] = w >> 1; fw[0] = 1; nw = 1; }
+  else {
+    if (((w + 1) >> 1) < g.Wo) { ow[nw] = (w + 1) >> 1; fw[nw] = 0; ++nw; }
+    ow[nw] = (w - 1) >> 1; fw[nw] = 2; ++nw;
+  }
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    if (e >= nh) break;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if (f >= nw) break;
+      const int64_t o = (((int64_t)bt * g.Ho + oh[e]) * g.Wo + ow[f]) * g.C + c;
+      const uchar4 am = *reinterpret_cast<const uchar4*>(arg + o);
+      const uint8_t tap = (uint8_t)(eh[e] * 3 + fw[f]);
+      float v[4];
+      ld4(dy, dt, o, v);
+      if (am.x == tap) s[0] += v[0];
+      if (am.y == tap) s[1] += v[1];
+      if (am.z == tap) s[2] += v[2];
+      if (am.w == tap) s[3] += v[3];
+    }
+  }
+  st4(dx, dt, ((int64_t)row * g.Wi + w) * g.C + c, s);
+}
+
+// CSTS_RESAMPLE_FAST=0 (A/B switch) sends everything through the generic kernels
+bool resample_fast_on() {
+  static const bool on = [] { const char* e = getenv("CSTS_RESAMPLE_FAST"); return !(e && e[0] == '0'); }();
+  return on;
+}
+bool fast_row(int row_tokens, int C, int64_t rows, FastRow& fr) {
+  fr.cq = C / VEC;
+  fr.wq = row_tokens * fr.cq;
+  fr.inv_cq = 1.f / (float)fr.cq;
+  // the reciprocal-multiply division is exact while the error of (i + 0.5) / cq stays below 0.5 / cq
+  return resample_fast_on() && C % VEC == 0 && fr.cq <= 256 && fr.wq <= 16384 && rows <= 65535 * (int64_t)1 && rows > 0;
+}
+
 int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 32); }
 // kernels that stage the 27 x HD weight table per workgroup.  Whole-step sweeps on MI355X, same box (elementwise cap /
 // staged cap -> ms per step): 2048 / 2048 -> 25.04, 2048 / 1024 -> 24.97, 8192 / 1024 -> 24.82..24.96, 8192 / 768 -> 24.85,
@@ -1081,6 +1225,14 @@ extern "C" int csts_maxpool_fwd(const csts_pool_geom* a, const void* x, int dt, 
   PoolGeom g; fill_pool(a, g);
   CSTS_REQUIRE(g.To == a->To && g.Ho == a->Ho && g.Wo == a->Wo, "output grid mismatch");
   const int64_t total = (int64_t)g.B * g.To * g.Ho * g.Wo * (g.C / VEC);
+  FastRow fr;
+  const bool k133 = a->st == 1 && a->sh == 2 && a->sw == 2;      // kernel (1, 3, 3), padding (0, 1, 1)
+  if (k133 && fast_row(g.Wo, g.C, (int64_t)g.B * g.To * g.Ho, fr)) {
+    hipLaunchKernelGGL(maxpool133_fwd_kernel, dim3((unsigned)cdiv(fr.wq, 256), (unsigned)(g.B * g.To * g.Ho)), dim3(256), 0, stream,
+                       g, fr, x, dt, y, argmax);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, x, dt, y, argmax);
   CSTS_LAUNCH_CHECK();
   return 0;
@@ -1092,6 +1244,14 @@ extern "C" int csts_maxpool_bwd(const csts_pool_geom* a, const void* dy, int dt,
   PoolGeom g; fill_pool(a, g);
   CSTS_REQUIRE(g.To == a->To && g.Ho == a->Ho && g.Wo == a->Wo, "output grid mismatch");
   const int64_t total = (int64_t)g.B * g.Ti * g.Hi * g.Wi * (g.C / VEC);
+  FastRow fr;
+  const bool k133 = a->st == 1 && a->sh == 2 && a->sw == 2;
+  if (k133 && fast_row(g.Wi, g.C, (int64_t)g.B * g.Ti * g.Hi, fr)) {
+    hipLaunchKernelGGL(maxpool133_bwd_kernel, dim3((unsigned)cdiv(fr.wq, 256), (unsigned)(g.B * g.Ti * g.Hi)), dim3(256), 0, stream,
+                       g, fr, dy, dt, argmax, dx);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, dy, dt, argmax, dx);
   CSTS_LAUNCH_CHECK();
   return 0;
@@ -1115,6 +1275,18 @@ extern "C" int csts_trilinear_bwd(const csts_pool_geom* a, const void* dy, int d
   CSTS_REQUIRE(a->To == a->Ti * a->st && a->Ho == a->Hi * a->sh && a->Wo == a->Wi * a->sw, "output grid must be input*scale");
   UpGeom g{a->B, a->C, a->Ti, a->Hi, a->Wi, a->To, a->Ho, a->Wo};
   const int64_t total = (int64_t)g.B * g.Ti * g.Hi * g.Wi * (g.C / VEC);
+  FastRow fr;
+  const int rt = g.To / g.Ti, rh = g.Ho / g.Hi, rw = g.Wo / g.Wi;
+  if (rt <= 2 && rh <= 2 && rw <= 2 && fast_row(g.Wi, g.C, (int64_t)g.B * g.Ti * g.Hi, fr)) {
+    const dim3 gridf((unsigned)cdiv(fr.wq, 256), (unsigned)(g.B * g.Ti * g.Hi));
+#define TRI_CASE(RT, RH, RW)                                                                                              \
+    if (rt == RT && rh == RH && rw == RW)                                                                                   \
+      hipLaunchKernelGGL((trilinear_bwd_fast_kernel<RT, RH, RW>), gridf, dim3(256), 0, stream, g, fr, dy, dy_dt, dx, dx_dt);
+    TRI_CASE(1, 1, 1) TRI_CASE(1, 1, 2) TRI_CASE(1, 2, 1) TRI_CASE(1, 2, 2) TRI_CASE(2, 1, 1) TRI_CASE(2, 1, 2) TRI_CASE(2, 2, 1) TRI_CASE(2, 2, 2)
+#undef TRI_CASE
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, g, dy, dy_dt, dx, dx_dt);
   CSTS_LAUNCH_CHECK();
   return 0;

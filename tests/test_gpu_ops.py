@@ -874,3 +874,36 @@ def test_linear_with_upsampled_residual_in_the_epilogue(compute, thw, stride, Ci
     assert rel_l2(y1, ref) < TOL[compute]
     with pytest.raises(L.CstsError):       # fine grid sizes must be powers of two
         ops.linear(o, W, b, residual=skip, out_dt=L.F32, compute=compute, res_up=(list(thw), [out[0], out[1], out[2] + 1]))
+
+
+def _resample_outputs():
+    """maxpool_skip / trilinear forward + backward on CSTS-like and ragged grids (called in-process and in a child process)."""
+    outs = []
+    for thw, stride in [((2, 8, 8), (1, 2, 2)), ((3, 7, 5), (1, 2, 2)), ((2, 16, 4), (1, 2, 2))]:
+        x = rnd(2, thw[0] * thw[1] * thw[2], 96, seed=11).requires_grad_(True)
+        y = ops.maxpool_skip(x, thw, stride)
+        y.backward(rnd(*y.shape, seed=12))
+        outs += [y.detach(), x.grad.detach()]
+    for thw, stride in [((2, 8, 8), (1, 2, 2)), ((4, 4, 4), (2, 1, 1)), ((3, 5, 7), (1, 2, 2)), ((2, 3, 4), (2, 2, 2)), ((1, 1, 6), (2, 2, 1))]:
+        x = rnd(2, thw[0] * thw[1] * thw[2], 64, seed=13).requires_grad_(True)
+        y = ops.trilinear(x, thw, stride)
+        y.backward(rnd(*y.shape, seed=14))
+        outs += [y.detach(), x.grad.detach()]
+    return [o.cpu() for o in outs]
+
+
+def test_resampling_specialisations_match_generic(tmp_path):
+    """The closed-form scale-1/2 resampling kernels (maxpool133_fwd / _bwd, trilinear_bwd_fast) against the generic kernels
+    they replace (a child process with CSTS_RESAMPLE_FAST=0): bit-identical outputs and gradients, ragged grids included."""
+    import os
+    import subprocess
+    import sys
+    fast = _resample_outputs()
+    out = str(tmp_path / "generic.pt")
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_ops as t; torch.save(t._resample_outputs(), %r)"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTS_RESAMPLE_FAST="0"), check=True, timeout=600)
+    generic = torch.load(out)
+    assert len(fast) == len(generic)
+    for i, (a, b) in enumerate(zip(fast, generic)):
+        assert torch.equal(a, b), i
