@@ -1,6 +1,7 @@
 // Layout, reduction and loss kernels around the GEMM/attention core of the CSTS path
 // (K1 im2col, K9 token fold, K10 glue, K11 head + losses of SURVEY.md 2.3).  All HBM-bound, fp32 math.
 #include "common.h"
+#include <type_traits>
 
 
 
@@ -46,7 +47,11 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colP g, const void* __re
 // of that) and every col byte once; the element-per-thread form above re-fetched the input ~13x (rocprofv3 FETCH_SIZE).
 template <bool XF32, bool CF32>
 __global__ __launch_bounds__(256) void im2col_strip_kernel(Im2colP g, const void* __restrict__ x, void* __restrict__ col) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];   // [Cin*KT*KH][W]
+  // staged rows [Cin*KT*KH][W] in the OUTPUT dtype (the values are only copied: rounding them here or at the store is the
+  // same), so that a bf16 strip is half the LDS and twice the workgroups per CU
+  typedef typename std::conditional<CF32, float, bf16>::type E;
+  extern __shared__ __attribute__((aligned(16))) char rows_raw[];
+  E* rows = reinterpret_cast<E*>(rows_raw);
   const int nrows = g.Cin * g.KT * g.KH;
   const int tid = threadIdx.x;
   int blk = blockIdx.x;
@@ -54,9 +59,7 @@ __global__ __launch_bounds__(256) void im2col_strip_kernel(Im2colP g, const void
   const int to = blk % g.To;
   const int b = blk / g.To;
   const int W4 = g.W / 4;
-  for (int i = tid; i < nrows * W4; i += 256) {
-    const int r = i / W4, w4 = i - r * W4;
-    const int kh = r % g.KH, kt = (r / g.KH) % g.KT, ci = r / (g.KH * g.KT);
+  auto stage = [&](int r, int w4, int kh, int kt, int ci) {
     const int t = to * g.st - g.pt + kt, h = ho * g.sh - g.ph + kh;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t >= 0 && t < g.T && h >= 0 && h < g.H) {
@@ -67,26 +70,60 @@ __global__ __launch_bounds__(256) void im2col_strip_kernel(Im2colP g, const void
         v = make_float4((float)q[0], (float)q[1], (float)q[2], (float)q[3]);
       }
     }
-    *reinterpret_cast<float4*>(&rows[(int64_t)r * g.W + 4 * w4]) = v;
+    if constexpr (CF32) *reinterpret_cast<float4*>(&rows[(int64_t)r * g.W + 4 * w4]) = v;
+    else {
+      const bf16x4 q = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+      *reinterpret_cast<bf16x4*>(&rows[(int64_t)r * g.W + 4 * w4]) = q;
+    }
+  };
+  if (256 % W4 == 0) {
+    // a thread keeps its column group and walks the rows: (kh, kt, ci) of its row by increments, no division per element
+    const int rstep = 256 / W4, w4 = tid % W4;
+    int r = tid / W4;
+    int kh = r % g.KH, kt = (r / g.KH) % g.KT, ci = r / (g.KH * g.KT);
+#pragma unroll 4
+    for (; r < nrows; r += rstep) {
+      stage(r, w4, kh, kt, ci);
+      kh += rstep;
+      while (kh >= g.KH) {
+        kh -= g.KH;
+        if (++kt == g.KT) { kt = 0; ++ci; }
+      }
+    }
+  } else {
+    for (int i = tid; i < nrows * W4; i += 256) {
+      const int r = i / W4, w4 = i - r * W4;
+      stage(r, w4, r % g.KH, (r / g.KH) % g.KT, r / (g.KH * g.KT));
+    }
   }
   __syncthreads();
   const int K8 = g.Kpad / 8;
   const int64_t row0 = (((int64_t)b * g.To + to) * g.Ho + ho) * g.Wo;
   for (int i = tid; i < g.Wo * K8; i += 256) {
     const int wo = i / K8, k0 = (i - wo * K8) * 8;
-    float v[8];
+    // (row, kw) of k0 by ONE division, then stepped: a division per element made this phase 8 x ~40 vector instructions per
+    // 16 bytes stored and the kernel bound by instruction issue (profiles/r3_im2col_ab.txt)
+    int r = k0 / g.KW, kw = k0 - r * g.KW;
+    const int wbase = wo * g.sw - g.pw;
+    E v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = k0 + j;
-      float val = 0.f;
-      if (k < g.K) {
-        const int r = k / g.KW;                       // row index (ci, kt, kh)
-        const int w = wo * g.sw - g.pw + (k - r * g.KW);
-        if (w >= 0 && w < g.W) val = rows[r * g.W + w];
-      }
+      const int w = wbase + kw;
+      E val = (E)0.f;
+      if (k0 + j < g.K && w >= 0 && w < g.W) val = rows[r * g.W + w];
       v[j] = val;
+      if (++kw == g.KW) { kw = 0; ++r; }
     }
-    st8_from_f32(col, CF32 ? CSTS_F32 : CSTS_BF16, (row0 + wo) * g.Kpad + k0, v);
+    if constexpr (CF32) {
+      float* d = reinterpret_cast<float*>(col) + (row0 + wo) * g.Kpad + k0;
+      reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
+      reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      bf16x8 q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = v[j];
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(col) + (row0 + wo) * g.Kpad + k0) = q;
+    }
   }
 }
 
@@ -634,7 +671,7 @@ extern "C" int csts_im2col(const csts_im2col_geom* g, const void* x, int x_dt, v
   p.Kpad = g->Kpad;
   CSTS_REQUIRE(p.Kpad >= p.K, "Kpad < K");
   CSTS_REQUIRE(p.To == g->To && p.Ho == g->Ho && p.Wo == g->Wo, "output grid mismatch");
-  const size_t strip_lds = (size_t)p.Cin * p.KT * p.KH * p.W * 4;
+  const size_t strip_lds = (size_t)p.Cin * p.KT * p.KH * p.W * (col_dt == CSTS_F32 ? 4 : 2);
   const int64_t strips = (int64_t)p.B * p.To * p.Ho;
   if (strip_lds <= 65536 && p.W % 4 == 0 && p.Kpad % 8 == 0 && strips < ((int64_t)1 << 31) && aligned16(x) &&
       aligned16(col)) {
