@@ -763,21 +763,29 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
   }
 }
 
-// second pass: dK/dV[b, k, head, :] = sum_split ws[...]
+// second pass: dK/dV[b, k, head, :] = sum_split ws[...]; a thread owns 8 consecutive channels of one key row (two 16-byte
+// loads per split, one 16-byte bf16 store; the element-per-thread form spent its time in 64-bit index divisions)
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnP p, int HD) {
   const int64_t per = (int64_t)p.B * p.H * p.Nk * HD;
-  const int64_t total = 2 * per;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  const int H8 = HD / 8;
+  const int64_t total8 = 2 * per / 8;
+  for (int64_t i8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8; i8 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = i8 * 8;
     const int which = idx >= per;
     int64_t e = idx - which * per;
-    float s = 0.f;
-    for (int sp = 0; sp < p.nsplit; ++sp) s += p.ws[((int64_t)which * p.nsplit + sp) * per + e];
-    const int d = (int)(e % HD); e /= HD;
-    const int k = (int)(e % p.Nk); e /= p.Nk;
-    const int head = (int)(e % p.H);
-    const int b = (int)(e / p.H);
-    if (which == 0) st_from_f32(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)k * p.dk_ts + (int64_t)head * p.dk_hs + d, s);
-    else st_from_f32(p.dV, p.dt, (int64_t)b * p.dv_bs + (int64_t)k * p.dv_ts + (int64_t)head * p.dv_hs + d, s);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < p.nsplit; ++sp) {            // splits in order: the sum does not depend on the launch geometry
+      const float4* q = reinterpret_cast<const float4*>(p.ws + ((int64_t)which * p.nsplit + sp) * per + e);
+      const float4 a = q[0], b4 = q[1];
+      s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += b4.x; s[5] += b4.y; s[6] += b4.z; s[7] += b4.w;
+    }
+    int64_t r = e / 8;
+    const int d = (int)(r % H8) * 8; r /= H8;
+    const int k = (int)(r % p.Nk); r /= p.Nk;
+    const int head = (int)(r % p.H);
+    const int b = (int)(r / p.H);
+    if (which == 0) st8_from_f32(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)k * p.dk_ts + (int64_t)head * p.dk_hs + d, s);
+    else st8_from_f32(p.dV, p.dt, (int64_t)b * p.dv_bs + (int64_t)k * p.dv_ts + (int64_t)head * p.dv_hs + d, s);
   }
 }
 
@@ -927,7 +935,7 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
     hipLaunchKernelGGL((attn_bwd_fused_kernel<96>), dim3((unsigned)p.nsplit, (unsigned)(a->B * a->H)), dim3(256), 0, stream, p);
     CSTS_LAUNCH_CHECK();
     if (p.nsplit > 1) {
-      const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim;
+      const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim / 8;
       hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
                          stream, p, a->head_dim);
       CSTS_LAUNCH_CHECK();
@@ -951,7 +959,7 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
     attn_dispatch(K_DKV, a, p, grid, stream);
     CSTS_LAUNCH_CHECK();
     if (p.nsplit > 1) {
-      const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim;
+      const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim / 8;
       hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 4096)), dim3(256), 0,
                          stream, p, a->head_dim);
       CSTS_LAUNCH_CHECK();

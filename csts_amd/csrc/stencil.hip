@@ -568,9 +568,12 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
   float a0[27], a1[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
-  for (int bt = beg + ty; bt < end; bt += blockDim.y) {
-    int b, ot, oh, ow;
-    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+  // (b, ot, oh, ow) of this lane's token: ONE decomposition, then stepped with the token index (three integer divisions per
+  // token were a quarter of this loop's vector instructions)
+  int b = 0, ot = 0, oh = 0, ow = 0;
+  if (beg + ty < end) decomp(beg + ty, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+  const int tstep = blockDim.y;
+  for (int bt = beg + ty; bt < end; bt += tstep) {
     int tof[3], hof[3], xof[3];
     bool tv[3], hv[3], xv[3];
 #pragma unroll
@@ -630,6 +633,14 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
             a0[tap] += __uint_as_float(r << 16) * c0;
             a1[tap] += __uint_as_float(r & 0xffff0000u) * c1;
           }
+    }
+    ow += tstep;
+    while (ow >= g.Wc) {
+      ow -= g.Wc;
+      if (++oh == g.Hc) {
+        oh = 0;
+        if (++ot == g.Tc) { ot = 0; ++b; }
+      }
     }
   }
   // fold the token lanes in a fixed order (lane 0 stores, lanes 1.. add in turn, as straight-line read / add / write batches:
