@@ -165,9 +165,8 @@ class GemmTimer:
                 b.row_scale = pool[k].data_ptr()
             b.workspace, b.ws_bytes, b.colsum = None, 0, None
             calls.append(b)
-        st = torch.cuda.current_stream().cuda_stream
-
         def issue():
+            st = torch.cuda.current_stream().cuda_stream          # inside torch.cuda.graph(...) this is the capturing stream
             for b in calls:
                 if lib.csts_gemm(C.byref(b), st) != 0:
                     raise RuntimeError("csts_gemm failed in the graph-replay roofline pass: " + lib.csts_last_error().decode())
