@@ -188,7 +188,12 @@ template <int V> __device__ __forceinline__ void fmav(float (&acc)[V], const flo
   }
 }
 
-// weights staged as wl[28][HD] fp32: 27 taps + one all-zero row (index 27) that invalid taps point to
+// weights staged as wl[28][HD + WPAD] fp32: 27 taps + one all-zero row (index 27) that invalid taps point to.
+// WPAD: the source is [channel][tap], so the 27 consecutive threads that hold one channel's taps store to addresses one ROW
+// apart -- with a row of HD = 96 or 192 floats (a multiple of the 32 banks) that is a 27-way bank conflict on every staging
+// store (5.3 of the 20 us of the 384-channel k|v launches went into staging two tables: tools/pool_ln_bench.py with the
+// staging compiled out); four floats of padding spread a channel's taps over 8 banks and keep the rows 16-byte aligned.
+constexpr int WPAD = 4;
 // Coalesced global reads, 12 per thread IN FLIGHT before the first LDS store (a plain load -> store loop waits for every
 // load on its own: 11 round trips in a row for a 96-channel table on 256 threads, and this table is the first thing every
 // workgroup of the stencil kernels needs); the (conflicting) transposition is paid in LDS.
@@ -208,12 +213,12 @@ __device__ __forceinline__ void stage_weight_rows(const float* __restrict__ w, f
     }
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
-      if (base + u * nthr < n) wl[k * HD + c] = v[u];
+      if (base + u * nthr < n) wl[k * (HD + WPAD) + c] = v[u];
       k += dr; c += dq;
       if (k >= 27) { k -= 27; ++c; }
     }
   }
-  for (int i = tid; i < HD; i += nthr) wl[27 * HD + i] = 0.f;
+  for (int i = tid; i < HD; i += nthr) wl[27 * (HD + WPAD) + i] = 0.f;
 }
 __device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, float* wl, int HD) {
   stage_weight_rows(w, wl, HD, blockDim.x * blockDim.y, threadIdx.y * blockDim.x + threadIdx.x);
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const v
           const int tap = (tv[kt] && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
           float v[V];
           rawv_cvt<V, FF32>(raw[kh * 3 + kw], v);
-          fmav<V>(acc, v, &wl[tap * g.HD + cw]);
+          fmav<V>(acc, v, &wl[tap * (g.HD + WPAD) + cw]);
         }
     }
     stvt<V, CF32>(bptr<CF32>(coarse, (int64_t)b * g.c_bs), (bt - b * ntok) * cts + c, acc);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   const Geom& g = rg.g;
   const int HD = g.HD, H = g.C / HD;
   {   // stage both slots' weights (tap-major, one zero row each)
-    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows(sl.w[s2], wl + s2 * 28 * HD, HD, blockDim.x, threadIdx.x);
+    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
     __syncthreads();
   }
   const int lane_in = threadIdx.x % GL;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
     }
     const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
-    const float* wls = wl + slot * 28 * HD + c8;
+    const float* wls = wl + slot * 28 * (HD + WPAD) + c8;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // 9 taps (one temporal slice) in flight at a time: a 128-register budget, FOUR workgroups per CU, so the 1024-workgroup
     // launches of the 384-channel stages are resident at once.  (All 27 taps at once -- one memory round trip per item
@@ -344,8 +349,8 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int tap = (tvk && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
-          const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * HD]);
-          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * HD + 4]);
+          const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD)]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD) + 4]);
           float v[8];
           raw8_cvt<F32>(raw[kh * 3 + kw], v);
           acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slot
           const int tap = (vt[a] && vh[e] && vw[f]) ? kt[a] * 9 + kh[e] * 3 + kw[f] : 27;
           float v[V];
           rawv_cvt<V, CF32>(raw[e * NW + f], v);
-          fmav<V>(acc, v, &wl[tap * g.HD + cw]);
+          fmav<V>(acc, v, &wl[tap * (g.HD + WPAD) + cw]);
         }
     }
     stvt<V, FF32>(bptr<FF32>(fine, (int64_t)b * g.f_bs), (bt - b * ntok) * fts + c, acc);
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(256) void dwconv_transposed_s22_kernel(RowGeom rg, 
       raw8_cvt<false>(raw[a][3], i11);
       // weight row of tap (kt, kh, kw); taps that do not exist read the all-zero row 27
       const int t9 = kt[a] * 9;
-      auto wrow = [&](bool ok, int kh, int kw) { return &wl[(ok ? t9 + kh * 3 + kw : 27) * g.HD + cw]; };
+      auto wrow = [&](bool ok, int kh, int kw) { return &wl[(ok ? t9 + kh * 3 + kw : 27) * (g.HD + WPAD) + cw]; };
       const bool v = vt[a];
       fmav<8>(o00, i00, wrow(v, 1, 1));
       fmav<8>(o01, i00, wrow(v, 1, 2));
@@ -1054,7 +1059,7 @@ extern "C" int csts_dwconv_strided(const csts_dwconv_geom* a, const void* fine, 
   const int vec = (!ff && !cf) ? 8 : VEC;     // bf16 on both sides: 8 channels (16 bytes) per thread
   const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc * (a->C / vec);
   const dim3 grid(grid_for_staged(total)), block(256);
-  const size_t sm = (size_t)a->HD * 28 * 4;
+  const size_t sm = (size_t)(a->HD + WPAD) * 28 * 4;
   if (ff && cf) hipLaunchKernelGGL((dwconv_strided_kernel<true, true, 4>), grid, block, sm, stream, rg, fine, weight, coarse);
   else if (!ff && !cf) hipLaunchKernelGGL((dwconv_strided_kernel<false, false, 8>), grid, block, sm, stream, rg, fine, weight, coarse);
   else if (ff) hipLaunchKernelGGL((dwconv_strided_kernel<true, false, 4>), grid, block, sm, stream, rg, fine, weight, coarse);
@@ -1078,7 +1083,7 @@ static int transposed_launch(const csts_dwconv_geom* a, int nslots, const void* 
   const bool f32 = fine_dt == CSTS_F32;
   const int64_t total = (int64_t)a->B * a->Tf * a->Hf * a->Wf * (a->C / (f32 ? VEC : 8));   // bf16: 8 channels per thread
   const dim3 grid(grid_for_staged(total), nslots), block(256);
-  const size_t sm = (size_t)a->HD * 28 * 4;
+  const size_t sm = (size_t)(a->HD + WPAD) * 28 * 4;
   auto nc = [](int st) { return st == 1 ? 3 : (st == 2 ? 2 : 1); };
   if (!f32 && a->sh == 2 && a->sw == 2 && a->Hf % 2 == 0 && a->Wf % 2 == 0) {   // 2 x 2 output blocks (see the kernel)
     const int64_t items = (int64_t)a->B * a->Tf * (a->Hf / 2) * (a->Wf / 2) * (a->C / 8);
@@ -1205,7 +1210,7 @@ extern "C" int csts_pool_ln_fwd(const csts_pool_ln_args* a, hipStream_t stream) 
   const int64_t items = (int64_t)gm->B * gm->Tc * gm->Hc * gm->Wc * (gm->C / gm->HD) * a->nslots;
   const int gpb = 256 / gl;
   const dim3 grid((unsigned)std::min<int64_t>(cdiv(items, gpb), grid_for_staged((int64_t)1 << 40))), block(256);
-  const size_t sm = (size_t)a->nslots * gm->HD * 28 * 4;
+  const size_t sm = (size_t)a->nslots * (gm->HD + WPAD) * 28 * 4;
   const bool f32 = a->dt == CSTS_F32;
   if (gl == 16) {
     if (f32) hipLaunchKernelGGL((pool_ln_fwd_kernel<16, true>), grid, block, sm, stream, rg, sl, a->nslots, a->eps);
