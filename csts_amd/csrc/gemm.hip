@@ -1328,15 +1328,18 @@ extern "C" int csts_gemm_kernel_name(const csts_gemm_args* a, char* buf, int buf
   int v2 = 0, rows = 0;
   if (csts_gemm_plan(a, &v2, &rows, nsplit) != 0) return -1;
   auto tf = [](bool b) { return b ? "true" : "false"; };
+  Params q{};          // what the gemm4 epilogue-form choice looks at
+  q.M = a->M; q.N = a->N; q.K = a->K; q.c_dt = a->c_dt; q.residual = a->residual; q.row_scale = a->row_scale; q.bias = a->bias;
+  q.epilogue = a->epilogue; q.aux = a->aux; q.aux_dt = a->aux_dt;
   if (a->algo % 1000 >= 400 && a->algo % 1000 < 500) {
     *nsplit = 1;
-    return csts_gemm4_name(a->algo % 1000 - 400, buf, buflen) ? 0 : -1;
+    return csts_gemm4_name(q, a->algo % 1000 - 400, buf, buflen) ? 0 : -1;
   }
   if (v2 < 0) {
     snprintf(buf, buflen, "gemm_tiny_kernel<%d, %s>", a->layout, tf(a->K > 16));
     return 0;
   }
-  if (v2 >= 400) return csts_gemm4_name(v2 - 400, buf, buflen) ? 0 : -1;
+  if (v2 >= 400) return csts_gemm4_name(q, v2 - 400, buf, buflen) ? 0 : -1;
   if (v2 >= 30) snprintf(buf, buflen, "gemm3_kernel<%d, %d>", rows / 64, v2 - 30);
   else if (v2)
     snprintf(buf, buflen, "gemm2_kernel<%s, %s, %s, %s, %d, 2>", tf(a->layout != CSTS_GEMM_TN), tf(a->layout == CSTS_GEMM_NT),

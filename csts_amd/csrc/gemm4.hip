@@ -21,6 +21,14 @@
 #include <cstdio>
 #include <type_traits>
 
+// Diagnostics build (-DCSTS_GEMM4_STAMPS, `make stamps`, tools/gemm4_stamps.py): wave 0 of workgroups 0 and 137 records shader-clock
+// stamps around the phases of every k-step and of the epilogue.  No stamp code exists in the library build.
+#ifdef CSTS_GEMM4_STAMPS
+#define G4_STAMP() do { if (stamp_on && nstamp < 500) stamp_buf[nstamp++] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G4_STAMP() do { } while (0)
+#endif
+
 namespace {
 
 template <int WM, int MT, int NT, int S> struct G4 {
@@ -37,16 +45,28 @@ template <int WM, int MT, int NT, int S> struct G4 {
   static_assert(2 * LPT <= 63, "vmcnt immediate");
 };
 
-// KTAIL: K % 64 != 0 (a last k-tile of 16, 32 or 48) is supported; without it the k-loop carries no tail code at all.
-template <int WM, int MT, int NT, int S, bool KTAIL>
+// FORM: the epilogue this instantiation carries (host-selected, gemm4_form): 0 = generic (any epilogue, ragged tiles);
+// 1 .. 4 = ONE straight-line epilogue for problems made of whole tiles with a bf16 C and no residual / row scale:
+// 1 bias, 2 bias + GELU (pre-activation to aux), 3 plain, 4 DGELU (times gelu'(aux)).  One epilogue per kernel keeps the
+// register allocation of the k-loop and of that epilogue inside the 128-register budget of two workgroups per CU (all forms
+// in one kernel: 59 spilled registers).
+template <int WM, int MT, int NT, int S, int FORM>
 __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)) void gemm4_kernel(Params p) {
   typedef G4<WM, MT, NT, S> G;
+  constexpr bool KTAIL = false;        // K % 64 != 0 is not instantiated (the library never picks this kernel for it)
   constexpr int BM = G::BM, BN = G::BN, A_BYTES = G::A_BYTES, STAGE = G::STAGE, NA = G::NA, NB = G::NB, LPT = G::LPT;
   __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it (and all it feeds) scalar
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef CSTS_GEMM4_STAMPS
+  const bool stamp_on = p.stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 137);
+  unsigned long long* stamp_buf = p.stamps + (blockIdx.x == 0 ? 0 : 512);
+  int nstamp = 1;
+  if (stamp_on) stamp_buf[500] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  G4_STAMP();
   const int nk = (int)((p.K + BK2 - 1) / BK2), nk_full = (int)(p.K / BK2), k_tail = KTAIL ? (int)((p.K % BK2) >> 4) : 0;
 
   // this workgroup's tiles: XCD x (= blockIdx.x % 8: workgroups are dealt round-robin over the XCDs) owns a contiguous
@@ -106,6 +126,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
     }
   }
 
+  G4_STAMP();      // prologue issued
   // ---- consumer side.  Fragment row = obase + (lane & 31) with obase % 32 == 0: the swizzle key is a per-lane constant
   const int key = (lane >> 1) & 7, hi = lane >> 5;
   int foff[4];
@@ -134,7 +155,9 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
       if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
       else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
       else wait_vm<0>();
+      G4_STAMP();      // own share landed
       __builtin_amdgcn_s_barrier();                  // every wave's share landed; everyone is done with the previous stage
+      G4_STAMP();      // barrier passed
       const char* As = smem_raw + cstage * STAGE;
       const char* Bs = As + A_BYTES;
       cstage = (cstage + 1 == S) ? 0 : cstage + 1;
@@ -174,6 +197,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
         if (DB == 1 && ks + 1 < NKS) frags(ks + 1, 0);
       }
       if (refill) advance();
+      G4_STAMP();      // fragment reads + MFMAs + refill issue of this k-step
     };
     for (int kt = 0; kt < nk_full; ++kt) kstep(std::integral_constant<int, 4>());
     if constexpr (KTAIL) {                                           // K % 64 = 16, 32 or 48 (K % 16 == 0)
@@ -182,6 +206,94 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
       else if (k_tail == 3) kstep(std::integral_constant<int, 3>());
     }
 
+    G4_STAMP();        // epilogue begins
+    // FAST PATH (whole tiles, bf16 C, no residual / row scale: every library-picked launch except ragged edge tiles).
+    // The generic code below tests bounds and epilogue kinds per 4-column run; the compiler turns that into one branch and
+    // one `s_waitcnt vmcnt(0)` per bias / aux load -- twelve dependent round trips per tile, each of which also drains every
+    // store issued before it (vector memory retires in order).  In-kernel stamps (tools/gemm4_stamps.py, 8192 x 1536 x 384):
+    // 8.5 k cycles of epilogue against 5.9 k of MFMA work per tile, 19.8 k with GELU.  Here the epilogue kind is a compile-time
+    // case, the code is straight-line, and the loads of column unit ni + 1 are issued BEFORE the stores of unit ni, so the wait
+    // for them is a counted one that leaves the stores in flight.  Same arithmetic, same order: bit-identical results.
+    if constexpr (FORM != 0) {
+      bf16* __restrict__ Cb = reinterpret_cast<bf16*>(p.C);
+      bf16* __restrict__ Xb = reinterpret_cast<bf16*>(p.aux);
+      const int hi16 = hi << 4;
+      // forward form: bias (+ GELU with the pre-activation written to aux).  A lane needs bias[c .. c + 3] for the sixteen
+      // 4-column runs it owns -- 48 floats per tile; instead of 12 float4 loads per lane, lane l fetches bias[unit column
+      // (l & 31)] once per 32-column unit and the values travel by ds_bpermute (LDS crossbar, not vector memory)
+      auto fwd = [&](auto gelu_tag) {
+        constexpr bool GELU = decltype(gelu_tag)::value;
+        const float* __restrict__ bias = p.bias;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int64_t m = m0 + mi * 32;
+          float bu[NT];
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) bu[ni] = bias[n0 - 4 * hi + ni * 32 + (lane & 31)];
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {          // a pair of runs = one 16-byte store: eight values live at a time
+              f32x4 o[2];
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int q = 2 * pr + qq;
+                  const float bq = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(hi16 + 4 * (8 * q + j), __builtin_bit_cast(int, bu[ni])));
+                  o[qq][j] = bq + acc[mi][ni][4 * q + j];
+                }
+              if constexpr (GELU) {
+                if (Xb != nullptr) st4x2_bf16_whole(Xb, m * p.ldaux + n0 + ni * 32, o[0], o[1], pr, hi);
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) o[qq][j] = gelu_fast(o[qq][j]);
+              }
+              st4x2_bf16_whole(Cb, m * p.ldc + n0 + ni * 32, o[0], o[1], pr, hi);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      };
+      // data-gradient form: no bias; DGELU multiplies by gelu'(aux): the aux runs of unit ni + 1 are requested before the
+      // stores of unit ni
+      auto bwd = [&](auto dgelu_tag) {
+        constexpr bool DGELU = decltype(dgelu_tag)::value;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const int64_t m = m0 + mi * 32;
+          bf16x4 hv[2][4];
+          auto loads = [&](int ni, int buf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[buf][q] = *reinterpret_cast<const bf16x4*>(Xb + m * p.ldaux + n0 + ni * 32 + 8 * q);
+          };
+          if constexpr (DGELU) loads(0, 0);
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni) {
+            const int cur = ni & 1;
+            if constexpr (DGELU) { if (ni + 1 < NT) loads(ni + 1, cur ^ 1); }
+            f32x4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float v = 0.f + acc[mi][ni][4 * q + j];
+                if constexpr (DGELU) v *= dgelu_fast((float)hv[cur][q][j]);
+                o[q][j] = v;
+              }
+              if constexpr (DGELU) __builtin_amdgcn_sched_barrier(0);
+            }
+            st4x4_bf16_whole(Cb, m * p.ldc + n0 + ni * 32, o, hi);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      if constexpr (FORM == 2) fwd(std::true_type());
+      else if constexpr (FORM == 1) fwd(std::false_type());
+      else if constexpr (FORM == 4) bwd(std::true_type());
+      else bwd(std::false_type());
+    } else {
     // ---------------- epilogue straight from the accumulators (same arithmetic order as gemm2_kernel / gemm3_kernel)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
@@ -230,21 +342,47 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
         st4x4(p.C, p.c_dt, m * p.ldc + n0 + ni * 32, o, mok, n0 + ni * 32, p.N, hi);
       }
     }
+    }
+    G4_STAMP();        // epilogue issued (stores in flight)
   }
   wait_vm<0>();
+  G4_STAMP();          // everything drained
+#ifdef CSTS_GEMM4_STAMPS
+  if (stamp_on) { stamp_buf[0] = (unsigned long long)nstamp; stamp_buf[501] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
-template <int WM, int MT, int NT, int S, bool TAIL_OK>
+// which epilogue form (see gemm4_kernel) a problem takes on BM x BN tiles
+int gemm4_form(const Params& p, int BM, int BN) {
+  if (p.M % BM != 0 || p.N % BN != 0 || p.c_dt != CSTS_BF16 || p.residual != nullptr || p.row_scale != nullptr) return 0;
+  if (p.bias != nullptr) {
+    if (p.epilogue == CSTS_EPI_NONE) return 1;
+    if (p.epilogue == CSTS_EPI_GELU && p.aux != nullptr && p.aux_dt == CSTS_BF16) return 2;
+    return 0;
+  }
+  if (p.epilogue == CSTS_EPI_NONE) return 3;
+  if (p.epilogue == CSTS_EPI_DGELU && p.aux != nullptr && p.aux_dt == CSTS_BF16) return 4;
+  return 0;
+}
+
+template <int WM, int MT, int NT, int S, bool FORMS>
 bool launch4(Params p, int wpc, hipStream_t s) {
   typedef G4<WM, MT, NT, S> G;
+  if (p.K % BK2 != 0) return false;
   const int64_t ntiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN);
   p.ntiles = ntiles;
   p.ntiles_n = (int)cdiv(p.N, G::BN);
   if (wpc <= 0 || wpc > G::WG) wpc = G::WG;
   const int64_t g = std::min<int64_t>(cdiv(ntiles, 8) * 8, (int64_t)256 * wpc);
-  if (p.K % BK2 == 0) hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, false>), dim3((unsigned)g), dim3(G::NTHR), 0, s, p);
-  else if (TAIL_OK) hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, TAIL_OK>), dim3((unsigned)g), dim3(G::NTHR), 0, s, p);
-  else return false;
+  const dim3 grid((unsigned)g), block(G::NTHR);
+  const int form = FORMS ? gemm4_form(p, G::BM, G::BN) : 0;
+  if constexpr (FORMS) {
+    if (form == 1) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 1>), grid, block, 0, s, p); return true; }
+    if (form == 2) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 2>), grid, block, 0, s, p); return true; }
+    if (form == 3) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 3>), grid, block, 0, s, p); return true; }
+    if (form == 4) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 4>), grid, block, 0, s, p); return true; }
+  }
+  hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 0>), grid, block, 0, s, p);
   return true;
 }
 
@@ -253,23 +391,27 @@ struct Variant { int code, wm, mt, nt, s; };
 //            3 = 128x128, 6 = 128x192, 4 = 128x256 (8 waves, wave tile 32 x 64/96/128); 5 = 128x128 on 4 waves (wave tile 64 x 64);
 // (4-wave workgroups with 64 x 96 / 64 x 128 / 128 x 64 wave tiles -- fewer LDS fragment bytes per MFMA -- measured 10-90 %
 //  slower than the 8-wave 128 x 192 variant on every CSTS shape and were removed: profiles/r2_gemm4_lab2.txt)
+// last column: the specialised epilogue forms exist (the variants the library picks by itself)
 #define G4_VARIANTS(X) \
-  X(2, 4, 2, 2, 2) X(3, 4, 2, 2, 3) X(12, 4, 2, 3, 2) X(22, 4, 2, 4, 2) \
-  X(32, 4, 1, 2, 2) X(33, 4, 1, 2, 3) X(34, 4, 1, 2, 4) X(62, 4, 1, 3, 2) X(63, 4, 1, 3, 3) X(42, 4, 1, 4, 2) \
-  X(52, 2, 2, 2, 2)
+  X(2, 4, 2, 2, 2, false) X(3, 4, 2, 2, 3, false) X(12, 4, 2, 3, 2, false) X(22, 4, 2, 4, 2, false) \
+  X(32, 4, 1, 2, 2, true) X(33, 4, 1, 2, 3, true) X(34, 4, 1, 2, 4, false) X(62, 4, 1, 3, 2, true) X(63, 4, 1, 3, 3, true) X(42, 4, 1, 4, 2, false) \
+  X(52, 2, 2, 2, 2, false)
 
 }  // namespace
 
-bool csts_gemm4_launch(const csts_gemm_params& p, const csts_gemm_args* a, int variant, int wpc, hipStream_t s) {
-  (void)a;
-#define X(code, wm, mt, nt, st) if (variant == code) return launch4<wm, mt, nt, st, false>(p, wpc, s);
+bool csts_gemm4_launch(const csts_gemm_params& p0, const csts_gemm_args* a, int variant, int wpc, hipStream_t s) {
+  csts_gemm_params p = p0;
+  p.stamps = (a != nullptr && a->workspace != nullptr && a->ws_bytes >= 8192) ? reinterpret_cast<unsigned long long*>(a->workspace) : nullptr;
+#define X(code, wm, mt, nt, st, forms) if (variant == code) return launch4<wm, mt, nt, st, forms>(p, wpc, s);
   G4_VARIANTS(X)
 #undef X
   return false;
 }
 
-bool csts_gemm4_name(int variant, char* buf, int buflen) {
-#define X(code, wm, mt, nt, st) if (variant == code) { snprintf(buf, buflen, "gemm4_kernel<%d, %d, %d, %d, false>", wm, mt, nt, st); return true; }
+// the kernel csts_gemm4_launch starts for these parameters, as rocprofv3 prints it
+bool csts_gemm4_name(const csts_gemm_params& p, int variant, char* buf, int buflen) {
+#define X(code, wm, mt, nt, st, forms) if (variant == code) { \
+    snprintf(buf, buflen, "gemm4_kernel<%d, %d, %d, %d, %d>", wm, mt, nt, st, forms ? gemm4_form(p, wm * 32 * mt, 64 * nt) : 0); return true; }
   G4_VARIANTS(X)
 #undef X
   return false;

@@ -43,6 +43,7 @@ __device__ __forceinline__ f32x4 ld4_as_f32(const void* p, int dt, int64_t i) {
 // adjacent runs of the same row, so v_permlane32_swap pairs them into 8 contiguous columns per lane -> one 16-byte
 // store per two runs (lower half-wave: columns 16 p .. + 7, upper: 16 p + 8 .. + 15, relative to the unit's first column).
 // Must be called with all lanes active (the swap is a cross-lane exchange); `rowok` / N only mask the stores.
+// (st4x4_bf16_whole below: the same stores for a tile that lies wholly inside the matrix, no tests)
 __device__ __forceinline__ void st4x4(void* base, int dt, int64_t at, const f32x4 (&o)[4], bool rowok, int64_t c0, int64_t N, int hi) {
   if (dt == CSTS_F32) {
 #pragma unroll
@@ -129,9 +130,40 @@ __device__ __forceinline__ void res_up_load(const Params& p, const ResUpRow& r, 
   }
 }
 
+// st4x4 for bf16 and a tile wholly inside the matrix: two unconditional 16-byte stores per lane (straight-line code: the
+// epilogue's vector-memory waits can then be counted ones)
+__device__ __forceinline__ void st4x4_bf16_whole(bf16* base, int64_t at, const f32x4 (&o)[4], int hi) {
+  uint2 pk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bf16x4 b = {(bf16)o[q][0], (bf16)o[q][1], (bf16)o[q][2], (bf16)o[q][3]};
+    pk[q] = __builtin_bit_cast(uint2, b);
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    uint2 a = pk[2 * pr], b = pk[2 * pr + 1];
+    const auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    a.x = rx[0]; b.x = rx[1]; a.y = ry[0]; b.y = ry[1];
+    *reinterpret_cast<uint4*>(base + at - 4 * hi + 16 * pr + 8 * hi) = make_uint4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// one pair of runs (columns 16 pr .. 16 pr + 15 of a 32-column unit): the lower half-wave ends up with columns 16 pr .. + 7
+// of its row, the upper one with 16 pr + 8 .. + 15 -> ONE 16-byte store per lane.  `at` = row * ld + unit column 0 + 4 * hi.
+__device__ __forceinline__ void st4x2_bf16_whole(bf16* base, int64_t at, const f32x4& o0, const f32x4& o1, int pr, int hi) {
+  const bf16x4 b0 = {(bf16)o0[0], (bf16)o0[1], (bf16)o0[2], (bf16)o0[3]};
+  const bf16x4 b1 = {(bf16)o1[0], (bf16)o1[1], (bf16)o1[2], (bf16)o1[3]};
+  uint2 a = __builtin_bit_cast(uint2, b0), b = __builtin_bit_cast(uint2, b1);
+  const auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+  const auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+  a.x = rx[0]; b.x = rx[1]; a.y = ry[0]; b.y = ry[1];
+  *reinterpret_cast<uint4*>(base + at - 4 * hi + 16 * pr + 8 * hi) = make_uint4(a.x, a.y, b.x, b.y);
+}
+
 }  // namespace
 
 // gemm4.hip: persistent NT kernel, 256-row (8-wave) and 128-row (4- or 8-wave) tiles, LDS-DMA ring.
 // variant = 10 * shape + stages (see gemm4.hip); returns false when the variant does not exist.
 bool csts_gemm4_launch(const csts_gemm_params& p, const csts_gemm_args* a, int variant, int wpc, hipStream_t s);
-bool csts_gemm4_name(int variant, char* buf, int buflen);
+bool csts_gemm4_name(const csts_gemm_params& p, int variant, char* buf, int buflen);
