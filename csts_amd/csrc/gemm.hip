@@ -541,6 +541,46 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
     }
     __syncthreads();
     if (n >= p.N) continue;
+    // Residual-stream form (fp32 C = (acc + bias) * row_scale + residual: proj / fc2 forward, skip projections), whole row
+    // groups: straight-line code with every load of the group -- the residual runs and the per-row drop-path scales -- issued
+    // BEFORE its first store.  The generic loop below loads, waits and stores row by row: vector memory retires in order, so
+    // the wait for row i + 1's residual is also a wait for row i's stores (one full store round trip per row).
+    if (p.residual != nullptr && p.res_row_mod == 0 && p.ru_To == 0 && p.epilogue == CSTS_EPI_NONE && p.split_k == 1 &&
+        p.c_dt == CSTS_F32 && p.r_dt == CSTS_F32 && m0 + g * 64 + 64 <= p.M) {            // block-uniform
+      constexpr int NI = 1024 / NTHR;
+      const float* __restrict__ res = reinterpret_cast<const float*>(p.residual);
+      float* __restrict__ Cf = reinterpret_cast<float*>(p.C);
+      float4 r0[NI], r1[NI];
+      float sc[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int64_t m = m0 + g * 64 + (tid >> 4) + (NTHR / 16) * i;
+        const float4* q = reinterpret_cast<const float4*>(res + m * p.ldr + n);
+        r0[i] = q[0]; r1[i] = q[1];
+        sc[i] = p.row_scale != nullptr ? p.row_scale[m / p.rows_per_scale] : 1.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = (tid >> 4) + (NTHR / 16) * i;
+        const int64_t m = m0 + g * 64 + row;
+        const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col + 4]);
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float rr[8] = {r0[i].x, r0[i].y, r0[i].z, r0[i].w, r1[i].x, r1[i].y, r1[i].z, r1[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias[j];
+        if (p.row_scale != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= sc[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        float4* d = reinterpret_cast<float4*>(Cf + m * p.ldc + n);
+        d[0] = make_float4(v[0], v[1], v[2], v[3]);
+        d[1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 1024 / NTHR; ++i) {
       const int row = (tid >> 4) + (NTHR / 16) * i;                         // 0..63 inside the group
@@ -798,6 +838,33 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
 
     // ---------------- epilogue straight from the accumulators (same arithmetic order as gemm2_kernel)
     G3_STAMP();
+    // residual-stream form on a whole tile (see gemm2_kernel): all eight residual runs of the lane's row first, then the
+    // arithmetic and the eight 16-byte stores -- no load behind a store
+    if (MT == 1 && p.residual != nullptr && p.res_row_mod == 0 && p.ru_To == 0 && p.epilogue == CSTS_EPI_NONE &&
+        p.c_dt == CSTS_F32 && p.r_dt == CSTS_F32 && (t / p.ntiles_n) * BM3 + BM3 <= p.M && (t % p.ntiles_n) * 128 + 128 <= p.N) {
+      const float* __restrict__ res = reinterpret_cast<const float*>(p.residual);
+      float* __restrict__ Cf = reinterpret_cast<float*>(p.C);
+      const int64_t m = m0;
+      f32x4 rr[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rr[ni][q] = *reinterpret_cast<const f32x4*>(res + m * p.ldr + n0 + ni * 32 + 8 * q);
+      const float rsc = p.row_scale != nullptr ? p.row_scale[m / p.rows_per_scale] : 1.f;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[0][ni][4 * q + j] + bias4[ni][q][j];
+          if (p.row_scale != nullptr) v *= rsc;
+          v += rr[ni][q];
+          *reinterpret_cast<f32x4*>(Cf + m * p.ldc + n0 + ni * 32 + 8 * q) = v;
+        }
+      G3_STAMP();
+      continue;
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int64_t m = m0 + mi * 32;
