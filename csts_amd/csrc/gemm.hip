@@ -581,6 +581,31 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
       }
       continue;
     }
+    // data gradient through GELU (v *= gelu'(aux), bf16 aux): the four pre-activation runs of the group first, then
+    // arithmetic and stores (same reason as above)
+    if (p.epilogue == CSTS_EPI_DGELU && p.aux_dt == CSTS_BF16 && p.residual == nullptr && p.row_scale == nullptr && p.split_k == 1 &&
+        m0 + g * 64 + 64 <= p.M) {                                                        // block-uniform
+      constexpr int NI = 1024 / NTHR;
+      const bf16* __restrict__ hx = reinterpret_cast<const bf16*>(p.aux);
+      bf16x8 hv[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int64_t m = m0 + g * 64 + (tid >> 4) + (NTHR / 16) * i;
+        hv[i] = *reinterpret_cast<const bf16x8*>(hx + m * p.ldaux + n);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = (tid >> 4) + (NTHR / 16) * i;
+        const int64_t m = m0 + g * 64 + row;
+        const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col + 4]);
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] + bias[j]) * dgelu_fast((float)hv[i][j]);
+        st8_from_f32(p.C, p.c_dt, m * p.ldc + n, v);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 1024 / NTHR; ++i) {
       const int row = (tid >> 4) + (NTHR / 16) * i;                         // 0..63 inside the group
