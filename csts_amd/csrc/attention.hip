@@ -13,7 +13,27 @@
 // v_mfma_f32_32x32x2_f32 with the accumulator registers consumed directly as the next B operand.
 // Softmax statistics, LSE and delta are fp32.  dK/dV are reduced over query splits by a second,
 // deterministic pass (no atomics).
+#include <type_traits>
+#include <utility>
 #include "common.h"
+
+// Diagnostics build (-DCSTS_ATTN_STAMPS, `make stamps`, tools/attn_stamps.py): thread 0 of workgroup (0,0,0) of the dK/dV
+// kernel records shader-clock stamps around the phases of every query tile.  No stamp code exists in the library build.
+#ifdef CSTS_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[4096];
+#define AT_STAMP() do { if (stamp_on && nstamp < 4000) g_attn_stamps[nstamp++] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int csts_debug_attn_stamps(unsigned long long* dst_host) {
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 4096);
+}
+#define AT_STAMP_P() do { if (stamp_on && *nstamp_p < 4000) g_attn_stamps[(*nstamp_p)++] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define AT_STAMP_PARAMS , bool stamp_on = false, int* nstamp_p = nullptr
+#define AT_STAMP_ARGS , stamp_on, &nstamp
+#else
+#define AT_STAMP() do { } while (0)
+#define AT_STAMP_P() do { } while (0)
+#define AT_STAMP_PARAMS
+#define AT_STAMP_ARGS
+#endif
 
 namespace {
 
@@ -60,6 +80,12 @@ template <int HD> struct RowFrag<HD, true> {
     for (int s = 0; s < HD / 2; ++s) f[s] = p[2 * s + h];
   }
 };
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
 template <bool F32> struct El;
 template <> struct El<false> { typedef bf16 T; };
@@ -149,6 +175,56 @@ __device__ __forceinline__ void pv(f32x16 (&out)[HD / 32], const typename El<F32
   }
 }
 
+// The same two products with their LDS operands read into registers AHEAD of the MFMAs (bf16).  A workgroup of the
+// backward kernels is one wave per SIMD: a ds_read issued right in front of the MFMA that consumes it (what the compiler
+// schedules by itself) exposes the whole LDS latency once per MFMA, and the matrix pipe sat idle ~80 % of the time.
+template <int HD> struct ScoreOps {          // A operands of score(): 32 rows x HD of one staged tile
+  bf16x8 a[HD / 16];
+  __device__ __forceinline__ void read(const bf16* X, int LD, int lane) {
+    const bf16* Xb = X + (lane & 31) * LD + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) a[s] = *reinterpret_cast<const bf16x8*>(Xb + 16 * s);
+  }
+};
+template <int HD>
+__device__ __forceinline__ void score_regs(f32x16& acc, const ScoreOps<HD>& x, const RowFrag<HD, false>& fr) {
+#pragma unroll
+  for (int s = 0; s < HD / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.a[s], fr.b[s], acc, 0, 0, 0);
+}
+template <int HD> struct PvOps {             // transposed A operands of pv(): the same 32 rows, read column-wise
+  s16x4 t[2][HD / 32][2];
+  __device__ __forceinline__ void read(const bf16* Y, int LD, int lane) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int h = lane >> 5, g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16* Yb = Y + (16 * s + 4 * h + qq) * LD + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+      for (int d = 0; d < HD / 32; ++d) {
+        t[s][d][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 32 * d));
+        t[s][d][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 32 * d + 8 * LD));
+      }
+    }
+  }
+};
+template <int HD>
+__device__ __forceinline__ void pv_regs(f32x16 (&out)[HD / 32], const PvOps<HD>& y, const f32x16& P) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 bp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bp[j] = (bf16)P[8 * s + j];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d) {
+      const bf16x4 b0 = __builtin_bit_cast(bf16x4, y.t[s][d][0]), b1 = __builtin_bit_cast(bf16x4, y.t[s][d][1]);
+      bf16x8 a;
+      a[0] = b0[0]; a[1] = b0[1]; a[2] = b0[2]; a[3] = b0[3];
+      a[4] = b1[0]; a[5] = b1[1]; a[6] = b1[2]; a[7] = b1[3];
+      out[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, out[d], 0, 0, 0);
+    }
+  }
+}
+
 // store a transposed accumulator: lane owns row `tok`, 4 consecutive columns per register quad
 template <int HD>
 __device__ __forceinline__ void store_rows(void* dst, int dt, int64_t off, const f32x16 (&acc)[HD / 32], float mul, int h) {
@@ -196,48 +272,92 @@ template <int HD, int ROWS> struct TileStage {
       *reinterpret_cast<uint4*>(S + row * LD + col) = r[i];
     }
   }
+  // the same load with this thread's element offsets (row * ts + col: tile-invariant) computed once by offsets(): inside a
+  // tile loop the 64-bit address arithmetic of gload() was ~100 cycles per chunk (in-kernel stamps, tools/attn_stamps.py)
+  int off[NCH];
+  __device__ __forceinline__ void offsets(int64_t ts, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, col = (c - row * CPR) * 8;
+      off[i] = (int)(row * ts) + col;
+    }
+  }
+  __device__ __forceinline__ void gload_at(const bf16* tile0, int row0, int lim, int tid) {   // tile0 = src + base + row0 * ts
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int row = (tid + 256 * i) / CPR;
+      r[i] = (row0 + row < lim) ? *reinterpret_cast<const uint4*>(tile0 + off[i]) : make_uint4(0, 0, 0, 0);
+    }
+  }
 };
 
 // Iterate over ROWS-row tiles [row_beg, row_end) of two tensors X, Y staged in LDS and call body(Xs, Ys, row0).
 // bf16: the next tile is prefetched into registers while the current one is consumed, LDS is double-buffered
 // (one barrier per tile, the HBM round trip hides under the MFMAs).  f32 (parity mode): synchronous, single buffer.
-template <int HD, int ROWS, int LDX, int LDY, bool F32, typename Body>
+// STATS: two per-row fp32 vectors (LSE and delta of the tile's rows) travel with the tiles: 2 * ROWS threads prefetch one
+// float each and the body finds them in LDS (s1 = stats, s2 = stats + ROWS; rows past row_end repeat the last row).  The
+// consumer runs one wave per SIMD, so a global load issued inside the body is an exposed L2 round trip per tile.
+template <int HD, int ROWS, int LDX, int LDY, bool F32, bool STATS = false, typename Body>
 __device__ __forceinline__ void tile_loop(typename El<F32>::T* smem, const void* X, int64_t xbase, int64_t xts,
                                           const void* Y, int64_t ybase, int64_t yts, int row_beg, int row_end, int tid,
-                                          Body&& body) {
+                                          Body&& body, const float* S1 = nullptr, const float* S2 = nullptr AT_STAMP_PARAMS) {
   typedef typename El<F32>::T T;
+  [[maybe_unused]] float snext = 0.f;
+  auto sload = [&](int r0) {
+    if constexpr (STATS) {
+      if (tid < 2 * ROWS) {
+        const float* sp = tid < ROWS ? S1 : S2;
+        snext = sp[min(r0 + (tid < ROWS ? tid : tid - ROWS), row_end - 1)];
+      }
+    }
+  };
   if constexpr (F32) {
+    float* stats = reinterpret_cast<float*>(smem + ROWS * (LDX + LDY));
     for (int row0 = row_beg; row0 < row_end; row0 += ROWS) {
       __syncthreads();
+      sload(row0);
       load_tile<HD, ROWS, LDX, true>(smem, X, xbase, xts, row0, row_end, tid);
       load_tile<HD, ROWS, LDY, true>(smem + ROWS * LDX, Y, ybase, yts, row0, row_end, tid);
+      if constexpr (STATS) { if (tid < 2 * ROWS) stats[tid] = snext; }
       __syncthreads();
-      body(smem, smem + ROWS * LDX, row0);
+      if constexpr (STATS) body(smem, smem + ROWS * LDX, row0, stats);
+      else body(smem, smem + ROWS * LDX, row0);
     }
   } else {
     constexpr int TILE = ROWS * (LDX + LDY);
+    float* stats = reinterpret_cast<float*>(smem + 2 * TILE);      // [2 buffers][2][ROWS]
     TileStage<HD, ROWS> sx, sy;
+    sx.offsets(xts, tid);
+    sy.offsets(yts, tid);
     sx.gload(X, xbase, xts, row_beg, row_end, tid);
     sy.gload(Y, ybase, yts, row_beg, row_end, tid);
+    sload(row_beg);
     sx.lstore(smem, LDX, tid);
     sy.lstore(smem + ROWS * LDX, LDY, tid);
+    if constexpr (STATS) { if (tid < 2 * ROWS) stats[tid] = snext; }
     if (row_beg + ROWS < row_end) {
       sx.gload(X, xbase, xts, row_beg + ROWS, row_end, tid);
       sy.gload(Y, ybase, yts, row_beg + ROWS, row_end, tid);
+      sload(row_beg + ROWS);
     }
     __syncthreads();
     int it = 0;
     for (int row0 = row_beg; row0 < row_end; row0 += ROWS, ++it) {
       T* cur = smem + (it & 1) * TILE;
       T* nxt = smem + ((it + 1) & 1) * TILE;
-      body(cur, cur + ROWS * LDX, row0);
+      if constexpr (STATS) body(cur, cur + ROWS * LDX, row0, stats + (it & 1) * 2 * ROWS);
+      else body(cur, cur + ROWS * LDX, row0);
       if (row0 + ROWS < row_end) {
         sx.lstore(nxt, LDX, tid);
         sy.lstore(nxt + ROWS * LDX, LDY, tid);
+        if constexpr (STATS) { if (tid < 2 * ROWS) stats[((it + 1) & 1) * 2 * ROWS + tid] = snext; }
+        AT_STAMP_P();                          // prefetched tile has arrived and is on its way into LDS
         if (row0 + 2 * ROWS < row_end) {
-          sx.gload(X, xbase, xts, row0 + 2 * ROWS, row_end, tid);
-          sy.gload(Y, ybase, yts, row0 + 2 * ROWS, row_end, tid);
+          sx.gload_at(reinterpret_cast<const bf16*>(X) + xbase + (int64_t)(row0 + 2 * ROWS) * xts, row0 + 2 * ROWS, row_end, tid);
+          sy.gload_at(reinterpret_cast<const bf16*>(Y) + ybase + (int64_t)(row0 + 2 * ROWS) * yts, row0 + 2 * ROWS, row_end, tid);
+          sload(row0 + 2 * ROWS);
         }
+        AT_STAMP_P();                          // next loads issued
       }
       __syncthreads();
     }
@@ -284,6 +404,31 @@ __device__ __forceinline__ void stage_rows_out(bf16* S, void* dst, int64_t base,
 #pragma unroll 2
   for (int c = tid; c < 128 * CPR; c += 256) {
     const int row = c / CPR, col = (c - row * CPR) * 8;
+    if (row0 + row < nrows_valid)
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(dst) + base + (int64_t)(row0 + row) * ts + col) =
+          *reinterpret_cast<const uint4*>(S + row * LDS_LD + col);
+  }
+}
+
+// same, for ONE wave's 32 rows (rows 32 w .. 32 w + 31 of the staging tile are written and read back by wave w only: LDS
+// executes a wave's instructions in order, so no barrier is needed)
+template <int HD>
+__device__ __forceinline__ void stage_rows_out_wave(bf16* S, void* dst, int64_t base, int64_t ts, int row0, int nrows_valid,
+                                                    const f32x16 (&acc)[HD / 32], float mul, int w, int lane) {
+  constexpr int CPR = HD / 8, LDS_LD = HD + 8;
+  const int h = lane >> 5, row_in_tile = w * 32 + (lane & 31);
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      bf16x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (bf16)(acc[d][4 * rq + j] * mul);
+      *reinterpret_cast<bf16x4*>(S + row_in_tile * LDS_LD + d * 32 + 8 * rq + 4 * h) = v;
+    }
+#pragma unroll
+  for (int i = 0; i < 32 * CPR / 64; ++i) {
+    const int c = lane + 64 * i, r = c / CPR, col = (c - r * CPR) * 8, row = w * 32 + r;
     if (row0 + row < nrows_valid)
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(dst) + base + (int64_t)(row0 + row) * ts + col) =
           *reinterpret_cast<const uint4*>(S + row * LDS_LD + col);
@@ -515,7 +660,10 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
 // ---------------------------------------------------------------------------------------------- dK, dV
 // (a 256-register budget for two workgroups per CU, as attn_fwd / attn_dq have, was measured 2-4 % slower here: this
 // kernel carries dK, dV, the key fragments and the score tiles and spills)
-template <int HD, bool F32>
+// SLOW: frame mask and / or a ragged last query tile (N_q not a multiple of the tile), as per-element tests.  A kernel-level
+// switch on purpose: with both forms of the tile body inside one loop the register allocator split the dK / dV accumulators
+// at the join and copied 96 registers between the VGPR and AGPR halves around the MFMAs of every tile.
+template <int HD, bool F32, bool SLOW>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   typedef typename El<F32>::T T;
   typedef Cfg<HD, F32> C;
@@ -540,65 +688,124 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   const int64_t qbase = (int64_t)b * p.q_bs + (int64_t)head * p.q_hs;
   const int64_t dobase = (int64_t)b * p.do_bs + (int64_t)head * p.do_hs;
   const int qbeg = split * p.q_chunk, qend = min(p.Nq, qbeg + p.q_chunk);
-  const float* Lrow = p.LSE + ((int64_t)b * p.H + head) * p.Nq;     // per-query statistics: wave-uniform (broadcast) loads
+  const float* Lrow = p.LSE + ((int64_t)b * p.H + head) * p.Nq;     // per-query statistics: staged with the tiles
   const float* Drow = p.delta + ((int64_t)b * p.H + head) * p.Nq;
   const int fk = frame_of(p, ki);
-  const bool stats_vec = (((uintptr_t)Lrow | (uintptr_t)Drow) & 15) == 0 && (qbeg & 3) == 0;
+#ifdef CSTS_ATTN_STAMPS
+  const bool stamp_on = tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  int nstamp = 1;
+#endif
+  AT_STAMP();
 
-  tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
-                                                 [&](const T* Qs, const T* dOs, int q0) {
-    const bool slow = (q0 + QBLK > qend) || p.mask_mode != 0;   // wave-uniform
-    // statistics of the whole tile first: the kernel runs one wave per SIMD, so these L2 round trips would otherwise be
-    // exposed once per 32-query unit
-    float4 L4a[QT][4], D4a[QT][4];
-    if (!(slow || !stats_vec)) {
+  tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32, true>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
+                                                       [&](const T* Qs, const T* dOs, int q0, const float* Ls) {
+    const float* Ds = Ls + QBLK;
+    AT_STAMP();                                // tile body begins (previous tile's staging + barrier done)
+    auto units = [&](auto slow_tag) {
+    constexpr bool slow = decltype(slow_tag)::value;
+    // P = exp2(S * scale - LSE), dS = P * (dP - delta); the 4 registers of a quad are 4 consecutive queries: one 16-byte
+    // (broadcast) LDS read of LSE / delta each
+    auto softmax_bwd = [&](f32x16& S, f32x16& dP, int qt) {
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
+      for (int j = 0; j < 4; ++j) {
+        const int qo = qt * 32 + 8 * j + 4 * h;
+        const float4 L4 = *reinterpret_cast<const float4*>(Ls + qo), D4 = *reinterpret_cast<const float4*>(Ds + qo);
+        const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = q0 + qt * 32 + 8 * j + 4 * h;
-          L4a[qt][j] = *reinterpret_cast<const float4*>(Lrow + q);
-          D4a[qt][j] = *reinterpret_cast<const float4*>(Drow + q);
-        }
-    }
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-
-      f32x16 S, dP;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
-      score<HD, C::LD_ROW, F32>(S, Qs + qt * 32 * C::LD_ROW, kf, lane);
-      score<HD, C::LD_ROW, F32>(dP, dOs + qt * 32 * C::LD_ROW, vf, lane);
-      if (slow || !stats_vec) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int q = q0 + qt * 32 + rowoff(r, h);
-          // clamped (invalid) key lanes are never stored, so they need no masking
-          const bool dead = (q >= qend) | ((p.mask_mode != 0) & (frame_of(p, q) != fk));
-          const int qc = q < qend ? q : qend - 1;
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], p.scale_log2, -Lrow[qc]));
-          const float pr = dead ? 0.f : e;
-          S[r] = pr;
-          dP[r] = pr * (dP[r] - Drow[qc]);
-        }
-      } else {
-        // the 4 registers of a quad are 4 consecutive queries: one 16-byte load of LSE / delta each
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 L4 = L4a[qt][j], D4 = D4a[qt][j];
-          const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * j + i], p.scale_log2, -l[i]));
-            S[4 * j + i] = pr;
-            dP[4 * j + i] = pr * (dP[4 * j + i] - dd[i]);
+        for (int i = 0; i < 4; ++i) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * j + i], p.scale_log2, -l[i]));
+          float pr = e;
+          if constexpr (slow) {
+            // clamped (invalid) key lanes are never stored, so they need no masking
+            const int q = q0 + qo + i;
+            const bool dead = (q >= qend) | ((p.mask_mode != 0) & (frame_of(p, q) != fk));
+            pr = dead ? 0.f : e;
           }
+          S[4 * j + i] = pr;
+          dP[4 * j + i] = pr * (dP[4 * j + i] - dd[i]);
         }
       }
-      pv<HD, C::LD_ROW, F32>(dV, dOs + qt * 32 * C::LD_ROW, S, lane);
-      pv<HD, C::LD_ROW, F32>(dK, Qs + qt * 32 * C::LD_ROW, dP, lane);
+    };
+    if constexpr (F32 || HD != 96) {          // (hd 192: dK, dV and the key fragments alone are 288 registers)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+        score<HD, C::LD_ROW, F32>(S, Qs + qt * 32 * C::LD_ROW, kf, lane);
+        score<HD, C::LD_ROW, F32>(dP, dOs + qt * 32 * C::LD_ROW, vf, lane);
+        softmax_bwd(S, dP, qt);
+        pv<HD, C::LD_ROW, F32>(dV, dOs + qt * 32 * C::LD_ROW, S, lane);
+        pv<HD, C::LD_ROW, F32>(dK, Qs + qt * 32 * C::LD_ROW, dP, lane);
+      }
+    } else {
+      // bf16: the tile's MFMAs as ONE stream of PER * QT slots, each with one LDS operand (16 bytes per lane: a row chunk
+      // for the S / dP products, two transposed 8-byte reads for the dV / dK products).  The operand of slot g + DEPTH is
+      // requested before the MFMA of slot g is issued and a scheduling fence after every slot keeps it that way.  The
+      // workgroup is one wave per SIMD: with the read next to its MFMA (what the compiler schedules on its own) every MFMA
+      // waited a whole LDS round trip and the matrix pipe was busy 18 % of the time.
+      constexpr int LD = C::LD_ROW, NS = HD / 16, ND = HD / 32, PER = 2 * NS + 4 * ND, DEPTH = 4, TOTAL = PER * QT;
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+      const bf16* rowQ = Qs + (lane & 31) * LD + 8 * h;
+      const bf16* rowD = dOs + (lane & 31) * LD + 8 * h;
+      const bf16* trQ = Qs + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
+      const bf16* trD = dOs + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
+      bf16x8 ring[DEPTH + 1];
+      auto request = [&](auto gc) {
+        constexpr int g = decltype(gc)::value, u = g / PER, k = g % PER;
+        bf16x8& dst = ring[g % (DEPTH + 1)];
+        if constexpr (k < 2 * NS) {
+          dst = *reinterpret_cast<const bf16x8*>((k < NS ? rowQ : rowD) + u * 32 * LD + 16 * (k % NS));
+        } else {
+          constexpr int idx = (k - 2 * NS) % (2 * ND), s2 = idx / ND, d = idx % ND;
+          const bf16* Yb = (k < 2 * NS + 2 * ND ? trD : trQ) + (u * 32 + 16 * s2) * LD + 32 * d;
+          const bf16x4 b0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb)));
+          const bf16x4 b1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 8 * LD)));
+          dst[0] = b0[0]; dst[1] = b0[1]; dst[2] = b0[2]; dst[3] = b0[3];
+          dst[4] = b1[0]; dst[5] = b1[1]; dst[6] = b1[2]; dst[7] = b1[3];
+        }
+      };
+      static_for<DEPTH>([&](auto gc) { request(gc); });
+      f32x16 S, dP;
+      bf16x8 bpS[2], bpD[2];
+      static_for<TOTAL>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, u = g / PER, k = g % PER;
+        if constexpr (k == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+        }
+        if constexpr (k == 2 * NS) {
+          AT_STAMP();                          // S / dP MFMAs issued
+          softmax_bwd(S, dP, u);
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bpS[s2][j] = (bf16)S[8 * s2 + j]; bpD[s2][j] = (bf16)dP[8 * s2 + j]; }
+          __builtin_amdgcn_sched_barrier(0);
+          AT_STAMP();                          // softmax backward done
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
+        const bf16x8 a = ring[g % (DEPTH + 1)];
+        if constexpr (k < NS) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf.b[k], S, 0, 0, 0);
+        else if constexpr (k < 2 * NS) dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf.b[k - NS], dP, 0, 0, 0);
+        else {
+          constexpr int idx = (k - 2 * NS) % (2 * ND), s2 = idx / ND, d = idx % ND;
+          if constexpr (k < 2 * NS + 2 * ND) dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpS[s2], dV[d], 0, 0, 0);
+          else dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpD[s2], dK[d], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
-  });
+    };
+    units(std::integral_constant<bool, SLOW>{});
+    AT_STAMP();                                // tile body done
+  }, Lrow, Drow AT_STAMP_ARGS);
+  AT_STAMP();
+#ifdef CSTS_ATTN_STAMPS
+  if (stamp_on) g_attn_stamps[0] = nstamp;
+#endif
   if (!kvalid) return;
   if (p.nsplit == 1) {
     store_rows<HD>(p.dK, p.dt, (int64_t)b * p.dk_bs + (int64_t)ki * p.dk_ts + (int64_t)head * p.dk_hs, dK, p.scale, h);
@@ -620,8 +827,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
 //   part A (= attn_dkv_kernel's body): wave w owns keys 32 w .. 32 w + 31 as row fragments and walks the tile's four
 //           32-query units: S, dP with the queries in the accumulator registers -> dV += P^T dO, dK += dS^T Q;
 //   part B (= attn_dq_kernel's body):  wave w owns queries 32 w .. 32 w + 31 of the tile as row fragments (read back
-//           from the staged tile) and walks the four 32-key units of K / V in LDS -> dQ = dS K, staged out through the
-//           Q tile's LDS buffer as coalesced 16-byte stores.  The O tile is staged beside dO, so delta = rowsum(dO * O)
+//           from the staged tile) and walks the four 32-key units of K / V in LDS -> dQ = dS K, staged out through this
+//           wave's rows of the O tile as coalesced 16-byte stores BEFORE part A (they drain under its MFMAs).  The O tile is staged beside dO, so delta = rowsum(dO * O)
 //           is a dot product of two row fragments here (no separate delta launch, no second read of dO); LSE and
 //           delta of the tile sit in LDS for part A.
 // S / dP are computed in both orientations (MFMA time is free here: the kernel is bound by the Q / dO / dQ streams).
@@ -645,8 +852,13 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
   const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs, vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
   const int64_t qbase = (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, dobase = (int64_t)b * p.do_bs + (int64_t)head * p.do_hs;
   const int64_t obase = (int64_t)b * p.o_bs + (int64_t)head * p.o_hs;
-  load_tile<HD, 128, LD, false>(Ks, p.K, kbase, p.k_ts, 0, p.Nk, tid);      // rows >= Nk are zero
-  load_tile<HD, 128, LD, false>(Vs, p.V, vbase, p.v_ts, 0, p.Nk, tid);
+  {                                         // K and V: all chunks requested at once (rows >= Nk are zero)
+    TileStage<HD, 128> sk, sv;
+    sk.gload(p.K, kbase, p.k_ts, 0, p.Nk, tid);
+    sv.gload(p.V, vbase, p.v_ts, 0, p.Nk, tid);
+    sk.lstore(Ks, LD, tid);
+    sv.lstore(Vs, LD, tid);
+  }
 
   const int kraw = w * 32 + (lane & 31);
   const bool kvalid = kraw < p.Nk;
@@ -668,7 +880,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
   so.gload(p.O, obase, p.o_ts, qbeg, qend, tid);
   if (tid < 128) lnext = Lrow[min(qbeg + tid, qend - 1)];
   for (int q0 = qbeg; q0 < qend; q0 += 128) {
-    __syncthreads();                       // the previous tile's dQ has left the Q buffer; everyone is done with dO / stats
+    __syncthreads();                       // everyone is done with the previous tile (Q, dO, stats; its dQ has left the O buffer)
     sq.lstore(Qs, LD, tid);
     sdo.lstore(dOs, LD, tid);
     so.lstore(Os, LD, tid);
@@ -720,6 +932,10 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
         pv<HD, LD, false>(acc, Ks + kt * 32 * LD, S, lane);
       }
     }
+    // dQ leaves NOW, through this wave's rows of the O tile (read for delta above and not needed again): the stores then
+    // drain under part A.  Issued at the end of the tile they were the youngest entries of the in-order memory counter
+    // and the wait for the prefetched next tile had to sit through their whole latency.
+    stage_rows_out_wave<HD>(Os, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, q0, qend, acc, p.scale, w, lane);
     __syncthreads();                       // every wave's delta is in LDS
     // ---- part A: this wave's 32 keys (row fragments) against the tile's 128 queries -> dK, dV
     const bool ragged = q0 + 128 > qend;   // wave-uniform
@@ -747,9 +963,6 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
       pv<HD, LD, false>(dV, dOs + qt * 32 * LD, S, lane);
       pv<HD, LD, false>(dK, Qs + qt * 32 * LD, dP, lane);
     }
-    __syncthreads();                       // every wave is done with the Q tile: it becomes the dQ staging buffer
-    stage_rows_out<HD>(Qs, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, q0, qend, acc, p.scale,
-                       w * 32 + (lane & 31), h, tid);
   }
   if (!kvalid) return;
   if (p.nsplit == 1) {
@@ -886,8 +1099,10 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
     const size_t sm = smem_bwd<HD, F32>();
     hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else {
-    const size_t sm = smem_bwd<HD, F32>();
-    hipLaunchKernelGGL((attn_dkv_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
+    const size_t sm = smem_bwd<HD, F32>() + (size_t)Cfg<HD, F32>::KVBLK * 4 * sizeof(float);   // + LSE / delta of the tile(s)
+    const bool slow = F32 || p.mask_mode != 0 || p.Nq % Cfg<HD, F32>::KVBLK != 0;             // (q_chunk is a multiple of the tile)
+    if (slow) hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, true>), grid, dim3(256), sm, stream, p);
+    else hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, F32>), grid, dim3(256), sm, stream, p);
   }
 }
 static void attn_dispatch(int which, const csts_attn_args* a, const AttnP& p, dim3 grid, hipStream_t stream) {
