@@ -364,6 +364,78 @@ __device__ __forceinline__ void tile_loop(typename El<F32>::T* smem, const void*
   }
 }
 
+// The same loop with the tiles (and the two statistics vectors) moved global -> LDS by LDS-DMA (global_load_lds): no staging
+// registers, no ds_write phase, and the next tile is in flight for the whole body of the current one.  A wave instruction
+// writes 64 consecutive 16-byte slots of the LDS image, the image has LD / 8 = 13 slots per row (12 chunks + the 16 bytes of
+// row padding that keep the fragment reads conflict-free), so slot -> (row, chunk) is a division by 13 done once per thread;
+// the lane that owns a padding slot fetches the row's last chunk again (never read).  bf16, whole tiles only (every row of
+// every tile exists: no zero fill), ROWS = 64 or 128.
+// a wave-uniform pointer pinned into scalar registers (otherwise loop strength reduction folds the tile base into per-lane
+// 64-bit induction variables: 16 more VGPRs in a kernel that has none to spare)
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));      // opaque to the optimiser
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+typedef __attribute__((address_space(1))) const void* attn_gptr_t;
+typedef __attribute__((address_space(3))) void* attn_lptr_t;
+// one LDS-DMA wave instruction, 16 bytes per lane: global (scalar base + 32-bit lane offset) -> LDS (wave-uniform base in M0 +
+// 16 * lane).  Written out because the builtin, inside the tile loop, was given full 64-bit lane addresses (zero-extended
+// offsets kept as register pairs: 16 VGPRs, spilled).  The compiler does not count these loads: callers wait with vmcnt(0).
+__device__ __forceinline__ void dma16(const char* base, unsigned lane_off, const void* lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(attn_lptr_t)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane_off), "s"(base) : "memory", "m0");
+}
+template <int HD, int ROWS, int LD, typename Body>
+__device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t xbase, int64_t xts, const void* Y,
+                                              int64_t ybase, int64_t yts, int row_beg, int row_end, int tid, Body&& body,
+                                              const float* S1, const float* S2 AT_STAMP_PARAMS) {
+  constexpr int CPR = HD / 8, SPR = LD / 8, NI = ROWS * SPR / 64, MAXI = (NI + 3) / 4, TILE = ROWS * 2 * LD;
+  static_assert(LD % 8 == 0 && (ROWS * SPR) % 64 == 0 && (ROWS == 64 || ROWS == 128), "LDS image must be whole wave instructions");
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned xo[MAXI], yo[MAXI];                 // byte offsets of this lane's slot in instruction w + 4 i of a tile (tile-invariant)
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPR, c = min(slot - row * SPR, CPR - 1);
+    xo[i] = (unsigned)(row * (int)xts + c * 8) * 2u;
+    yo[i] = (unsigned)(row * (int)yts + c * 8) * 2u;
+  }
+  float* stats = reinterpret_cast<float*>(smem + 2 * TILE);      // [2 buffers][2][ROWS]
+  auto issue = [&](int row0, int buf) {        // scalar tile base + 32-bit lane offset: the saddr form of the instruction
+    const char* xs = uniform_ptr(reinterpret_cast<const bf16*>(X) + xbase + (int64_t)row0 * xts);
+    const char* ys = uniform_ptr(reinterpret_cast<const bf16*>(Y) + ybase + (int64_t)row0 * yts);
+    char* dx = reinterpret_cast<char*>(smem + buf * TILE);
+    char* dy = dx + ROWS * LD * 2;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int t = w + 4 * i;                 // wave-uniform
+      if (t < NI) {
+        dma16(xs, xo[i], dx + t * 1024);
+        dma16(ys, yo[i], dy + t * 1024);
+      }
+    }
+    // LSE and delta of the tile's rows, one dword per lane: 64 rows -> waves 0 / 1; 128 rows -> waves 0, 1 / 2, 3
+    constexpr int WPS = ROWS / 64;
+    if (w < 2 * WPS)
+      __builtin_amdgcn_global_load_lds((attn_gptr_t)((w < WPS ? S1 : S2) + row0 + (w % WPS) * 64 + lane),
+                                       (attn_lptr_t)(stats + buf * 2 * ROWS + (w / WPS) * ROWS + (w % WPS) * 64), 4, 0, 0);
+  };
+  issue(row_beg, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int it = 0;
+  for (int row0 = row_beg; row0 < row_end; row0 += ROWS, ++it) {
+    bf16* cur = smem + (it & 1) * TILE;
+    if (row0 + ROWS < row_end) issue(row0 + ROWS, (it + 1) & 1);   // that buffer was last read before the previous barrier
+    AT_STAMP_P();
+    body(cur, cur + ROWS * LD, row0, stats + (it & 1) * 2 * ROWS);
+    AT_STAMP_P();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // Row-per-lane operands (the 128 query rows of a workgroup, one per lane) are moved through LDS: the tile is loaded /
 // stored by the whole workgroup in 16-byte chunks that run along each 2*HD-byte row (consecutive lanes -> consecutive
 // chunks), and only the LDS side is accessed row-per-lane.  A direct row-per-lane global access makes every wave
@@ -663,11 +735,15 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
 // SLOW: frame mask and / or a ragged last query tile (N_q not a multiple of the tile), as per-element tests.  A kernel-level
 // switch on purpose: with both forms of the tile body inside one loop the register allocator split the dK / dV accumulators
 // at the join and copied 96 registers between the VGPR and AGPR halves around the MFMAs of every tile.
+// FAST (hd 96, bf16, no mask, every 128-query tile whole): tiles by LDS-DMA and the software-pipelined MFMA stream below.
+// (Two 32-key groups per wave -- every LDS operand feeding two MFMAs -- was built and measured: the second group's
+// accumulators do not fit the 256 AGPRs beside S / dP and were copied to and from VGPRs around every product; no gain.)
 template <int HD, bool F32, bool SLOW>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   typedef typename El<F32>::T T;
   typedef Cfg<HD, F32> C;
-  constexpr int QBLK = C::KVBLK, QT = QBLK / 32;
+  constexpr bool FAST = !F32 && HD == 96 && !SLOW;
+  constexpr int QBLK = FAST ? 128 : C::KVBLK, QT = QBLK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
@@ -697,33 +773,28 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
 #endif
   AT_STAMP();
 
-  tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32, true>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
-                                                       [&](const T* Qs, const T* dOs, int q0, const float* Ls) {
+  auto tile_body = [&](const T* Qs, const T* dOs, int q0, const float* Ls) {
     const float* Ds = Ls + QBLK;
-    AT_STAMP();                                // tile body begins (previous tile's staging + barrier done)
-    auto units = [&](auto slow_tag) {
-    constexpr bool slow = decltype(slow_tag)::value;
-    // P = exp2(S * scale - LSE), dS = P * (dP - delta); the 4 registers of a quad are 4 consecutive queries: one 16-byte
-    // (broadcast) LDS read of LSE / delta each
-    auto softmax_bwd = [&](f32x16& S, f32x16& dP, int qt) {
+    AT_STAMP();                                // tile body begins
+    // P = exp2(S * scale - LSE), dS = P * (dP - delta) for registers r0 .. r0 + n - 1 (n <= 4, inside one quad: the 4
+    // registers of a quad are 4 consecutive queries -> one 16-byte broadcast LDS read of LSE / delta)
+    auto softmax_bwd = [&](f32x16& S, f32x16& dP, int qt, int r0, int n) {
+      const int j = r0 >> 2, qo = qt * 32 + 8 * j + 4 * h;
+      const float4 L4 = *reinterpret_cast<const float4*>(Ls + qo), D4 = *reinterpret_cast<const float4*>(Ds + qo);
+      const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int qo = qt * 32 + 8 * j + 4 * h;
-        const float4 L4 = *reinterpret_cast<const float4*>(Ls + qo), D4 = *reinterpret_cast<const float4*>(Ds + qo);
-        const float l[4] = {L4.x, L4.y, L4.z, L4.w}, dd[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[4 * j + i], p.scale_log2, -l[i]));
-          float pr = e;
-          if constexpr (slow) {
-            // clamped (invalid) key lanes are never stored, so they need no masking
-            const int q = q0 + qo + i;
-            const bool dead = (q >= qend) | ((p.mask_mode != 0) & (frame_of(p, q) != fk));
-            pr = dead ? 0.f : e;
-          }
-          S[4 * j + i] = pr;
-          dP[4 * j + i] = pr * (dP[4 * j + i] - dd[i]);
+      for (int r = r0; r < r0 + n; ++r) {
+        const int i = r & 3;
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], p.scale_log2, -l[i]));
+        float pr = e;
+        if constexpr (SLOW) {
+          // clamped (invalid) key lanes are never stored, so they need no masking
+          const int q = q0 + qo + i;
+          const bool dead = (q >= qend) | ((p.mask_mode != 0) & (frame_of(p, q) != fk));
+          pr = dead ? 0.f : e;
         }
+        S[r] = pr;
+        dP[r] = pr * (dP[r] - dd[i]);
       }
     };
     if constexpr (F32 || HD != 96) {          // (hd 192: dK, dV and the key fragments alone are 288 registers)
@@ -734,17 +805,24 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
         score<HD, C::LD_ROW, F32>(S, Qs + qt * 32 * C::LD_ROW, kf, lane);
         score<HD, C::LD_ROW, F32>(dP, dOs + qt * 32 * C::LD_ROW, vf, lane);
-        softmax_bwd(S, dP, qt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) softmax_bwd(S, dP, qt, 4 * j, 4);
         pv<HD, C::LD_ROW, F32>(dV, dOs + qt * 32 * C::LD_ROW, S, lane);
         pv<HD, C::LD_ROW, F32>(dK, Qs + qt * 32 * C::LD_ROW, dP, lane);
       }
     } else {
-      // bf16: the tile's MFMAs as ONE stream of PER * QT slots, each with one LDS operand (16 bytes per lane: a row chunk
-      // for the S / dP products, two transposed 8-byte reads for the dV / dK products).  The operand of slot g + DEPTH is
-      // requested before the MFMA of slot g is issued and a scheduling fence after every slot keeps it that way.  The
-      // workgroup is one wave per SIMD: with the read next to its MFMA (what the compiler schedules on its own) every MFMA
-      // waited a whole LDS round trip and the matrix pipe was busy 18 % of the time.
-      constexpr int LD = C::LD_ROW, NS = HD / 16, ND = HD / 32, PER = 2 * NS + 4 * ND, DEPTH = 4, TOTAL = PER * QT;
+      // hd 96 / bf16: the tile's MFMAs as ONE stream of slots, each with one LDS operand (16 bytes per lane: a row chunk
+      // for the S / dP products, two transposed 8-byte reads for the dV / dK products).  The workgroup is one wave per
+      // SIMD, so nothing hides a latency unless the instruction stream does:
+      //  * the operand of slot g + DEPTH is requested before the MFMA of slot g is issued and a scheduling fence after
+      //    every slot keeps it that way (with the read next to its MFMA -- what the compiler schedules on its own -- every
+      //    MFMA waited a whole LDS round trip and the matrix pipe was busy 18 % of the time);
+      //  * blocks of 12 slots are ordered SC(0) SC(1) PV(0) SC(2) PV(1) ... SC(QT-1) PV(QT-2) PV(QT-1)  (SC(u): S and dP of
+      //    the 32-query unit u, PV(u): its dV and dK products) and the softmax backward of unit u is cut into 8 two-register
+      //    pieces that ride on the first 8 slots of the block after SC(u): its exponentials issue under MFMAs that do not
+      //    depend on them.  S / dP and their bf16 forms are double-buffered by unit parity.
+      constexpr int LD = C::LD_ROW, NS = HD / 16, ND = HD / 32, BLK = 2 * NS, DEPTH = 4, NBLK = 2 * QT, TOTAL = BLK * NBLK;
+      static_assert(BLK == 4 * ND, "S/dP and dV/dK blocks have the same number of slots");
       typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
       const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
       const bf16* rowQ = Qs + (lane & 31) * LD + 8 * h;
@@ -752,14 +830,19 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       const bf16* trQ = Qs + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
       const bf16* trD = dOs + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
       bf16x8 ring[DEPTH + 1];
+      // block bi -> (is it a dV/dK block, which unit)
+      auto blk_pv = [](int bi) constexpr { return bi == NBLK - 1 || (bi >= 2 && (bi & 1) == 0); };
+      auto blk_unit = [](int bi) constexpr { return bi == 0 ? 0 : bi == NBLK - 1 ? QT - 1 : (bi & 1) ? (bi + 1) / 2 : bi / 2 - 1; };
       auto request = [&](auto gc) {
-        constexpr int g = decltype(gc)::value, u = g / PER, k = g % PER;
+        constexpr int g = decltype(gc)::value, bi = g / BLK, k = g % BLK;
+        constexpr bool is_pv = blk_pv(bi);
+        constexpr int u = blk_unit(bi);
         bf16x8& dst = ring[g % (DEPTH + 1)];
-        if constexpr (k < 2 * NS) {
+        if constexpr (!is_pv) {
           dst = *reinterpret_cast<const bf16x8*>((k < NS ? rowQ : rowD) + u * 32 * LD + 16 * (k % NS));
         } else {
-          constexpr int idx = (k - 2 * NS) % (2 * ND), s2 = idx / ND, d = idx % ND;
-          const bf16* Yb = (k < 2 * NS + 2 * ND ? trD : trQ) + (u * 32 + 16 * s2) * LD + 32 * d;
+          constexpr int idx = k % (2 * ND), s2 = idx / ND, d = idx % ND;
+          const bf16* Yb = (k < 2 * ND ? trD : trQ) + (u * 32 + 16 * s2) * LD + 32 * d;
           const bf16x4 b0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb)));
           const bf16x4 b1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 8 * LD)));
           dst[0] = b0[0]; dst[1] = b0[1]; dst[2] = b0[2]; dst[3] = b0[3];
@@ -767,41 +850,47 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
         }
       };
       static_for<DEPTH>([&](auto gc) { request(gc); });
-      f32x16 S, dP;
-      bf16x8 bpS[2], bpD[2];
+      f32x16 S[2], dP[2];
+      bf16x8 bpS[2][2], bpD[2][2];
       static_for<TOTAL>([&](auto gc) {
-        constexpr int g = decltype(gc)::value, u = g / PER, k = g % PER;
-        if constexpr (k == 0) {
+        constexpr int g = decltype(gc)::value, bi = g / BLK, k = g % BLK;
+        constexpr bool is_pv = blk_pv(bi);
+        constexpr int u = blk_unit(bi), par = u & 1;
+        if constexpr (!is_pv && k == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
-        }
-        if constexpr (k == 2 * NS) {
-          AT_STAMP();                          // S / dP MFMAs issued
-          softmax_bwd(S, dP, u);
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { bpS[s2][j] = (bf16)S[8 * s2 + j]; bpD[s2][j] = (bf16)dP[8 * s2 + j]; }
-          __builtin_amdgcn_sched_barrier(0);
-          AT_STAMP();                          // softmax backward done
-          __builtin_amdgcn_sched_barrier(0);
+          for (int r = 0; r < 16; ++r) { S[par][r] = 0.f; dP[par][r] = 0.f; }
         }
         if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
         const bf16x8 a = ring[g % (DEPTH + 1)];
-        if constexpr (k < NS) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf.b[k], S, 0, 0, 0);
-        else if constexpr (k < 2 * NS) dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf.b[k - NS], dP, 0, 0, 0);
-        else {
-          constexpr int idx = (k - 2 * NS) % (2 * ND), s2 = idx / ND, d = idx % ND;
-          if constexpr (k < 2 * NS + 2 * ND) dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpS[s2], dV[d], 0, 0, 0);
-          else dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpD[s2], dK[d], 0, 0, 0);
+        if constexpr (!is_pv) {
+          if constexpr (k < NS) S[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf.b[k], S[par], 0, 0, 0);
+          else dP[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf.b[k - NS], dP[par], 0, 0, 0);
+        } else {
+          constexpr int idx = k % (2 * ND), s2 = idx / ND, d = idx % ND;
+          if constexpr (k < 2 * ND) dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpS[par][s2], dV[d], 0, 0, 0);
+          else dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpD[par][s2], dK[d], 0, 0, 0);
+        }
+        // the softmax backward of the unit whose S / dP block came just before this block
+        if constexpr (bi >= 1 && k < 8) {
+          constexpr int su = bi == 1 ? 0 : bi / 2, sp = su & 1;     // SC(su) is block 2 su - 1 (block 0 for su = 0)
+          if constexpr ((bi == 1) || ((bi & 1) == 0 && bi / 2 <= QT - 1)) {
+            softmax_bwd(S[sp], dP[sp], su, 2 * k, 2);
+            constexpr int s2 = (2 * k) / 8, e0 = (2 * k) % 8;
+            bpS[sp][s2][e0] = (bf16)S[sp][2 * k]; bpS[sp][s2][e0 + 1] = (bf16)S[sp][2 * k + 1];
+            bpD[sp][s2][e0] = (bf16)dP[sp][2 * k]; bpD[sp][s2][e0 + 1] = (bf16)dP[sp][2 * k + 1];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       });
     }
-    };
-    units(std::integral_constant<bool, SLOW>{});
     AT_STAMP();                                // tile body done
-  }, Lrow, Drow AT_STAMP_ARGS);
+  };
+  if constexpr (FAST)
+    tile_loop_dma<HD, QBLK, C::LD_ROW>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid, tile_body, Lrow,
+                                       Drow AT_STAMP_ARGS);
+  else
+    tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32, true>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
+                                                         tile_body, Lrow, Drow AT_STAMP_ARGS);
   AT_STAMP();
 #ifdef CSTS_ATTN_STAMPS
   if (stamp_on) g_attn_stamps[0] = nstamp;
@@ -1058,6 +1147,12 @@ bool fused_bwd_ok(const csts_attn_args* a) {
   return a->dtype == CSTS_BF16 && a->head_dim == 96 && a->Nk <= 128 && a->mask_mode == 0 && a->Nq >= 1024;
 }
 
+// attn_dkv_kernel's FAST form: hd 96, bf16, no mask, every query tile whole (128 queries)
+bool dkv_fast(int dt, int hd, int mask_mode, int Nq) {
+  static const bool off = [] { const char* e = getenv("CSTS_ATTN_DKV_FAST"); return e && atoi(e) == 0; }();
+  return !off && dt == CSTS_BF16 && hd == 96 && mask_mode == 0 && Nq % 128 == 0;
+}
+
 void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
   if (fused_bwd_ok(a)) {      // one workgroup per CU (its LDS holds K, V and the Q / dO tile): aim at two rounds of the chip
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)a->B * a->H), cdiv(a->Nq, 256)));
@@ -1065,7 +1160,7 @@ void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
     nsplit = (int)cdiv(a->Nq, q_chunk);
     return;
   }
-  const int qblk = a->head_dim == 96 ? 64 : 32;
+  const int qblk = dkv_fast(a->dtype, a->head_dim, a->mask_mode, a->Nq) ? 128 : a->head_dim == 96 ? 64 : 32;
   const int64_t base = cdiv(a->Nk, 128) * a->B * a->H;
   int64_t want = std::max<int64_t>(1, 256 / base);   // one workgroup per CU: the kernel runs one wave per SIMD (measured: 512 -> 76 us, 256 -> 66 us, 128 -> 82 us on the 2048 x 512 block)   // one workgroup per CU (the kernel runs one wave per SIMD)
   want = std::min<int64_t>(want, cdiv(a->Nq, 4 * qblk));
@@ -1100,9 +1195,19 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
     hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else {
     const size_t sm = smem_bwd<HD, F32>() + (size_t)Cfg<HD, F32>::KVBLK * 4 * sizeof(float);   // + LSE / delta of the tile(s)
-    const bool slow = F32 || p.mask_mode != 0 || p.Nq % Cfg<HD, F32>::KVBLK != 0;             // (q_chunk is a multiple of the tile)
-    if (slow) hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, true>), grid, dim3(256), sm, stream, p);
-    else hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, F32>), grid, dim3(256), sm, stream, p);
+    if (!dkv_fast(p.dt, HD, p.mask_mode, p.Nq)) {
+      // masked / ragged shapes (and every fp32 call) take the per-element tests
+      const bool slow = F32 || p.mask_mode != 0 || p.Nq % Cfg<HD, F32>::KVBLK != 0;           // (q_chunk is a multiple of the tile)
+      if (slow) hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, true>), grid, dim3(256), sm, stream, p);
+      else hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, F32>), grid, dim3(256), sm, stream, p);
+    } else if constexpr (!F32 && HD == 96) {
+      // 128-query tiles, double-buffered, + statistics: 108 KB of dynamic LDS (one workgroup per CU either way)
+      constexpr size_t smf = (size_t)2 * 128 * 2 * Cfg<96, false>::LD_ROW * 2 + 2 * 2 * 128 * sizeof(float);
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dkv_kernel<96, false, false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smf);
+      (void)attr;
+      hipLaunchKernelGGL((attn_dkv_kernel<96, false, false>), grid, dim3(256), smf, stream, p);
+    }
   }
 }
 static void attn_dispatch(int which, const csts_attn_args* a, const AttnP& p, dim3 grid, hipStream_t stream) {

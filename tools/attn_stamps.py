@@ -6,7 +6,7 @@ import os, sys, ctypes as C
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from csts_amd import lib as L
-L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag", "libcsts_hip_stamps.so")
+L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag", os.environ.get("STAMPS_LIB", "libcsts_hip_stamps.so"))
 dev = torch.device("cuda:0")
 B, H, Nq, Nk = [int(v) for v in sys.argv[1:5]]
 hd = 96
@@ -35,34 +35,18 @@ assert raw.csts_debug_attn_stamps(buf) == 0
 n = buf[0]
 t = [buf[i] for i in range(1, n)]
 print(f"{n - 1} stamps; kernel body {t[-1] - t[0]} cycles")
-# layout: start | per tile: body_begin, (mfma1, softmax) x QT, body_end | end
-QT = 2
-per = 2 + 2 * QT + 2
-i = 1
-tile = 0
-prev_end = t[0]
+# LDS-DMA tile loop: start | per tile: DMA issued, body begins, body done, loop stamp | end
+per = 4
 rows = []
-while i + per <= len(t) - 1 + 1 and tile < 10000:
-    seg = t[i:i + per]
-    if len(seg) < per: break
-    stage = seg[0] - prev_end
-    units = []
-    last = seg[0]
-    for u in range(QT):
-        m1 = seg[1 + 2 * u] - last
-        sm = seg[2 + 2 * u] - seg[1 + 2 * u]
-        # dV/dK MFMAs of unit u run until the next unit's S/dP stamp; reported with it, except for the last unit
-        units.append((m1, sm))
-        last = seg[2 + 2 * u]
-    body_end = seg[per - 3]
-    tail = body_end - seg[per - 4]
-    rows.append((stage, units, tail, body_end - seg[0], seg[per - 2] - body_end, seg[per - 1] - seg[per - 2]))
-    prev_end = seg[per - 1]
+i = 1
+prev = t[0]
+while i + per <= len(t) - 1:
+    g = t[i:i + per]
+    rows.append(dict(sync=g[0] - prev, body=g[2] - g[1], tile=g[3] - prev))
+    prev = g[3]
     i += per
-    tile += 1
-for r in rows[:6] + rows[-2:]:
-    print(f"  staging+barrier {r[0]:6d} | " + " | ".join(f"(pv of previous +) S/dP {m:5d}, softmax {sm:5d}" for m, sm in r[1]) + f" | last dV/dK {r[2]:5d} | body {r[3]} | wait for prefetch + ds_write {r[4]} | issue next loads {r[5]}")
 import statistics as st
-print("median: wait+ds_write", st.median(r[4] for r in rows), "issue", st.median(r[5] for r in rows), "barrier", st.median(r[0] for r in rows), "body", st.median(r[3] for r in rows),
-      "unit0 S/dP", st.median(r[1][0][0] for r in rows), "softmax", st.median(r[1][0][1] for r in rows),
-      "unit1 pv+S/dP", st.median(r[1][1][0] for r in rows), "softmax", st.median(r[1][1][1] for r in rows), "last pv", st.median(r[2] for r in rows))
+keys = ["sync", "body", "tile"]
+print("per 128-query tile, median shader-clock ticks: wait for the next tile + barrier + DMA issue | MFMA stream | whole tile "
+      "(192 MFMAs per wave = 6144 ticks at the matrix pipe's issue rate)")
+print("  " + " | ".join(f"{k} {int(st.median(r[k] for r in rows[1:]))}" for k in keys), f"({len(rows)} tiles)")
