@@ -387,10 +387,10 @@ __device__ __forceinline__ void dma16(const char* base, unsigned lane_off, const
   const uint32_t l = (uint32_t)(uintptr_t)(attn_lptr_t)lds_dst;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane_off), "s"(base) : "memory", "m0");
 }
-template <int HD, int ROWS, int LD, typename Body>
+template <int HD, int ROWS, int LD, bool STATS = true, typename Body>
 __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t xbase, int64_t xts, const void* Y,
                                               int64_t ybase, int64_t yts, int row_beg, int row_end, int tid, Body&& body,
-                                              const float* S1, const float* S2 AT_STAMP_PARAMS) {
+                                              const float* S1 = nullptr, const float* S2 = nullptr AT_STAMP_PARAMS) {
   constexpr int CPR = HD / 8, SPR = LD / 8, NI = ROWS * SPR / 64, MAXI = (NI + 3) / 4, TILE = ROWS * 2 * LD;
   static_assert(LD % 8 == 0 && (ROWS * SPR) % 64 == 0 && (ROWS == 64 || ROWS == 128), "LDS image must be whole wave instructions");
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -417,7 +417,7 @@ __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t
     }
     // LSE and delta of the tile's rows, one dword per lane: 64 rows -> waves 0 / 1; 128 rows -> waves 0, 1 / 2, 3
     constexpr int WPS = ROWS / 64;
-    if (w < 2 * WPS)
+    if (STATS && w < 2 * WPS)
       __builtin_amdgcn_global_load_lds((attn_gptr_t)((w < WPS ? S1 : S2) + row0 + (w % WPS) * 64 + lane),
                                        (attn_lptr_t)(stats + buf * 2 * ROWS + (w / WPS) * ROWS + (w % WPS) * 64), 4, 0, 0);
   };
@@ -429,7 +429,8 @@ __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t
     bf16* cur = smem + (it & 1) * TILE;
     if (row0 + ROWS < row_end) issue(row0 + ROWS, (it + 1) & 1);   // that buffer was last read before the previous barrier
     AT_STAMP_P();
-    body(cur, cur + ROWS * LD, row0, stats + (it & 1) * 2 * ROWS);
+    if constexpr (STATS) body(cur, cur + ROWS * LD, row0, stats + (it & 1) * 2 * ROWS);
+    else body(cur, cur + ROWS * LD, row0);
     AT_STAMP_P();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -727,6 +728,131 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
     stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, blockIdx.x * 128, p.Nq, acc, p.scale,
                        w * 32 + (lane & 31), h, tid);
   }
+}
+
+// dQ, FAST form (hd 96, bf16, no mask, every 64-key tile whole): K / V tiles by LDS-DMA and the MFMA slot stream of
+// attn_dkv_kernel (operands requested DEPTH slots ahead, scheduling fence per slot).  Per 32-key unit u: SC(u) = S and dP
+// (12 slots, operands = rows of K / V, the query fragments in registers), PV(u) = dQ += dS K (6 slots, transposed reads of
+// K).  Block order SC(0) SC(1) PV(0) PV(1); dS(0) = P (dP - delta) rides in two-register pieces on SC(1), dS(1) on PV(0).
+__global__ __launch_bounds__(256, 2) void attn_dq_fast_kernel(AttnP p) {
+  constexpr int HD = 96;
+  typedef Cfg<HD, false> C;
+  constexpr int KBLK = 64, KT = KBLK / 32, LD = C::LD_ROW;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  const bool qvalid = qraw < p.Nq;
+  const int qi = qvalid ? qraw : p.Nq - 1;
+
+  RowFrag<HD, false> qf, dof;
+  float dl = 0.f;
+  {
+    // all three row tiles are requested at once (ONE memory round trip instead of three in a row), then pass through the
+    // two LDS staging regions
+    RowFrag<HD, false> of;
+    TileStage<HD, 128> tq, tdo, to;
+    tq.gload(p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+    tdo.gload(p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, blockIdx.x * 128, p.Nq, tid);
+    to.gload(p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+    tq.lstore(smem, LD, tid);
+    tdo.lstore(smem + 128 * LD, LD, tid);
+    __syncthreads();
+    frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
+    frag_from_lds<HD>(dof, smem + 128 * LD, w * 32 + (lane & 31), h);
+    __syncthreads();
+    to.lstore(smem, LD, tid);
+    __syncthreads();
+    frag_from_lds<HD>(of, smem, w * 32 + (lane & 31), h);
+    __syncthreads();
+    // delta = rowsum(dO * O): kept for the dK/dV kernel, which runs after this one
+#pragma unroll
+    for (int s2 = 0; s2 < HD / 16; ++s2)
+#pragma unroll
+      for (int j2 = 0; j2 < 8; ++j2) dl += (float)dof.b[s2][j2] * (float)of.b[s2][j2];
+    dl += __shfl_xor(dl, 32, 64);
+    if (h == 0 && qvalid) p.delta[((int64_t)b * p.H + head) * p.Nq + qi] = dl;
+  }
+  const float negL = -p.LSE[((int64_t)b * p.H + head) * p.Nq + qi];
+  f32x16 acc[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+
+  tile_loop_dma<HD, KBLK, LD, false>(smem, p.K, kbase, p.k_ts, p.V, vbase, p.v_ts, 0, p.Nk, tid,
+                                     [&](const bf16* Ks, const bf16* Vs, int) {
+    constexpr int NS = HD / 16, ND = HD / 32, SCB = 2 * NS, PVB = 2 * ND, DEPTH = 4, TOTAL = KT * (SCB + PVB);
+    static_assert(KT == 2, "block order below is written for two units per tile");
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* rowK = Ks + (lane & 31) * LD + 8 * h;
+    const bf16* rowV = Vs + (lane & 31) * LD + 8 * h;
+    const bf16* trK = Ks + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
+    // slot g -> (block, k): blocks SC(0) [0, 12), SC(1) [12, 24), PV(0) [24, 30), PV(1) [30, 36)
+    auto is_pv = [](int g) constexpr { return g >= 2 * SCB; };
+    auto unit = [](int g) constexpr { return g < SCB ? 0 : g < 2 * SCB ? 1 : g < 2 * SCB + PVB ? 0 : 1; };
+    auto kk = [](int g) constexpr { return g < 2 * SCB ? g % SCB : (g - 2 * SCB) % PVB; };
+    bf16x8 ring[DEPTH + 1];
+    auto request = [&](auto gc) {
+      constexpr int g = decltype(gc)::value, u = unit(g), k = kk(g);
+      bf16x8& dst = ring[g % (DEPTH + 1)];
+      if constexpr (!is_pv(g)) {
+        dst = *reinterpret_cast<const bf16x8*>((k < NS ? rowK : rowV) + u * 32 * LD + 16 * (k % NS));
+      } else {
+        constexpr int s2 = k / ND, d = k % ND;
+        const bf16* Yb = trK + (u * 32 + 16 * s2) * LD + 32 * d;
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb)));
+        const bf16x4 b1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 8 * LD)));
+        dst[0] = b0[0]; dst[1] = b0[1]; dst[2] = b0[2]; dst[3] = b0[3];
+        dst[4] = b1[0]; dst[5] = b1[1]; dst[6] = b1[2]; dst[7] = b1[3];
+      }
+    };
+    static_for<DEPTH>([&](auto gc) { request(gc); });
+    f32x16 S[2], dP[2];
+    bf16x8 bp[2][2];
+    // dS of registers 2 q, 2 q + 1 of unit su
+    auto piece = [&](auto suc, auto qc) {
+      constexpr int su = decltype(suc)::value, q = decltype(qc)::value;
+#pragma unroll
+      for (int r = 2 * q; r < 2 * q + 2; ++r) {
+        const float ds = __builtin_amdgcn_exp2f(__builtin_fmaf(S[su][r], p.scale_log2, negL)) * (dP[su][r] - dl);
+        bp[su][r / 8][r % 8] = (bf16)ds;
+      }
+    };
+    static_for<TOTAL>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, u = unit(g), k = kk(g);
+      if constexpr (!is_pv(g) && k == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[u][r] = 0.f; dP[u][r] = 0.f; }
+      }
+      if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
+      const bf16x8 a = ring[g % (DEPTH + 1)];
+      if constexpr (!is_pv(g)) {
+        if constexpr (k < NS) S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf.b[k], S[u], 0, 0, 0);
+        else dP[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dof.b[k - NS], dP[u], 0, 0, 0);
+      } else {
+        constexpr int s2 = k / ND, d = k % ND;
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp[u][s2], acc[d], 0, 0, 0);
+      }
+      if constexpr (g >= SCB && g < SCB + 8) {                       // dS(0) under SC(1): one piece per slot
+        piece(std::integral_constant<int, 0>{}, std::integral_constant<int, g - SCB>{});
+      } else if constexpr (g >= 2 * SCB && g < 2 * SCB + PVB) {      // dS(1) under PV(0): 8 pieces on 6 slots
+        constexpr int j = g - 2 * SCB;
+        if constexpr (j < 4) piece(std::integral_constant<int, 1>{}, std::integral_constant<int, j>{});
+        else {
+          piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 4 + 2 * (j - 4)>{});
+          piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 5 + 2 * (j - 4)>{});
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, blockIdx.x * 128, p.Nq, acc, p.scale,
+                     w * 32 + (lane & 31), h, tid);
 }
 
 // ---------------------------------------------------------------------------------------------- dK, dV
@@ -1153,6 +1279,12 @@ bool dkv_fast(int dt, int hd, int mask_mode, int Nq) {
   return !off && dt == CSTS_BF16 && hd == 96 && mask_mode == 0 && Nq % 128 == 0;
 }
 
+// attn_dq_fast_kernel: hd 96, bf16, no mask, every 64-key tile whole
+bool dq_fast(int dt, int hd, int mask_mode, int Nk) {
+  static const bool off = [] { const char* e = getenv("CSTS_ATTN_DQ_FAST"); return e && atoi(e) == 0; }();
+  return !off && dt == CSTS_BF16 && hd == 96 && mask_mode == 0 && Nk % 64 == 0;
+}
+
 void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
   if (fused_bwd_ok(a)) {      // one workgroup per CU (its LDS holds K, V and the Q / dO tile): aim at two rounds of the chip
     const int64_t want = std::max<int64_t>(1, std::min<int64_t>(256 / ((int64_t)a->B * a->H), cdiv(a->Nq, 256)));
@@ -1192,7 +1324,8 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
     hipLaunchKernelGGL((attn_fwd_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else if (which == K_DQ) {
     const size_t sm = smem_bwd<HD, F32>();
-    hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
+    if (dq_fast(p.dt, HD, p.mask_mode, p.Nk)) hipLaunchKernelGGL(attn_dq_fast_kernel, grid, dim3(256), sm, stream, p);
+    else hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else {
     const size_t sm = smem_bwd<HD, F32>() + (size_t)Cfg<HD, F32>::KVBLK * 4 * sizeof(float);   // + LSE / delta of the tile(s)
     if (!dkv_fast(p.dt, HD, p.mask_mode, p.Nq)) {
