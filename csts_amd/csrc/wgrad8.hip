@@ -19,6 +19,18 @@
 // have output features % 192 == 0 and input features % 384 == 0; token chunks must be multiples of 64 (host-checked).
 #include "common.h"
 
+// Diagnostics build (-DCSTS_WGRAD8_STAMPS, `make stamps`, tools/wgrad8_stamps.py): thread 0 of workgroup 0 records shader-clock
+// stamps around the phases of every k-tile.  No stamp code exists in the library build.
+#ifdef CSTS_WGRAD8_STAMPS
+__device__ unsigned long long g_w8_stamps[4096];
+#define W8_STAMP() do { if (stamp_on && nstamp < 4000) g_w8_stamps[nstamp++] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int csts_debug_wgrad8_stamps(unsigned long long* dst_host) {
+  return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_w8_stamps), sizeof(unsigned long long) * 4096);
+}
+#else
+#define W8_STAMP() do { } while (0)
+#endif
+
 namespace {
 
 constexpr int W8_TM = 192, W8_TN = 384, W8_THR = 512;
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
   // ---- producer: piece p = wave + 8 i of the stage image (A rows first, then B rows) belongs to this wave; this lane's
   // source offset (elements, relative to the k-tile's first token row) of each.  LDS byte `off` of an image holds token row
   // off / ROWB, rotated chunk (off % ROWB) / 16; the lane fetches the chunk that belongs there.
-  int soff[NPW];
+  unsigned soff[NPW];                                         // BYTE offsets
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     const int p = min(wave + 8 * i, G::NPIECE - 1);
@@ -82,25 +94,30 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
       const int off = p * 1024 + lane * 16, row = off / W8_AROW, chp = (off % W8_AROW) / 16;
       int c = chp - 4 * ((row >> 1) & 1);
       if (c < 0) c += W8_AROW / 16;
-      soff[i] = row * (int)it.lda + (int)m0 + c * 8;
+      soff[i] = (unsigned)(row * (int)it.lda + (int)m0 + c * 8) * 2u;
     } else {
       const int off = p * 1024 - A_BYTES + lane * 16, row = off / W8_BROW, chp = (off % W8_BROW) / 16;
       int c = chp - 4 * (row & 3);
       if (c < 0) c += W8_BROW / 16;
-      soff[i] = row * (int)it.ldb + (int)n0 + c * 8;
+      soff[i] = (unsigned)(row * (int)it.ldb + (int)n0 + c * 8) * 2u;
     }
   }
   const bf16* __restrict__ A = reinterpret_cast<const bf16*>(it.A);
   const bf16* __restrict__ B = reinterpret_cast<const bf16*>(it.B);
+  // one LDS-DMA wave instruction as scalar base + 32-bit lane offset (the saddr form), M0 = the piece's LDS address.  Written
+  // out: through the builtin the compiler formed a 64-bit lane address per piece (two v_lshl_add_u64 + readfirstlane per
+  // instruction) and the nine instructions of a refill took ~700 ticks (in-kernel stamps, tools/wgrad8_stamps.py).
   auto issue = [&](char* st, int64_t k0) {
-    const bf16* a = A + k0 * it.lda;
-    const bf16* b = B + k0 * it.ldb;
+    const char* a = reinterpret_cast<const char*>(A + k0 * it.lda);
+    const char* b = reinterpret_cast<const char*>(B + k0 * it.ldb);
+    const uint32_t l0 = (uint32_t)(uintptr_t)(lptr_t)st;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       if (i == NPW - 1 && short_wave) break;
       const int p = wave + 8 * i;                              // scalar
-      const bf16* src = (p * 1024 < A_BYTES) ? a : b;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + soff[i]), (lptr_t)(st + p * 1024), 16, 0, 0);
+      const char* src = (p * 1024 < A_BYTES) ? a : b;
+      const uint32_t l = l0 + (uint32_t)p * 1024u;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(soff[i]), "s"(src) : "memory", "m0");
     }
   };
   // k-tile kt has landed once at most `ahead` younger k-tiles of this wave's pieces are outstanding
@@ -128,12 +145,20 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
   for (int s2 = 0; s2 < S - 1; ++s2)
     if (s2 < nk) issue(smem + s2 * STAGE, kbeg + (int64_t)s2 * BK);
   int cs = 0, ps = (S - 1) % S;                               // consumer stage, producer stage
+#ifdef CSTS_WGRAD8_STAMPS
+  const bool stamp_on = tid == 0 && blockIdx.x == 0;
+  int nstamp = 1;
+#endif
+  W8_STAMP();
   for (int kt = 0; kt < nk; ++kt) {
     wait_tile(min(S - 2, nk - 1 - kt));                      // this wave's pieces of k-tile kt have landed
+    W8_STAMP();
     __builtin_amdgcn_s_barrier();                            // ... everyone's have, and everyone is done with the stage refilled next
+    W8_STAMP();
     const char* As = smem + cs * STAGE;
     const char* Bs = As + A_BYTES;
     if (kt + S - 1 < nk) issue(smem + ps * STAGE, kbeg + (int64_t)(kt + S - 1) * BK);
+    W8_STAMP();
     cs = (cs + 1 == S) ? 0 : cs + 1;
     ps = (ps + 1 == S) ? 0 : ps + 1;
     if (do_colsum) {
@@ -159,7 +184,11 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // operands swapped: see the epilogue
     }
+    W8_STAMP();
   }
+#ifdef CSTS_WGRAD8_STAMPS
+  if (stamp_on) g_w8_stamps[0] = nstamp;
+#endif
 
   if (it.colsum != nullptr && n0 == 0) {   // block-uniform: fold the four token slices of every column (fixed order)
     __syncthreads();
