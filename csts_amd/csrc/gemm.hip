@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
   static_assert(32 * CS_LD * 4 <= STAGE_BYTES, "C staging (32 rows) must fit one ring stage");
   __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int nk = (int)((p.K + BK2 - 1) / BK2), nk_full = (int)(p.K / BK2), k_tail = (int)((p.K % BK2) >> 4);
 
@@ -716,8 +716,9 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
   const int total_k = my_tiles * nk;
 
   // ---- producer side: per-lane source rows of the pieces this wave stages (8 rows x 128 B per wave-instruction)
-  const bf16* asrc[NA];
-  const bf16* bsrc[NB];
+  // (scalar matrix base + k offset) + 32-bit lane byte offset: the saddr form of the LDS-DMA instruction (host-checked:
+  // M * lda and N * ldb fit 31 bits of bytes)
+  unsigned asrc[NA], bsrc[NB];
   int ach[NA], bch[NB];                              // swizzled k-chunk (x8 elements) this lane fetches
 #pragma unroll
   for (int i = 0; i < NA; ++i) ach[i] = ((lane & 7) ^ ((((wave * NA + i) * 8 + (lane >> 3)) >> 1) & 7)) * 8;
@@ -727,10 +728,10 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
     const int64_t m0 = (t / p.ntiles_n) * BM3, n0 = (t % p.ntiles_n) * 128;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      asrc[i] = reinterpret_cast<const bf16*>(p.A) + min(m0 + (wave * NA + i) * 8 + (lane >> 3), p.M - 1) * p.lda;
+      asrc[i] = (unsigned)(min(m0 + (wave * NA + i) * 8 + (lane >> 3), p.M - 1) * p.lda) * 2u;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      bsrc[i] = reinterpret_cast<const bf16*>(p.B) + min(n0 + (wave * NB + i) * 8 + (lane >> 3), p.N - 1) * p.ldb;
+      bsrc[i] = (unsigned)(min(n0 + (wave * NB + i) * 8 + (lane >> 3), p.N - 1) * p.ldb) * 2u;
   };
   int64_t pt = t_first;                              // producer position: tile, k-tile inside it, flattened index
   int pk = 0, pidx = 0, pstage = 0;
@@ -740,15 +741,13 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
     const int64_t k0 = (int64_t)pk * BK2;
     const bool full = k0 + BK2 <= p.K;               // wave-uniform; chunks past K are fetched from chunk 0 (never used)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int64_t k = (full || k0 + ach[i] < p.K) ? k0 + ach[i] : k0;
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k), (lptr_t)(st + (wave * NA + i) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < NA; ++i)
+      lds_dma16(reinterpret_cast<const char*>(p.A) + k0 * 2, asrc[i] + ((full || k0 + ach[i] < p.K) ? 2u * ach[i] : 0u),
+                st + (wave * NA + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int64_t k = (full || k0 + bch[i] < p.K) ? k0 + bch[i] : k0;
-      __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + k), (lptr_t)(st + A_BYTES + (wave * NB + i) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < NB; ++i)
+      lds_dma16(reinterpret_cast<const char*>(p.B) + k0 * 2, bsrc[i] + ((full || k0 + bch[i] < p.K) ? 2u * bch[i] : 0u),
+                st + A_BYTES + (wave * NB + i) * 1024);
     ++pidx;
     pstage = (pstage + 1 == S) ? 0 : pstage + 1;
     if (++pk == nk) {
@@ -830,12 +829,12 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
             const bool mine = (NKS == 4) ? (i * 4 / LPT == ks) : (ks == 0);
             if (!mine) continue;
             if (i < NA) {
-              const int64_t k = (full || k0 + ach[i] < p.K) ? k0 + ach[i] : k0;
-              __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k), (lptr_t)(st + (wave * NA + i) * 1024), 16, 0, 0);
+              lds_dma16(reinterpret_cast<const char*>(p.A) + k0 * 2, asrc[i] + ((full || k0 + ach[i] < p.K) ? 2u * ach[i] : 0u),
+                        st + (wave * NA + i) * 1024);
             } else {
               const int b = i - NA;
-              const int64_t k = (full || k0 + bch[b] < p.K) ? k0 + bch[b] : k0;
-              __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[b] + k), (lptr_t)(st + A_BYTES + (wave * NB + b) * 1024), 16, 0, 0);
+              lds_dma16(reinterpret_cast<const char*>(p.B) + k0 * 2, bsrc[b] + ((full || k0 + bch[b] < p.K) ? 2u * bch[b] : 0u),
+                        st + A_BYTES + (wave * NB + b) * 1024);
             }
           }
         }
@@ -1118,7 +1117,8 @@ int pick_tile_rows(const csts_gemm_args* a, int64_t per) {
 // gemm3 (LDS-DMA ring, NT bf16 x bf16): usable when every 16-byte chunk is whole and K has only whole MFMA sub-steps
 bool v3_ok(const csts_gemm_args* a, int split) {
   return v2_ok(a) && a->layout == CSTS_GEMM_NT && a->a_dt == CSTS_BF16 && a->b_dt == CSTS_BF16 && a->K % 16 == 0 &&
-         split == 1 && a->colsum == nullptr;
+         split == 1 && a->colsum == nullptr &&
+         a->M * a->lda < (int64_t(1) << 30) && a->N * a->ldb < (int64_t(1) << 30);   // 32-bit lane byte offsets of the LDS-DMA
 }
 // Library heuristic for the persistent LDS-DMA kernel (64-row tiles, 3-stage ring, 2 workgroups per CU).
 bool pick3(const csts_gemm_args* a, int split, int* mt, int* stages) {

@@ -32,6 +32,14 @@ __device__ __forceinline__ void lds_barrier() {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// one LDS-DMA wave instruction, 16 bytes per lane: global (wave-uniform base + 32-bit lane byte offset: the saddr form) ->
+// LDS (wave-uniform address in M0 + 16 * lane).  Written out because the builtin is handed full 64-bit lane addresses; the
+// compiler does not count these loads (callers wait with explicit vmcnt, as they do for the builtin's).
+__device__ __forceinline__ void lds_dma16(const char* base, unsigned lane_off, const void* lds_dst) {
+  const uint32_t l = (uint32_t)(uintptr_t)(lptr_t)lds_dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane_off), "s"(base) : "memory", "m0");
+}
+
 // 4 consecutive elements -> 4 floats
 __device__ __forceinline__ f32x4 ld4_as_f32(const void* p, int dt, int64_t i) {
   if (dt == CSTS_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i);
