@@ -1150,6 +1150,11 @@ bool pick4(const csts_gemm_args* a, int split, int* variant) {
   const int64_t rows = cdiv(a->M, 128);
   if (a->N % 192 == 0 && rows * (a->N / 192) >= 256) {
     *variant = (a->K >= 1536 && rows * (a->N / 192) <= 256) ? 63 : 62;
+    // short K, many row tiles, whole tiles: the wave-specialised form (4 producer waves; gemm4.hip) -- OFF by default:
+    // -4 .. -11 % on six of ten isolated cases, but +0.18 ms per step inside the two-stream step (one 12-wave workgroup per
+    // CU), profiles/r3_shortk_gemm_stamps.txt.  CSTS_GEMM4_SPLIT=1 switches it on for A/B runs.
+    static const bool split_on = [] { const char* e = getenv("CSTS_GEMM4_SPLIT"); return e && e[0] == '1'; }();
+    if (split_on && a->K <= 192 && a->M % 128 == 0 && a->M >= 32768 && a->row_scale == nullptr) *variant = 83;
     return true;
   }
   const int64_t t128 = rows * cdiv(a->N, 128);

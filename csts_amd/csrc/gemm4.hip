@@ -31,16 +31,23 @@
 
 namespace {
 
-template <int WM, int MT, int NT, int S> struct G4 {
+// NP > 0: wave specialisation.  NP extra PRODUCER waves issue every LDS-DMA instruction and do nothing else; the 2 WM consumer
+// waves multiply and store and never issue or wait for a load.  Vector memory retires in order on one counter per wave, so a
+// wave that both stores a tile and stages the next one cannot see its loads land before its stores have drained: on the
+// short-K, large-M shapes every workgroup alternated between "storing" and "loading + multiplying" and the chip averaged 3 TB/s
+// (profiles/r3_shortk_gemm_stamps.txt).  A producer's counter never holds a store.
+template <int WM, int MT, int NT, int S, int NP_ = 0> struct G4 {
+  static constexpr int NP = NP_;
   static constexpr int DB = (MT * NT >= 6) ? 1 : 2;      // fragment register sets: the 96 / 128-accumulator tiles have no room for two
-  static constexpr int NWAVES = WM * 2, NTHR = 64 * NWAVES;
+  static constexpr int NWAVES = WM * 2, NTHR = 64 * (NWAVES + NP);
+  static constexpr int DW = NP > 0 ? NP : NWAVES;        // waves that issue LDS-DMA
   static constexpr int BM = WM * 32 * MT, BN = 64 * NT;
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static constexpr int NA = BM / 8 / NWAVES, NB = BN / 8 / NWAVES, LPT = NA + NB;   // LDS-DMA instructions per thread per k-tile
+  static constexpr int NA = BM / 8 / DW, NB = BN / 8 / DW, LPT = NA + NB;   // LDS-DMA instructions per (issuing) thread per k-tile
   static constexpr int FIT = (160 * 1024) / (S * STAGE);
-  static constexpr int WG = FIT < 1 ? 1 : (FIT > 2 ? 2 : FIT);                        // workgroups per CU the register budget is set for
-  static constexpr int WPS = (WG * NWAVES + 3) / 4;                                   // waves per SIMD
-  static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "pieces must divide over the waves");
+  static constexpr int WG = NP > 0 ? 1 : (FIT < 1 ? 1 : (FIT > 2 ? 2 : FIT));        // workgroups per CU the register budget is set for
+  static constexpr int WPS = (WG * (NWAVES + NP) + 3) / 4;                            // waves per SIMD
+  static_assert(BM % (8 * DW) == 0 && BN % (8 * DW) == 0, "pieces must divide over the issuing waves");
   static_assert(S * STAGE <= 160 * 1024, "ring exceeds the CU's LDS");
   static_assert(2 * LPT <= 63, "vmcnt immediate");
 };
@@ -50,9 +57,9 @@ template <int WM, int MT, int NT, int S> struct G4 {
 // 1 bias, 2 bias + GELU (pre-activation to aux), 3 plain, 4 DGELU (times gelu'(aux)).  One epilogue per kernel keeps the
 // register allocation of the k-loop and of that epilogue inside the 128-register budget of two workgroups per CU (all forms
 // in one kernel: 59 spilled registers).
-template <int WM, int MT, int NT, int S, int FORM>
-__global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)) void gemm4_kernel(Params p) {
-  typedef G4<WM, MT, NT, S> G;
+template <int WM, int MT, int NT, int S, int FORM, int NP = 0>
+__global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, NP>::WPS)) void gemm4_kernel(Params p) {
+  typedef G4<WM, MT, NT, S, NP> G;
   constexpr bool KTAIL = false;        // K % 64 != 0 is not instantiated (the library never picks this kernel for it)
   constexpr int BM = G::BM, BN = G::BN, A_BYTES = G::A_BYTES, STAGE = G::STAGE, NA = G::NA, NB = G::NB, LPT = G::LPT;
   __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE];
@@ -60,6 +67,9 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it (and all it feeds) scalar
   const int wm = wave >> 1, wn = wave & 1;
+  const bool producer = NP > 0 && wave >= G::NWAVES;              // wave-uniform
+  const bool issues = NP == 0 || producer;
+  const int dw = NP > 0 ? wave - G::NWAVES : wave;                // index among the issuing waves
 #ifdef CSTS_GEMM4_STAMPS
   const bool stamp_on = p.stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 137);
   unsigned long long* stamp_buf = p.stamps + (blockIdx.x == 0 ? 0 : 512);
@@ -90,14 +100,14 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
     bbase = reinterpret_cast<const char*>(p.B) + n0 * p.ldb * 2;
     const int ra = (int)min((int64_t)BM, p.M - m0) - 1, rb = (int)min((int64_t)BN, p.N - n0) - 1;   // last valid row of the tile
 #pragma unroll
-    for (int i = 0; i < NA; ++i) aoff[i] = (unsigned)(min((wave * NA + i) * 8 + (lane >> 3), ra) * (int)p.lda * 2 + chunk(wave * NA + i));
+    for (int i = 0; i < NA; ++i) aoff[i] = (unsigned)(min((dw * NA + i) * 8 + (lane >> 3), ra) * (int)p.lda * 2 + chunk(dw * NA + i));
 #pragma unroll
-    for (int i = 0; i < NB; ++i) boff[i] = (unsigned)(min((wave * NB + i) * 8 + (lane >> 3), rb) * (int)p.ldb * 2 + chunk(wave * NB + i));
+    for (int i = 0; i < NB; ++i) boff[i] = (unsigned)(min((dw * NB + i) * 8 + (lane >> 3), rb) * (int)p.ldb * 2 + chunk(dw * NB + i));
   };
   int64_t pt = t_first;                              // producer position: tile, k-tile inside it, flattened index
   int pk = 0, pidx = 0, pstage = 0;
   auto issue = [&](int i, char* st, int64_t k0, bool full) {      // LDS-DMA instruction i of this thread's share of a k-tile
-    const int piece = (i < NA) ? wave * NA + i : wave * NB + (i - NA);
+    const int piece = (i < NA) ? dw * NA + i : dw * NB + (i - NA);
     unsigned off = (i < NA) ? aoff[i] : boff[i - NA];
     if (KTAIL && !full && k0 + chunk(piece) / 2 >= p.K) off -= chunk(piece);   // chunks past K are fetched from chunk 0 (never used)
     const char* src = ((i < NA) ? abase : bbase) + k0 * 2 + off;
@@ -113,10 +123,10 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
       if (pidx < total_k) set_tile(pt);
     }
   };
-  if (my_tiles > 0) set_tile(pt);
+  if (my_tiles > 0 && issues) set_tile(pt);
 #pragma unroll
   for (int s = 0; s < S - 1; ++s) {
-    if (pidx < total_k) {
+    if (issues && pidx < total_k) {
       char* st = smem_raw + pstage * STAGE;
       const int64_t k0 = (int64_t)pk * BK2;
       const bool full = !KTAIL || k0 + BK2 <= p.K;
@@ -127,6 +137,27 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
   }
 
   G4_STAMP();      // prologue issued
+  if constexpr (NP > 0) {
+    if (producer) {
+      // ---- producer waves: one barrier per k-tile, exactly as the consumers' loop below.  k-tile c has landed once at most
+      // `ahead` younger k-tiles of this wave's own pieces are outstanding (nothing else is ever on this wave's counter).
+      for (int c = 0; c < total_k; ++c) {
+        const int ahead = min(S - 2, total_k - 1 - c);
+        if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
+        else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                // this k-tile is complete; everyone is done with the stage refilled next
+        if (pidx < total_k) {
+          char* st = smem_raw + pstage * STAGE;
+          const int64_t k0 = (int64_t)pk * BK2;
+#pragma unroll
+          for (int i = 0; i < LPT; ++i) issue(i, st, k0, true);
+          advance();
+        }
+      }
+      return;
+    }
+  }
   // ---- consumer side.  Fragment row = obase + (lane & 31) with obase % 32 == 0: the swizzle key is a per-lane constant
   const int key = (lane >> 1) & 7, hi = lane >> 5;
   int foff[4];
@@ -151,10 +182,12 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
       constexpr int NKS = decltype(nks_tag)::value;
       // k-tile cidx has landed once at most `ahead` younger k-tiles (LPT instructions each) are outstanding; epilogue
       // stores issued meanwhile are younger still, so the count only ever over-waits
-      const int ahead = min(S - 2, total_k - 1 - cidx);
-      if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
-      else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
-      else wait_vm<0>();
+      if constexpr (NP == 0) {
+        const int ahead = min(S - 2, total_k - 1 - cidx);
+        if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
+        else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
+        else wait_vm<0>();
+      }
       G4_STAMP();      // own share landed
       __builtin_amdgcn_s_barrier();                  // every wave's share landed; everyone is done with the previous stage
       G4_STAMP();      // barrier passed
@@ -162,7 +195,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S>::NTHR), (G4<WM, MT, NT, S>::WPS)
       const char* Bs = As + A_BYTES;
       cstage = (cstage + 1 == S) ? 0 : cstage + 1;
       ++cidx;
-      const bool refill = pidx < total_k;            // wave-uniform
+      const bool refill = NP == 0 && pidx < total_k; // wave-uniform
       char* st = smem_raw + pstage * STAGE;
       const int64_t k0 = (int64_t)pk * BK2;
       const bool full = !KTAIL || k0 + BK2 <= p.K;
@@ -365,9 +398,9 @@ int gemm4_form(const Params& p, int BM, int BN) {
   return 0;
 }
 
-template <int WM, int MT, int NT, int S, bool FORMS>
+template <int WM, int MT, int NT, int S, bool FORMS, int NP = 0>
 bool launch4(Params p, int wpc, hipStream_t s) {
-  typedef G4<WM, MT, NT, S> G;
+  typedef G4<WM, MT, NT, S, NP> G;
   if (p.K % BK2 != 0) return false;
   const int64_t ntiles = cdiv(p.M, G::BM) * cdiv(p.N, G::BN);
   p.ntiles = ntiles;
@@ -377,12 +410,12 @@ bool launch4(Params p, int wpc, hipStream_t s) {
   const dim3 grid((unsigned)g), block(G::NTHR);
   const int form = FORMS ? gemm4_form(p, G::BM, G::BN) : 0;
   if constexpr (FORMS) {
-    if (form == 1) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 1>), grid, block, 0, s, p); return true; }
-    if (form == 2) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 2>), grid, block, 0, s, p); return true; }
-    if (form == 3) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 3>), grid, block, 0, s, p); return true; }
-    if (form == 4) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 4>), grid, block, 0, s, p); return true; }
+    if (form == 1) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 1, NP>), grid, block, 0, s, p); return true; }
+    if (form == 2) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 2, NP>), grid, block, 0, s, p); return true; }
+    if (form == 3) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 3, NP>), grid, block, 0, s, p); return true; }
+    if (form == 4) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 4, NP>), grid, block, 0, s, p); return true; }
   }
-  hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 0>), grid, block, 0, s, p);
+  hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 0, NP>), grid, block, 0, s, p);
   return true;
 }
 
@@ -399,9 +432,12 @@ struct Variant { int code, wm, mt, nt, s; };
 
 }  // namespace
 
+// wave-specialised variants (4 producer waves, 3-stage ring, one workgroup per CU): 83 = 128 x 192, 84 = 128 x 128
 bool csts_gemm4_launch(const csts_gemm_params& p0, const csts_gemm_args* a, int variant, int wpc, hipStream_t s) {
   csts_gemm_params p = p0;
   p.stamps = (a != nullptr && a->workspace != nullptr && a->ws_bytes >= 8192) ? reinterpret_cast<unsigned long long*>(a->workspace) : nullptr;
+  if (variant == 83) return launch4<4, 1, 3, 3, true, 4>(p, 1, s);
+  if (variant == 84) return launch4<4, 1, 2, 3, true, 4>(p, 1, s);
 #define X(code, wm, mt, nt, st, forms) if (variant == code) return launch4<wm, mt, nt, st, forms>(p, wpc, s);
   G4_VARIANTS(X)
 #undef X
@@ -410,8 +446,13 @@ bool csts_gemm4_launch(const csts_gemm_params& p0, const csts_gemm_args* a, int 
 
 // the kernel csts_gemm4_launch starts for these parameters, as rocprofv3 prints it
 bool csts_gemm4_name(const csts_gemm_params& p, int variant, char* buf, int buflen) {
+  if (variant == 83 || variant == 84) {
+    const int nt = variant == 83 ? 3 : 2;
+    snprintf(buf, buflen, "gemm4_kernel<4, 1, %d, 3, %d, 4>", nt, gemm4_form(p, 128, 64 * nt));
+    return true;
+  }
 #define X(code, wm, mt, nt, st, forms) if (variant == code) { \
-    snprintf(buf, buflen, "gemm4_kernel<%d, %d, %d, %d, %d>", wm, mt, nt, st, forms ? gemm4_form(p, wm * 32 * mt, 64 * nt) : 0); return true; }
+    snprintf(buf, buflen, "gemm4_kernel<%d, %d, %d, %d, %d, 0>", wm, mt, nt, st, forms ? gemm4_form(p, wm * 32 * mt, 64 * nt) : 0); return true; }
   G4_VARIANTS(X)
 #undef X
   return false;
