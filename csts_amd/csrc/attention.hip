@@ -1329,10 +1329,11 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
   } else {
     const size_t sm = smem_bwd<HD, F32>() + (size_t)Cfg<HD, F32>::KVBLK * 4 * sizeof(float);   // + LSE / delta of the tile(s)
     if (!dkv_fast(p.dt, HD, p.mask_mode, p.Nq)) {
-      // masked / ragged shapes (and every fp32 call) take the per-element tests
-      const bool slow = F32 || p.mask_mode != 0 || p.Nq % Cfg<HD, F32>::KVBLK != 0;           // (q_chunk is a multiple of the tile)
+      // masked / ragged shapes (and every fp32 call) take the per-element tests.  <96, false, false> IS the FAST form (128-query
+      // tiles, its own LDS size): every other hd 96 / bf16 call takes the SLOW instantiation, whatever its shape
+      const bool slow = F32 || (HD == 96) || p.mask_mode != 0 || p.Nq % Cfg<HD, F32>::KVBLK != 0;   // (q_chunk is a multiple of the tile)
       if (slow) hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, true>), grid, dim3(256), sm, stream, p);
-      else hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, F32>), grid, dim3(256), sm, stream, p);
+      else hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, F32 || HD == 96>), grid, dim3(256), sm, stream, p);
     } else if constexpr (!F32 && HD == 96) {
       // 128-query tiles, double-buffered, + statistics: 108 KB of dynamic LDS (one workgroup per CU either way)
       constexpr size_t smf = (size_t)2 * 128 * 2 * Cfg<96, false>::LD_ROW * 2 + 2 * 2 * 128 * sizeof(float);

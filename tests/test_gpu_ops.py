@@ -682,8 +682,67 @@ def test_tap_sums_both_gradients_and_bf16_copy_is_version_guarded():
     assert ops._grad16(g, L.BF16) is None
 
 
+def _attn_bwd_outputs():
+    """csts_attn_bwd (bf16, hd 96) on shapes that take every combination of the FAST / generic dQ and dK/dV kernels (called
+    in-process and in a child process with the FAST forms switched off)."""
+    import ctypes as C
+    outs = []
+    hd = 96
+    for (B, H, Nq, Nk) in [(1, 2, 512, 256), (2, 1, 384, 192), (1, 2, 192, 100), (1, 1, 1024, 640), (1, 3, 320, 64)]:
+        Cc = H * hd
+        q = rnd(B, Nq, Cc, seed=21).to(torch.bfloat16)
+        k, v = rnd(B, Nk, Cc, seed=22).to(torch.bfloat16), rnd(B, Nk, Cc, seed=23).to(torch.bfloat16)
+        do = rnd(B, Nq, Cc, seed=24).to(torch.bfloat16)
+        o = torch.empty_like(q)
+        lse, delta = torch.empty(B, H, Nq, device=DEV), torch.empty(B, H, Nq, device=DEV)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        a = L.AttnArgs()
+        a.Q, a.K, a.V, a.O, a.LSE = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+        a.dO, a.delta, a.dQ, a.dK, a.dV = do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        a.dtype, a.B, a.H, a.Nq, a.Nk, a.head_dim = L.BF16, B, H, Nq, Nk, hd
+        sq, sk = (C.c_int64 * 3)(Nq * Cc, Cc, hd), (C.c_int64 * 3)(Nk * Cc, Cc, hd)
+        a.q_strides = sq; a.o_strides = sq; a.do_strides = sq; a.dq_strides = sq
+        a.k_strides = sk; a.v_strides = sk; a.dk_strides = sk; a.dv_strides = sk
+        a.scale = hd ** -0.5
+        lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(lib.csts_attn_fwd(C.byref(a), st), "fwd")
+        ws = torch.empty(max(16, lib.csts_attn_bwd_workspace(C.byref(a))), dtype=torch.uint8, device=DEV)
+        L.check(lib.csts_attn_bwd(C.byref(a), ws.data_ptr(), ws.numel(), st), "bwd")
+        torch.cuda.synchronize()
+        qf = q.float().reshape(B, Nq, H, hd).transpose(1, 2).detach().requires_grad_(True)
+        kf = k.float().reshape(B, Nk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+        vf = v.float().reshape(B, Nk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+        of = torch.softmax(qf @ kf.transpose(-1, -2) * hd ** -0.5, -1) @ vf
+        of.backward(do.float().reshape(B, Nq, H, hd).transpose(1, 2))
+        back = lambda t, n: t.transpose(1, 2).reshape(B, n, Cc)
+        for got, ref, what in [(dq, back(qf.grad, Nq), "dq"), (dk, back(kf.grad, Nk), "dk"), (dv, back(vf.grad, Nk), "dv")]:
+            assert rel_l2(got.float(), ref) < 2e-2, (what, B, H, Nq, Nk)
+        outs += [delta.cpu(), dq.cpu(), dk.cpu(), dv.cpu()]
+    return outs
+
+
+def test_attention_backward_fast_forms_match_generic(tmp_path):
+    """attn_dq_fast_kernel / the FAST form of attn_dkv_kernel (LDS-DMA tiles, MFMA slot stream) against the generic kernels (a
+    child process with CSTS_ATTN_DQ_FAST=0 CSTS_ATTN_DKV_FAST=0) on shapes that mix whole and ragged tiles on either side; both
+    are also checked against fp32 autograd inside _attn_bwd_outputs.  Same products in the same order per 32-row unit: the
+    results agree to bf16 rounding of partial sums that are split differently (128- vs 64-query tiles)."""
+    import os
+    import subprocess
+    import sys
+    fast = _attn_bwd_outputs()
+    out = str(tmp_path / "generic.pt")
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_ops as t; torch.save(t._attn_bwd_outputs(), %r)"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTS_ATTN_DQ_FAST="0", CSTS_ATTN_DKV_FAST="0"), check=True, timeout=600)
+    generic = torch.load(out)
+    assert len(fast) == len(generic)
+    for i, (a, b) in enumerate(zip(fast, generic)):
+        assert rel_l2(a.float(), b.float()) < 4e-3, i
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,hd", [(1, 2, 4096, 2048, 96), (2, 1, 8192, 512, 96), (1, 4, 1000, 2048, 96), (1, 2, 2048, 1024, 192),
-                                           (1, 1, 16384, 4096, 96)])
+                                           (1, 1, 16384, 4096, 96), (1, 2, 192, 448, 96), (1, 1, 640, 100, 96)])
 def test_attention_bf16_backward_many_key_tiles(B, H, Nq, Nk, hd):
     """csts_attn_fwd / csts_attn_bwd in bf16 at the key counts of the benchmarked grids (N_k = 512 ... 2048 at 16x256^2, 4096 at
     32x256^2): keys span many LDS tiles (online softmax over them), queries are split over workgroups, dK / dV partials go
