@@ -730,14 +730,17 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
   }
 }
 
-// dQ, FAST form (hd 96, bf16, no mask, every 64-key tile whole): K / V tiles by LDS-DMA and the MFMA slot stream of
+// dQ, FAST form (hd 96, bf16, no mask, every KT * 32-key tile whole): K / V tiles by LDS-DMA and the MFMA slot stream of
 // attn_dkv_kernel (operands requested DEPTH slots ahead, scheduling fence per slot).  Per 32-key unit u: SC(u) = S and dP
 // (12 slots, operands = rows of K / V, the query fragments in registers), PV(u) = dQ += dS K (6 slots, transposed reads of
-// K).  Block order SC(0) SC(1) PV(0) PV(1); dS(0) = P (dP - delta) rides in two-register pieces on SC(1), dS(1) on PV(0).
-__global__ __launch_bounds__(256, 2) void attn_dq_fast_kernel(AttnP p) {
+// K).  Block order SC(0) SC(1) PV(0) SC(2) PV(1) ... SC(KT-1) PV(KT-2) PV(KT-1); dS(u) = P (dP - delta) rides in two-register
+// pieces on the block after SC(u): dS(0) on SC(1) (one piece per slot), dS(u >= 1) on PV(u - 1) (8 pieces on 6 slots).
+// KT = 2: 64-key tiles, two workgroups per CU.  KT = 4: 128-key tiles, one workgroup per CU (106 KB of LDS).
+template <int KT>
+__global__ __launch_bounds__(256, (KT == 2 ? 2 : 1)) void attn_dq_fast_kernel(AttnP p) {
   constexpr int HD = 96;
   typedef Cfg<HD, false> C;
-  constexpr int KBLK = 64, KT = KBLK / 32, LD = C::LD_ROW;
+  constexpr int KBLK = 32 * KT, LD = C::LD_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
@@ -785,22 +788,22 @@ __global__ __launch_bounds__(256, 2) void attn_dq_fast_kernel(AttnP p) {
 
   tile_loop_dma<HD, KBLK, LD, false>(smem, p.K, kbase, p.k_ts, p.V, vbase, p.v_ts, 0, p.Nk, tid,
                                      [&](const bf16* Ks, const bf16* Vs, int) {
-    constexpr int NS = HD / 16, ND = HD / 32, SCB = 2 * NS, PVB = 2 * ND, DEPTH = 4, TOTAL = KT * (SCB + PVB);
-    static_assert(KT == 2, "block order below is written for two units per tile");
+    constexpr int NS = HD / 16, ND = HD / 32, SCB = 2 * NS, PVB = 2 * ND, DEPTH = 4, NBLK = 2 * KT, TOTAL = KT * (SCB + PVB);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
     const bf16* rowK = Ks + (lane & 31) * LD + 8 * h;
     const bf16* rowV = Vs + (lane & 31) * LD + 8 * h;
     const bf16* trK = Ks + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
-    // slot g -> (block, k): blocks SC(0) [0, 12), SC(1) [12, 24), PV(0) [24, 30), PV(1) [30, 36)
-    auto is_pv = [](int g) constexpr { return g >= 2 * SCB; };
-    auto unit = [](int g) constexpr { return g < SCB ? 0 : g < 2 * SCB ? 1 : g < 2 * SCB + PVB ? 0 : 1; };
-    auto kk = [](int g) constexpr { return g < 2 * SCB ? g % SCB : (g - 2 * SCB) % PVB; };
+    // block bi of the order above: is it a PV block, which unit, how many slots, its first slot
+    auto blk_pv = [](int bi) constexpr { return bi == NBLK - 1 || (bi >= 2 && (bi & 1) == 0); };
+    auto blk_unit = [](int bi) constexpr { return bi == 0 ? 0 : bi == NBLK - 1 ? KT - 1 : (bi & 1) ? (bi + 1) / 2 : bi / 2 - 1; };
+    auto blk_of = [=](int g) constexpr { int bi = 0, s0 = 0; for (;; ++bi) { const int n = blk_pv(bi) ? PVB : SCB; if (g < s0 + n) return bi; s0 += n; } };
+    auto blk_start = [=](int bi) constexpr { int s0 = 0; for (int i = 0; i < bi; ++i) s0 += blk_pv(i) ? PVB : SCB; return s0; };
     bf16x8 ring[DEPTH + 1];
     auto request = [&](auto gc) {
-      constexpr int g = decltype(gc)::value, u = unit(g), k = kk(g);
+      constexpr int g = decltype(gc)::value, bi = blk_of(g), u = blk_unit(bi), k = g - blk_start(bi);
       bf16x8& dst = ring[g % (DEPTH + 1)];
-      if constexpr (!is_pv(g)) {
+      if constexpr (!blk_pv(bi)) {
         dst = *reinterpret_cast<const bf16x8*>((k < NS ? rowK : rowV) + u * 32 * LD + 16 * (k % NS));
       } else {
         constexpr int s2 = k / ND, d = k % ND;
@@ -814,38 +817,40 @@ __global__ __launch_bounds__(256, 2) void attn_dq_fast_kernel(AttnP p) {
     static_for<DEPTH>([&](auto gc) { request(gc); });
     f32x16 S[2], dP[2];
     bf16x8 bp[2][2];
-    // dS of registers 2 q, 2 q + 1 of unit su
+    // dS of registers 2 q, 2 q + 1 of unit su (S / dP / bp double-buffered by unit parity)
     auto piece = [&](auto suc, auto qc) {
-      constexpr int su = decltype(suc)::value, q = decltype(qc)::value;
+      constexpr int sp = decltype(suc)::value & 1, q = decltype(qc)::value;
 #pragma unroll
       for (int r = 2 * q; r < 2 * q + 2; ++r) {
-        const float ds = __builtin_amdgcn_exp2f(__builtin_fmaf(S[su][r], p.scale_log2, negL)) * (dP[su][r] - dl);
-        bp[su][r / 8][r % 8] = (bf16)ds;
+        const float ds = __builtin_amdgcn_exp2f(__builtin_fmaf(S[sp][r], p.scale_log2, negL)) * (dP[sp][r] - dl);
+        bp[sp][r / 8][r % 8] = (bf16)ds;
       }
     };
     static_for<TOTAL>([&](auto gc) {
-      constexpr int g = decltype(gc)::value, u = unit(g), k = kk(g);
-      if constexpr (!is_pv(g) && k == 0) {
+      constexpr int g = decltype(gc)::value, bi = blk_of(g), u = blk_unit(bi), k = g - blk_start(bi), par = u & 1;
+      constexpr bool is_pv = blk_pv(bi);
+      if constexpr (!is_pv && k == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { S[u][r] = 0.f; dP[u][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { S[par][r] = 0.f; dP[par][r] = 0.f; }
       }
       if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
       const bf16x8 a = ring[g % (DEPTH + 1)];
-      if constexpr (!is_pv(g)) {
-        if constexpr (k < NS) S[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf.b[k], S[u], 0, 0, 0);
-        else dP[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dof.b[k - NS], dP[u], 0, 0, 0);
+      if constexpr (!is_pv) {
+        if constexpr (k < NS) S[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf.b[k], S[par], 0, 0, 0);
+        else dP[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dof.b[k - NS], dP[par], 0, 0, 0);
       } else {
         constexpr int s2 = k / ND, d = k % ND;
-        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp[u][s2], acc[d], 0, 0, 0);
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp[par][s2], acc[d], 0, 0, 0);
       }
-      if constexpr (g >= SCB && g < SCB + 8) {                       // dS(0) under SC(1): one piece per slot
-        piece(std::integral_constant<int, 0>{}, std::integral_constant<int, g - SCB>{});
-      } else if constexpr (g >= 2 * SCB && g < 2 * SCB + PVB) {      // dS(1) under PV(0): 8 pieces on 6 slots
-        constexpr int j = g - 2 * SCB;
-        if constexpr (j < 4) piece(std::integral_constant<int, 1>{}, std::integral_constant<int, j>{});
+      // the dS pieces of the unit whose SC block came just before this block
+      if constexpr (bi == 1) {                                       // dS(0) under SC(1): one piece per slot
+        if constexpr (k < 8) piece(std::integral_constant<int, 0>{}, std::integral_constant<int, k>{});
+      } else if constexpr (bi >= 2 && (bi & 1) == 0) {               // dS(bi / 2) under PV(bi / 2 - 1): 8 pieces on 6 slots
+        constexpr int su = bi / 2;
+        if constexpr (k < 4) piece(std::integral_constant<int, su>{}, std::integral_constant<int, k>{});
         else {
-          piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 4 + 2 * (j - 4)>{});
-          piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 5 + 2 * (j - 4)>{});
+          piece(std::integral_constant<int, su>{}, std::integral_constant<int, 4 + 2 * (k - 4)>{});
+          piece(std::integral_constant<int, su>{}, std::integral_constant<int, 5 + 2 * (k - 4)>{});
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1279,10 +1284,13 @@ bool dkv_fast(int dt, int hd, int mask_mode, int Nq) {
   return !off && dt == CSTS_BF16 && hd == 96 && mask_mode == 0 && Nq % 128 == 0;
 }
 
-// attn_dq_fast_kernel: hd 96, bf16, no mask, every 64-key tile whole
-bool dq_fast(int dt, int hd, int mask_mode, int Nk) {
-  static const bool off = [] { const char* e = getenv("CSTS_ATTN_DQ_FAST"); return e && atoi(e) == 0; }();
-  return !off && dt == CSTS_BF16 && hd == 96 && mask_mode == 0 && Nk % 64 == 0;
+// attn_dq_fast_kernel: hd 96, bf16, no mask, every key tile whole.  Returns the 32-key units per tile (0: generic kernel).
+// 2 (64-key tiles, two workgroups per CU) is the library's choice: 128-key tiles at one workgroup per CU measured 3-17 %
+// slower per call (profiles/r3_attn_backward_ab.txt).  CSTS_ATTN_DQ_FAST = 0 / 4 forces the generic kernel / the 128-key form.
+int dq_fast(int dt, int hd, int mask_mode, int Nk) {
+  static const int force = [] { const char* e = getenv("CSTS_ATTN_DQ_FAST"); return e ? atoi(e) : -1; }();
+  if (force == 0 || dt != CSTS_BF16 || hd != 96 || mask_mode != 0 || Nk % 64 != 0) return 0;
+  return (force == 4 && Nk % 128 == 0) ? 4 : 2;
 }
 
 void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
@@ -1324,7 +1332,13 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
     hipLaunchKernelGGL((attn_fwd_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else if (which == K_DQ) {
     const size_t sm = smem_bwd<HD, F32>();
-    if (dq_fast(p.dt, HD, p.mask_mode, p.Nk)) hipLaunchKernelGGL(attn_dq_fast_kernel, grid, dim3(256), sm, stream, p);
+    if (const int kt = dq_fast(p.dt, HD, p.mask_mode, p.Nk); kt == 4) {
+      constexpr size_t sm4 = (size_t)2 * 128 * 2 * Cfg<96, false>::LD_ROW * 2;       // 128-key K and V tiles, double-buffered
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dq_fast_kernel<4>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
+      (void)attr;
+      hipLaunchKernelGGL(attn_dq_fast_kernel<4>, grid, dim3(256), sm4, stream, p);
+    } else if (kt == 2) hipLaunchKernelGGL(attn_dq_fast_kernel<2>, grid, dim3(256), sm, stream, p);
     else hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else {
     const size_t sm = smem_bwd<HD, F32>() + (size_t)Cfg<HD, F32>::KVBLK * 4 * sizeof(float);   // + LSE / delta of the tile(s)
