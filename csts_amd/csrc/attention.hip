@@ -387,18 +387,24 @@ __device__ __forceinline__ void dma16(const char* base, unsigned lane_off, const
   const uint32_t l = (uint32_t)(uintptr_t)(attn_lptr_t)lds_dst;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane_off), "s"(base) : "memory", "m0");
 }
-template <int HD, int ROWS, int LD, bool STATS = true, typename Body>
+template <int HD, int ROWS, int LD, bool STATS = true, int LDY = LD, typename Body>
 __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t xbase, int64_t xts, const void* Y,
                                               int64_t ybase, int64_t yts, int row_beg, int row_end, int tid, Body&& body,
                                               const float* S1 = nullptr, const float* S2 = nullptr AT_STAMP_PARAMS) {
-  constexpr int CPR = HD / 8, SPR = LD / 8, NI = ROWS * SPR / 64, MAXI = (NI + 3) / 4, TILE = ROWS * 2 * LD;
-  static_assert(LD % 8 == 0 && (ROWS * SPR) % 64 == 0 && (ROWS == 64 || ROWS == 128), "LDS image must be whole wave instructions");
+  constexpr int CPR = HD / 8, SPRX = LD / 8, SPRY = LDY / 8, NIX = ROWS * SPRX / 64, NIY = ROWS * SPRY / 64;
+  constexpr int MAXIX = (NIX + 3) / 4, MAXIY = (NIY + 3) / 4, TILE = ROWS * (LD + LDY);
+  static_assert(LD % 8 == 0 && LDY % 8 == 0 && (ROWS * SPRX) % 64 == 0 && (ROWS * SPRY) % 64 == 0 && SPRX >= CPR && SPRY >= CPR &&
+                    (ROWS == 64 || ROWS == 128), "LDS images must be whole wave instructions");
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned xo[MAXI], yo[MAXI];                 // byte offsets of this lane's slot in instruction w + 4 i of a tile (tile-invariant)
+  unsigned xo[MAXIX], yo[MAXIY];               // byte offsets of this lane's slot in instruction w + 4 i of a tile (tile-invariant)
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i) {
-    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPR, c = min(slot - row * SPR, CPR - 1);
+  for (int i = 0; i < MAXIX; ++i) {
+    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPRX, c = min(slot - row * SPRX, CPR - 1);
     xo[i] = (unsigned)(row * (int)xts + c * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXIY; ++i) {
+    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPRY, c = min(slot - row * SPRY, CPR - 1);
     yo[i] = (unsigned)(row * (int)yts + c * 8) * 2u;
   }
   float* stats = reinterpret_cast<float*>(smem + 2 * TILE);      // [2 buffers][2][ROWS]
@@ -408,12 +414,14 @@ __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t
     char* dx = reinterpret_cast<char*>(smem + buf * TILE);
     char* dy = dx + ROWS * LD * 2;
 #pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
+    for (int i = 0; i < MAXIX; ++i) {
       const int t = w + 4 * i;                 // wave-uniform
-      if (t < NI) {
-        dma16(xs, xo[i], dx + t * 1024);
-        dma16(ys, yo[i], dy + t * 1024);
-      }
+      if (t < NIX) dma16(xs, xo[i], dx + t * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXIY; ++i) {
+      const int t = w + 4 * i;
+      if (t < NIY) dma16(ys, yo[i], dy + t * 1024);
     }
     // LSE and delta of the tile's rows, one dword per lane: 64 rows -> waves 0 / 1; 128 rows -> waves 0, 1 / 2, 3
     constexpr int WPS = ROWS / 64;
@@ -607,6 +615,117 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_ke
     stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, O, 1.f / lsum,
                        w * 32 + (lane & 31), h, tid);
   }
+  if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
+}
+
+// forward, FAST form (hd 96, bf16, no mask, every 64-key tile whole): K / V tiles by LDS-DMA (K rows padded to 104 elements,
+// V -- read transposed only -- unpadded) and the MFMA slot stream of the backward kernels: 12 slots S = Q K^T (two 32-key
+// units), the online softmax of the tile (it needs the maximum over both units, so it cannot ride on its own block), 12 slots
+// O += P V; the operand of slot g + DEPTH is requested before the MFMA of slot g, across the softmax as well.
+__global__ __launch_bounds__(256, 3) void attn_fwd_fast_kernel(AttnP p) {
+  constexpr int HD = 96;
+  typedef Cfg<HD, false> C;
+  constexpr int KBLK = 64, LDK = C::LD_ROW, LDV = C::LD_TR;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  const bool qvalid = qraw < p.Nq;
+  const int qi = qvalid ? qraw : p.Nq - 1;
+
+  RowFrag<HD, false> qf;
+  stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+  __syncthreads();
+  frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
+  __syncthreads();          // the K/V tile loop reuses this LDS
+  f32x16 O[HD / 32];
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+  float m = -1e30f, lsum = 0.f;
+  const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs;
+  const int64_t vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
+
+  tile_loop_dma<HD, KBLK, LDK, false, LDV>(smem, p.K, kbase, p.k_ts, p.V, vbase, p.v_ts, 0, p.Nk, tid,
+                                           [&](const bf16* Ks, const bf16* Vs, int) {
+    constexpr int NS = HD / 16, ND = HD / 32, SCB = 2 * NS, DEPTH = 4, TOTAL = 2 * SCB;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+    const bf16* rowK = Ks + (lane & 31) * LDK + 8 * h;
+    const bf16* trV = Vs + (4 * h + qq) * LDV + 16 * g1 + 4 * pp;
+    bf16x8 ring[DEPTH + 1];
+    auto request = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      bf16x8& dst = ring[g % (DEPTH + 1)];
+      if constexpr (g < SCB) {
+        constexpr int u = g / NS, k = g % NS;
+        dst = *reinterpret_cast<const bf16x8*>(rowK + u * 32 * LDK + 16 * k);
+      } else {
+        constexpr int j = g - SCB, u = j / (2 * ND), s2 = (j % (2 * ND)) / ND, d = j % ND;
+        const bf16* Yb = trV + (u * 32 + 16 * s2) * LDV + 32 * d;
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb)));
+        const bf16x4 b1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 8 * LDV)));
+        dst[0] = b0[0]; dst[1] = b0[1]; dst[2] = b0[2]; dst[3] = b0[3];
+        dst[4] = b1[0]; dst[5] = b1[1]; dst[6] = b1[2]; dst[7] = b1[3];
+      }
+    };
+    static_for<DEPTH>([&](auto gc) { request(gc); });
+    f32x16 S[2];
+    bf16x8 bp[2][2];
+    static_for<TOTAL>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g == 0 || g == NS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[g / NS][r] = 0.f;
+      }
+      if constexpr (g == SCB) {
+        // online softmax of the tile (same arithmetic, in the same order, as attn_fwd_kernel): lazy running maximum -- rescale
+        // only when some row's maximum grew by more than 2^8 -- the scale rides on the exp2 argument's fma
+        float mx = S[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float ms = mx * p.scale_log2;
+        const bool grow = ms > m + 8.f;
+        if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+          const float mn = grow ? ms : m;
+          const float alpha = __builtin_amdgcn_exp2f(m - mn);
+          m = mn;
+          lsum *= alpha;
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+        }
+        const float negm = -m;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kt][r], p.scale_log2, negm));
+            lsum += e;
+            bp[kt][r / 8][r % 8] = (bf16)e;
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
+      const bf16x8 a = ring[g % (DEPTH + 1)];
+      if constexpr (g < SCB) {
+        S[g / NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf.b[g % NS], S[g / NS], 0, 0, 0);
+      } else {
+        constexpr int j = g - SCB, u = j / (2 * ND), s2 = (j % (2 * ND)) / ND, d = j % ND;
+        O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp[u][s2], O[d], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
+  lsum += __shfl_xor(lsum, 32, 64);
+  stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, O, 1.f / lsum,
+                     w * 32 + (lane & 31), h, tid);
   if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
 }
 
@@ -1329,7 +1448,11 @@ template <int HD, bool F32>
 static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream) {
   if (which == K_FWD) {
     const size_t sm = smem_fwd<HD, F32>();
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
+    static const bool fast_off = [] { const char* e = getenv("CSTS_ATTN_FWD_FAST"); return e && atoi(e) == 0; }();
+    if (!fast_off && !F32 && HD == 96 && p.mask_mode == 0 && p.Nk % 64 == 0)
+      hipLaunchKernelGGL(attn_fwd_fast_kernel, grid, dim3(256), sm, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
   } else if (which == K_DQ) {
     const size_t sm = smem_bwd<HD, F32>();
     if (const int kt = dq_fast(p.dt, HD, p.mask_mode, p.Nk); kt == 4) {
