@@ -718,13 +718,14 @@ def _attn_bwd_outputs():
         back = lambda t, n: t.transpose(1, 2).reshape(B, n, Cc)
         for got, ref, what in [(dq, back(qf.grad, Nq), "dq"), (dk, back(kf.grad, Nk), "dk"), (dv, back(vf.grad, Nk), "dv")]:
             assert rel_l2(got.float(), ref) < 2e-2, (what, B, H, Nq, Nk)
-        outs += [delta.cpu(), dq.cpu(), dk.cpu(), dv.cpu()]
+        assert rel_l2(o.float(), back(of, Nq)) < 1e-2, ("o", B, H, Nq, Nk)
+        outs += [o.cpu(), lse.cpu(), delta.cpu(), dq.cpu(), dk.cpu(), dv.cpu()]
     return outs
 
 
 def test_attention_backward_fast_forms_match_generic(tmp_path):
-    """attn_dq_fast_kernel / the FAST form of attn_dkv_kernel (LDS-DMA tiles, MFMA slot stream) against the generic kernels (a
-    child process with CSTS_ATTN_DQ_FAST=0 CSTS_ATTN_DKV_FAST=0) on shapes that mix whole and ragged tiles on either side; both
+    """attn_fwd_fast_kernel / attn_dq_fast_kernel / the FAST form of attn_dkv_kernel (LDS-DMA tiles, MFMA slot stream) against the
+    generic kernels (a child process with CSTS_ATTN_{FWD,DQ,DKV}_FAST=0) on shapes that mix whole and ragged tiles on either side; both
     are also checked against fp32 autograd inside _attn_bwd_outputs.  Same products in the same order per 32-row unit: the
     results agree to bf16 rounding of partial sums that are split differently (128- vs 64-query tiles)."""
     import os
@@ -734,7 +735,8 @@ def test_attention_backward_fast_forms_match_generic(tmp_path):
     out = str(tmp_path / "generic.pt")
     code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_ops as t; torch.save(t._attn_bwd_outputs(), %r)"
             % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out))
-    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTS_ATTN_DQ_FAST="0", CSTS_ATTN_DKV_FAST="0"), check=True, timeout=600)
+    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTS_ATTN_FWD_FAST="0", CSTS_ATTN_DQ_FAST="0", CSTS_ATTN_DKV_FAST="0"),
+                   check=True, timeout=600)
     generic = torch.load(out)
     assert len(fast) == len(generic)
     for i, (a, b) in enumerate(zip(fast, generic)):
