@@ -1394,7 +1394,8 @@ bool strides_ok(const int64_t* s, int dt) {
 
 // one-pass backward (attn_bwd_fused_kernel): bf16, head_dim 96, all keys in one LDS tile, no mask, enough queries to split
 bool fused_bwd_ok(const csts_attn_args* a) {
-  return a->dtype == CSTS_BF16 && a->head_dim == 96 && a->Nk <= 128 && a->mask_mode == 0 && a->Nq >= 1024;
+  static const bool off = [] { const char* e = getenv("CSTS_ATTN_FUSED_BWD"); return e && atoi(e) == 0; }();
+  return !off && a->dtype == CSTS_BF16 && a->head_dim == 96 && a->Nk <= 128 && a->mask_mode == 0 && a->Nq >= 1024;
 }
 
 // attn_dkv_kernel's FAST form: hd 96, bf16, no mask, every query tile whole (128 queries)
