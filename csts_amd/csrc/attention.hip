@@ -1446,7 +1446,7 @@ void dkv_plan(const csts_attn_args* a, int& nsplit, int& q_chunk) {
 
 enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
 template <int HD, bool F32>
-static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream) {
+static bool attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream) {
   if (which == K_FWD) {
     const size_t sm = smem_fwd<HD, F32>();
     static const bool fast_off = [] { const char* e = getenv("CSTS_ATTN_FWD_FAST"); return e && atoi(e) == 0; }();
@@ -1458,9 +1458,7 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
     const size_t sm = smem_bwd<HD, F32>();
     if (const int kt = dq_fast(p.dt, HD, p.mask_mode, p.Nk); kt == 4) {
       constexpr size_t sm4 = (size_t)2 * 128 * 2 * Cfg<96, false>::LD_ROW * 2;       // 128-key K and V tiles, double-buffered
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dq_fast_kernel<4>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm4);
-      (void)attr;
+      if (!csts_dyn_lds_optin(reinterpret_cast<const void*>(&attn_dq_fast_kernel<4>), (int)sm4)) return false;
       hipLaunchKernelGGL(attn_dq_fast_kernel<4>, grid, dim3(256), sm4, stream, p);
     } else if (kt == 2) hipLaunchKernelGGL(attn_dq_fast_kernel<2>, grid, dim3(256), sm, stream, p);
     else hipLaunchKernelGGL((attn_dq_kernel<HD, F32>), grid, dim3(256), sm, stream, p);
@@ -1475,22 +1473,16 @@ static void attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
     } else if constexpr (!F32 && HD == 96) {
       // 128-query tiles, double-buffered, + statistics: 108 KB of dynamic LDS (one workgroup per CU either way)
       constexpr size_t smf = (size_t)2 * 128 * 2 * Cfg<96, false>::LD_ROW * 2 + 2 * 2 * 128 * sizeof(float);
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_dkv_kernel<96, false, false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smf);
-      (void)attr;
+      if (!csts_dyn_lds_optin(reinterpret_cast<const void*>(&attn_dkv_kernel<96, false, false>), (int)smf)) return false;
       hipLaunchKernelGGL((attn_dkv_kernel<96, false, false>), grid, dim3(256), smf, stream, p);
     }
   }
+  return true;
 }
-static void attn_dispatch(int which, const csts_attn_args* a, const AttnP& p, dim3 grid, hipStream_t stream) {
+static bool attn_dispatch(int which, const csts_attn_args* a, const AttnP& p, dim3 grid, hipStream_t stream) {
   const bool f32 = a->dtype == CSTS_F32;
-  if (a->head_dim == 96) {
-    if (f32) attn_launch<96, true>(which, p, grid, stream);
-    else attn_launch<96, false>(which, p, grid, stream);
-  } else {
-    if (f32) attn_launch<192, true>(which, p, grid, stream);
-    else attn_launch<192, false>(which, p, grid, stream);
-  }
+  if (a->head_dim == 96) return f32 ? attn_launch<96, true>(which, p, grid, stream) : attn_launch<96, false>(which, p, grid, stream);
+  return f32 ? attn_launch<192, true>(which, p, grid, stream) : attn_launch<192, false>(which, p, grid, stream);
 }
 
 extern "C" int csts_attn_fwd(const csts_attn_args* a, hipStream_t stream) {
@@ -1498,7 +1490,7 @@ extern "C" int csts_attn_fwd(const csts_attn_args* a, hipStream_t stream) {
   CSTS_REQUIRE(a->O && a->LSE && aligned16(a->O) && strides_ok(a->o_strides, a->dtype), "bad output");
   AttnP p; fill(a, p);
   dim3 grid((unsigned)cdiv(a->Nq, 128), a->H, a->B);
-  attn_dispatch(K_FWD, a, p, grid, stream);
+  CSTS_REQUIRE(attn_dispatch(K_FWD, a, p, grid, stream), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on this device");
   CSTS_LAUNCH_CHECK();
   return 0;
 }
@@ -1537,7 +1529,7 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
   // 1 + 2. delta = rowsum(dO * O) and dQ (the dQ kernel computes delta from its staged O rows and leaves it for step 3)
   {
     dim3 grid((unsigned)cdiv(a->Nq, 128), a->H, a->B);
-    attn_dispatch(K_DQ, a, p, grid, stream);
+    CSTS_REQUIRE(attn_dispatch(K_DQ, a, p, grid, stream), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on this device");
     CSTS_LAUNCH_CHECK();
   }
   // 3. dK, dV (query-split, deterministic reduce)
@@ -1548,7 +1540,7 @@ extern "C" int csts_attn_bwd(const csts_attn_args* a, void* workspace, size_t ws
       p.ws = reinterpret_cast<float*>(workspace);
     }
     dim3 grid((unsigned)cdiv(a->Nk, 128), p.nsplit, a->B * a->H);
-    attn_dispatch(K_DKV, a, p, grid, stream);
+    CSTS_REQUIRE(attn_dispatch(K_DKV, a, p, grid, stream), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed on this device");
     CSTS_LAUNCH_CHECK();
     if (p.nsplit > 1) {
       const int64_t total = (int64_t)2 * a->B * a->H * a->Nk * a->head_dim / 8;

@@ -36,6 +36,23 @@ void csts_set_error(const std::string& s);
     if (e__ != hipSuccess) CSTS_FAIL(std::string("launch: ") + hipGetErrorString(e__)); \
   } while (0)
 
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute is per (function, device): done once for each pair a
+// process launches on, and a failure is reported to the caller instead of surfacing as an opaque launch error.
+#include <mutex>
+#include <set>
+#include <utility>
+static inline bool csts_dyn_lds_optin(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({fn, dev})) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done.insert({fn, dev});
+  return true;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

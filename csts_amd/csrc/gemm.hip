@@ -1326,6 +1326,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   }
   if (a->algo % 1000 >= 400 && a->algo % 1000 < 500) {   // forced: 1000 * workgroups-per-CU + 400 + gemm4 variant code (gemm4.hip)
     CSTS_REQUIRE(v3_ok(a, split), "algo 4xx (8-wave LDS-DMA NT kernel) not applicable to this problem");
+    CSTS_REQUIRE(a->K % 64 == 0, "algo 4xx needs K % 64 == 0 (no k-tail instantiations)");
     CSTS_REQUIRE(csts_gemm4_launch(p, a, a->algo % 1000 - 400, a->algo / 1000, stream), "unknown gemm4 variant");
     CSTS_LAUNCH_CHECK();
     return 0;
@@ -1333,7 +1334,7 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   {
     int v4;
     if (pick4(a, split, &v4)) {
-      csts_gemm4_launch(p, a, v4, 0, stream);
+      CSTS_REQUIRE(csts_gemm4_launch(p, a, v4, 0, stream), "gemm4 heuristic picked a variant that is not instantiated");
       CSTS_LAUNCH_CHECK();
       return 0;
     }

@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSTS_HIP_LIB") or os.path.join(_HERE, "libcsts_hip.so")   # override: A/B runs of two builds on one box
 
+ABI_VERSION = 3   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
@@ -196,6 +197,12 @@ def load() -> C.CDLL:
             raise CstsError(f"{LIB_PATH} does not export {name}: stale build?")
         fn.restype = res
         fn.argtypes = args
+    got = lib.csts_abi_version()
+    if got != ABI_VERSION:
+        # a stale / alternate build reads the argument structs with another layout (e.g. a pre-res_up library would read
+        # the coarse decoder skip as a plain residual: out-of-bounds reads, silently wrong outputs) -- never run it
+        raise CstsError(f"{LIB_PATH} has C-ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                        "(`make -C csts_amd/csrc`) or point CSTS_HIP_LIB at a matching build")
     _lib = lib
     return lib
 

@@ -31,6 +31,11 @@ enum { CSTS_GEMM_NT = 0, CSTS_GEMM_NN = 1, CSTS_GEMM_TN = 2 };
 enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 
+/* Version of this header's struct layouts and call semantics.  Bumped whenever a struct grows or a field changes meaning
+ * (2: csts_gemm_args.res_up; 3: fused-MLP entry points, compact K|V pooling).  csts_abi_version() returns the value the
+ * LIBRARY was built with: a caller must compare it with the CSTS_ABI_VERSION it was compiled against and refuse a mismatch
+ * (the Python binding does, csts_amd/lib.py::load). */
+#define CSTS_ABI_VERSION 3
 const char* csts_last_error(void);
 int csts_abi_version(void);
 
@@ -63,7 +68,7 @@ typedef struct {
   void* workspace; size_t ws_bytes;   /* optional: makes split_k deterministic (partial slabs + finishing pass) */
   float* colsum;   /* optional, TN + bf16 v2 kernel only: colsum[m] = sum_k A[k,m] (the bias gradient of a Linear) */
   int tile_rows;   /* 0 = library heuristic; 64 / 128 / 256 force the bf16 kernel's row tile (tuning sweeps) */
-  int algo;        /* 0 = library heuristic; 2 = register-staged kernel; 1000 * wg_per_cu + 300 + 10 * (tile_rows / 64) + stages = persistent LDS-DMA NT kernel (tuning sweeps) */
+  int algo;        /* 0 = library heuristic; 2 = register-staged kernel; 1000 * wg_per_cu + 300 + 10 * (tile_rows / 64) + stages = persistent LDS-DMA NT kernel; 1000 * wg_per_cu + 400 + variant = 8-wave LDS-DMA NT kernel, needs K % 64 == 0 (tuning sweeps) */
   int res_up[6];   /* {Ti, Hi, Wi, To, Ho, Wo}; all 0 = plain residual */
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);

@@ -19,7 +19,7 @@ YAML = os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml")
 def test_library_exports_every_declared_symbol():
     from csts_amd import lib
     handle = lib.load()                      # raises loudly if the .so is missing / stale
-    assert handle.csts_abi_version() == 1
+    assert handle.csts_abi_version() == lib.ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "csts_hip.h")).read()
     declared = set(re.findall(r"\b(csts_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"

@@ -1,8 +1,10 @@
 # same-box A/B of an environment switch on the whole step: bash tools/scripts/ab_env.sh VAR val_a val_b [rounds]
 # prints ms per step (20 timed steps) and the median of 30 single steps for each arm, interleaved
-VAR=$1; A=$2; B=$3; R=${4:-3}
-cd $GRAFT_REPO_ROOT
-for i in $(seq 1 $R); do
+set -euo pipefail
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}"   # the repo root: gpurun exports it; else derived from this script's path
+VAR=$1; A=$2; B=$3; N=${4:-3}
+cd "$R"
+for i in $(seq 1 $N); do
   for v in $A $B; do
     env $VAR=$v python bench.py --steps 20 --warmup 5 --median-steps 30 --no-cpu-baseline --no-roofline --no-segments --no-loss-check 2>/dev/null \
       | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$VAR=$v', d['ms_per_step'], d['median_step_ms'])"

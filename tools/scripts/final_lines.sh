@@ -1,10 +1,10 @@
 # the bench lines DESIGN section 6 quotes, from the current build:  bash tools/scripts/final_lines.sh <tag>
-set -e
+set -euo pipefail
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}"   # the repo root: gpurun exports it; else derived from this script's path
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-final}
+O="$R/gpurun_out/${1:-final}"
 mkdir -p $O
-cd $R
+cd "$R"
 timeout -k 10 900 python bench.py --op-breakdown $O/op_breakdown.txt --dump-gemm $O/gemm_shapes.txt > $O/bench.json 2> $O/bench.err
 echo "default done"; tail -c 300 $O/bench.json
 timeout -k 10 300 python bench.py --mode fwd --no-cpu-baseline > $O/bench_fwd.json 2>> $O/bench.err

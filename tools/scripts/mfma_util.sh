@@ -1,11 +1,11 @@
 # MFMA utilisation / stall / HBM-traffic counters of the ten kernels with the most time in a step:
 #   bash tools/scripts/mfma_util.sh <tag>        (on the GPU box; separate --pmc passes, no tracing combined with counters)
-set -e
+set -euo pipefail
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}"   # the repo root: gpurun exports it; else derived from this script's path
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-mfma_util}
+O="$R/gpurun_out/${1:-mfma_util}"
 mkdir -p $O
-cd $R
+cd "$R"
 B="python3 bench.py --one-stream --median-steps 0 --no-cpu-baseline --no-segments --no-loss-check"
 # graph replay: kernel durations + the ordered GEMM list (algorithmic bytes / flops per kernel name)
 timeout -k 10 600 $B --steps 5 --warmup 3 --dump-gemm-order $O/order.json > $O/bench.json 2> $O/bench.err

@@ -1,9 +1,9 @@
-set -e
+set -euo pipefail
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}"   # the repo root: gpurun exports it; else derived from this script's path
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2v2
+O="$R/gpurun_out/r2v2"
 mkdir -p $O
-cd $R
+cd "$R"
 timeout -k 10 900 python bench.py --op-breakdown $O/op_breakdown.txt --dump-gemm $O/gemm_shapes.txt > $O/bench.json 2> $O/bench.err
 tail -c 600 $O/bench.json
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o x -- python3 bench.py --steps 4 --warmup 2 --median-steps 0 --quick-cpu-baseline --no-segments --no-loss-check --no-roofline > $O/prof_bench.txt 2>&1
