@@ -69,6 +69,44 @@ def _log(stats: dict):
               flush=True)
 
 
+def is_checkpoint_epoch(cfg, cur_epoch: int) -> bool:
+    """slowfast/utils/checkpoint.py:87-107 (no multigrid schedule on this path): the last epoch, and every CHECKPOINT_PERIOD-th."""
+    return cur_epoch + 1 == cfg.SOLVER.MAX_EPOCH or (cur_epoch + 1) % cfg.TRAIN.CHECKPOINT_PERIOD == 0
+
+
+def is_eval_epoch(cfg, cur_epoch: int) -> bool:
+    """slowfast/utils/misc.py:200-221: the last epoch, and every EVAL_PERIOD-th."""
+    return cur_epoch + 1 == cfg.SOLVER.MAX_EPOCH or (cur_epoch + 1) % cfg.TRAIN.EVAL_PERIOD == 0
+
+
+@torch.no_grad()
+def eval_epoch(cfg, model, cur_epoch: int, dev, rank: int, world: int):
+    """tools/train_avgaze_net.py:158-219 on synthetic validation clips: eval-mode forward -> frame_softmax(T = 2) -> gather of
+    predictions / heat-map labels / gaze labels over the ranks (:192-193) -> min-max rescale + adaptive_f1 on the device
+    (:196-199) -> the epoch means the reference's ValGazeMeter logs (meters.py: f1 / recall / precision)."""
+    from . import train as T
+    from . import losses, metrics
+    from . import distributed as du
+    core = model.module if hasattr(model, "module") else model
+    was_training = core.training
+    model.eval()
+    b = max(1, cfg.TRAIN.BATCH_SIZE // world)
+    n = int(getattr(cfg.CSTS_AMD, "EVAL_STEPS", 2))
+    acc = [0.0, 0.0, 0.0]
+    for it in range(n):
+        batch = T.synthetic_batch(b, cfg.DATA.NUM_FRAMES, cfg.DATA.TEST_CROP_SIZE, 500000 + rank + 7919 * it, dev)
+        preds = losses.frame_softmax(model([batch["video"]], batch["audio"]), temperature=2)
+        labels_hm, labels = batch["labels_hm"], batch["labels"]
+        if world > 1:
+            preds, labels_hm, labels = du.all_gather([preds, labels_hm, labels])
+        f1, recall, precision, threshold = metrics.adaptive_f1(preds, labels_hm, labels, dataset=cfg.TRAIN.DATASET, rescale=True)
+        acc = [a + v for a, v in zip(acc, (f1, recall, precision))]
+    _log({"_type": "val_epoch", "epoch": cur_epoch + 1, "f1": acc[0] / n, "recall": acc[1] / n, "precision": acc[2] / n,
+          "iters": n})
+    if was_training:
+        model.train()
+
+
 def train(cfg):
     """Epoch loop of tools/train_avgaze_net.py:246-361 on synthetic clips."""
     from .build import build_model
@@ -83,11 +121,18 @@ def train(cfg):
     steps = cfg.CSTS_AMD.STEPS_PER_EPOCH
     from . import checkpoint as ck
     start_epoch = ck.load_train_checkpoint(cfg, model, optimizer)          # train_avgaze_net.py:280
+    _log({"_type": "train_start", "start_epoch": start_epoch + 1, "resumed": start_epoch > 0,
+          "optimizer_steps": int(optimizer.step_count()) if hasattr(optimizer, "step_count") else None})
     model.train()
     # the iteration runs from HIP graphs (the step is launch-bound from Python): one graph on a single GPU, a chain of graphs
     # with the RCCL collectives issued eagerly between them when data-parallel (train.SegmentedTrainStep)
     graphed = None
-    for epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCH):
+    # CSTS_AMD.EPOCHS_THIS_RUN > 0 ends this invocation after that many epochs (a pre-empted job, for resume tests); the
+    # schedule and the checkpoint / eval periods still follow SOLVER.MAX_EPOCH
+    last = cfg.SOLVER.MAX_EPOCH
+    if int(getattr(cfg.CSTS_AMD, "EPOCHS_THIS_RUN", 0) or 0) > 0:
+        last = min(last, start_epoch + int(cfg.CSTS_AMD.EPOCHS_THIS_RUN))
+    for epoch in range(start_epoch, last):
         t0 = time.time()
         for it in range(steps):
             batch = T.synthetic_batch(b, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE, 1000 + rank + 7919 * (epoch * steps + it), dev)
@@ -103,12 +148,18 @@ def train(cfg):
                 lv = float(vals[0])
                 if not (lv == lv) or lv in (float("inf"), float("-inf")):
                     raise RuntimeError("ERROR: Got NaN losses")      # misc.check_nan_losses (misc.py:26-33)
-                _log({"_type": "train_iter", "epoch": epoch + 1, "iter": it + 1, "lr": lr, "loss": lv,
+                _log({"_type": "train_iter", "epoch": epoch + 1, "iter": it + 1, "lr": lr,
+                      "lr_device": float(optimizer.param_groups[0]["lr"]),        # what the (captured) optimizer kernels read
+                      "loss": lv,
                       "kldiv_loss": float(vals[1]), "nce_loss": float(vals[2]) if nce is not None else None})
         torch.cuda.synchronize()
         _log({"_type": "train_epoch", "epoch": epoch + 1, "clips_per_s": steps * b * world / (time.time() - t0)})
-        if getattr(cfg.CSTS_AMD, "SAVE_CHECKPOINTS", False) and (epoch + 1) % cfg.TRAIN.CHECKPOINT_PERIOD == 0:
-            ck.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, epoch, cfg)  # train_avgaze_net.py:345 (0.75 GB + moments)
+        if getattr(cfg.CSTS_AMD, "SAVE_CHECKPOINTS", False) and is_checkpoint_epoch(cfg, epoch):
+            path = ck.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, epoch, cfg)  # train_avgaze_net.py:337-346 (0.75 GB + moments)
+            _log({"_type": "checkpoint", "epoch": epoch + 1, "path": path,
+                  "optimizer_steps": int(optimizer.step_count()) if hasattr(optimizer, "step_count") else None})
+        if is_eval_epoch(cfg, epoch):                                         # train_avgaze_net.py:338,355-356
+            eval_epoch(cfg, model, epoch, dev, rank, world)
 
 
 @torch.no_grad()

@@ -109,6 +109,8 @@ def get_cfg() -> CfgNode:
     c.CSTS_AMD = _node(COMPUTE="auto",               # "fp32": exact-fp32 MFMA parity mode ; "bf16": throughput mode ; "auto": by TRAIN.MIXED_PRECISION (model.resolve_compute)
                        SYNTHETIC_DATA=True,          # the data pipeline is out of scope: synthetic clips
                        STEPS_PER_EPOCH=50,
+                       EPOCHS_THIS_RUN=0,            # > 0: stop this invocation after that many epochs (pre-emption; the next one auto-resumes)
+                       EVAL_STEPS=2,                 # synthetic validation iterations of the periodic eval pass (TRAIN.EVAL_PERIOD)
                        GRAD_BUCKET_MB=64,
                        TRUNK_CUT=3,                  # data-parallel graph chain: second autograd cut in front of this video block (0 = trunks in one piece)
                        TWO_STREAMS=True,             # audio trunk on a second HIP stream, concurrent with the video trunk

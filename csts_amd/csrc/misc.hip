@@ -464,6 +464,40 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const csts_transpo
     }
   }
 }
+// ---- rows of a token grid that a strided 3x3x3 pool reads (csts_kv_rows_geom, include/csts_hip.h).
+// compact cell ch of an axis <-> fine index ((ch + 1) / 3) * s + (ch + 1) % 3 - 1
+__device__ __forceinline__ int kv_fine_index(int ch, int s) { const int q = (ch + 1) / 3; return q * s + (ch + 1 - 3 * q) - 1; }
+// dst[b, t, ch, cw, :] = src[b, t, h(ch), w(cw), :]   (16 bytes per thread: 8 bf16 / 4 fp32 channels)
+template <int EB>   // element bytes
+__global__ __launch_bounds__(256) void rows_gather_kernel(csts_kv_rows_geom g, const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                          int64_t total, int cv) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv);
+    int64_t r = i / cv;
+    const int cw = (int)(r % g.Wc); r /= g.Wc;
+    const int ch = (int)(r % g.Hc); r /= g.Hc;            // r = b * T + t
+    const int64_t frow = (r * g.H + kv_fine_index(ch, g.sh)) * g.W + kv_fine_index(cw, g.sw);
+    dst[i] = src[frow * cv + c];
+  }
+}
+// dst[b, t, h(ch), w(cw), :] += src[b, t, ch, cw, :]   (every fine row is the image of at most one compact row: no races)
+__global__ __launch_bounds__(256) void rows_scatter_add_kernel(csts_kv_rows_geom g, const void* __restrict__ src, int s_dt,
+                                                               void* __restrict__ dst, int d_dt, int64_t total, int c8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c8);
+    int64_t r = i / c8;
+    const int64_t crow = r;
+    const int cw = (int)(r % g.Wc); r /= g.Wc;
+    const int ch = (int)(r % g.Hc); r /= g.Hc;
+    const int64_t frow = (r * g.H + kv_fine_index(ch, g.sh)) * g.W + kv_fine_index(cw, g.sw);
+    float a[8], b[8];
+    ld8_as_f32(src, s_dt, (crow * c8 + c) * 8, a);
+    ld8_as_f32(dst, d_dt, (frow * c8 + c) * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] += a[j];
+    st8_from_f32(dst, d_dt, (frow * c8 + c) * 8, b);
+  }
+}
 // out[m,n] = x[m,n] * row_scale[m / rows_per_scale]   (backward of the drop-path scaling, common.py:46-59)
 __global__ __launch_bounds__(256) void scale_rows_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ rs,
                                                          int64_t rows_per_scale, void* __restrict__ out, int o_dt,
@@ -828,6 +862,31 @@ extern "C" int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void
                           float beta, hipStream_t stream) {
   CSTS_REQUIRE(a && out && n > 0, "bad args");
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, a_dt, b, b_dt, out, out_dt, n, alpha, beta);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+static int kv_rows_check(const csts_kv_rows_geom* g) {
+  CSTS_REQUIRE(g != nullptr && g->B > 0 && g->T > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->C % 8 == 0, "bad geometry (C % 8)");
+  CSTS_REQUIRE(g->sh >= 3 && g->sw >= 3 && g->Hc > 0 && g->Wc > 0, "compaction needs pool strides >= 3");
+  // every compact cell must be a row of the fine grid
+  CSTS_REQUIRE(((g->Hc) / 3) * g->sh + (g->Hc) % 3 - 1 < g->H && ((g->Wc) / 3) * g->sw + (g->Wc) % 3 - 1 < g->W, "compact grid exceeds the fine grid");
+  return 0;
+}
+extern "C" int csts_rows_gather(const csts_kv_rows_geom* g, const void* src, int dt, void* dst, hipStream_t stream) {
+  if (int rc = kv_rows_check(g)) return rc;
+  CSTS_REQUIRE(src && dst && aligned16(src) && aligned16(dst) && (dt == CSTS_F32 || dt == CSTS_BF16), "bad args");
+  const int cv = dt == CSTS_F32 ? g->C / 4 : g->C / 8;
+  const int64_t total = (int64_t)g->B * g->T * g->Hc * g->Wc * cv;
+  hipLaunchKernelGGL(rows_gather_kernel<2>, dim3(grid_for(total)), dim3(256), 0, stream, *g, reinterpret_cast<const uint4*>(src),
+                     reinterpret_cast<uint4*>(dst), total, cv);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_rows_scatter_add(const csts_kv_rows_geom* g, const void* src, int src_dt, void* dst, int dst_dt, hipStream_t stream) {
+  if (int rc = kv_rows_check(g)) return rc;
+  CSTS_REQUIRE(src && dst && aligned16(src) && aligned16(dst), "bad args");
+  const int64_t total = (int64_t)g->B * g->T * g->Hc * g->Wc * (g->C / 8);
+  hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(grid_for(total)), dim3(256), 0, stream, *g, src, src_dt, dst, dst_dt, total, g->C / 8);
   CSTS_LAUNCH_CHECK();
   return 0;
 }

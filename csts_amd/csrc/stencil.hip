@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const v
     bool tv[3], hv[3], xv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      const int t = ot * g.st - 1 + k, h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
       tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
       hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
     bool hv[3], xv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      const int h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
       hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
     }
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
     // those launches, 10-30 % faster for the smaller ones; rocprofv3 kernel trace, profiles/r2_pool_ln_ab.txt.)
 #pragma unroll 1
     for (int kt = 0; kt < 3; ++kt) {           // a real loop: unrolled, the scheduler hoists all 27 loads again and spills
-      const int t = (ot << rg.lt) - 1 + kt;
+      const int t = ot * g.st - 1 + kt;
       const bool tvk = (unsigned)t < (unsigned)g.Tf;
       const int tofk = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
       Raw8<F32> raw[9];
@@ -408,8 +408,9 @@ __device__ __forceinline__ void axis_cand(int f, int s, int ls, int nc, int (&k)
     int kk, n;
     if (N == 3) { kk = i; n = f + 1 - i; }
     else if (N == 2) { kk = ((f + 1) & 1) + 2 * i; n = f + 1 - kk; }
-    else { kk = (f + 1) & (s - 1); n = f + 1 - kk; }
-    const int oo = n >> ls;
+    else if (ls >= 0) { kk = (f + 1) & (s - 1); n = f + 1 - kk; }
+    else { kk = (f + 1) % s; n = f + 1 - kk; }                       // stride 3: the compact K/V grids (csts_kv_rows_geom)
+    const int oo = ls >= 0 ? (n >> ls) : (n >= 0 ? n / s : -1);
     ok[i] = kk <= 2 && n >= 0 && oo < nc;
     k[i] = min(kk, 2);
     o[i] = min(max(oo, 0), nc - 1);
@@ -583,7 +584,7 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
     bool tv[3], hv[3], xv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int t = (ot << rg.lt) - 1 + k, h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+      const int t = ot * g.st - 1 + k, h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
       tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
       hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
@@ -1017,7 +1018,7 @@ int grid_for(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 25
 // 2048 / 4096 -> 25.27, 1024 / 2048 -> 25.27: 4 staged workgroups per CU, the element-wise kernels effectively uncapped.
 int grid_for_staged(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 256), 256 * 4); }
 
-int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+int ilog2(int v) { if (v <= 0 || (v & (v - 1)) != 0) return -1; int l = 0; while ((1 << l) < v) ++l; return l; }   // -1: not a power of two
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 int fill_geom(const csts_dwconv_geom* a, RowGeom& rg) {
@@ -1037,7 +1038,8 @@ int fill_geom(const csts_dwconv_geom* a, RowGeom& rg) {
   CSTS_REQUIRE((a) != nullptr, "null geometry");                                                              \
   CSTS_REQUIRE((a)->B > 0 && (a)->C > 0 && (a)->HD > 0 && (a)->C % (a)->HD == 0 && (a)->HD % 8 == 0, "bad channels (head_dim % 8)"); \
   CSTS_REQUIRE((a)->HD <= 192 && (a)->C <= 1024, "head_dim > 192 / C > 1024 unsupported");                   \
-  CSTS_REQUIRE(pow2((a)->st) && pow2((a)->sh) && pow2((a)->sw), "strides must be powers of two");           \
+  CSTS_REQUIRE((a)->st >= 1 && (a)->sh >= 1 && (a)->sw >= 1 && (pow2((a)->st) || (a)->st >= 3) &&                \
+               (pow2((a)->sh) || (a)->sh >= 3) && (pow2((a)->sw) || (a)->sw >= 3), "bad strides");               \
   CSTS_REQUIRE((a)->Tc == ((a)->Tf - 1) / (a)->st + 1 && (a)->Hc == ((a)->Hf - 1) / (a)->sh + 1 &&          \
                    (a)->Wc == ((a)->Wf - 1) / (a)->sw + 1,                                                   \
                "coarse grid must equal floor((fine-1)/stride)+1");                                           \

@@ -77,6 +77,11 @@ class Im2colGeom(C.Structure):
                 ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Kpad", C.c_int)]
 
 
+class KvRowsGeom(C.Structure):
+    _fields_ = [("B", C.c_int), ("C", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("sh", C.c_int), ("sw", C.c_int),
+                ("Hc", C.c_int), ("Wc", C.c_int)]
+
+
 class WgradItem(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("colsum", vp), ("lda", i64), ("ldb", i64), ("ldc", i64),
                 ("kbeg", i64), ("kend", i64), ("M", C.c_int), ("N", C.c_int), ("m0", C.c_int), ("n0", C.c_int)]
@@ -144,6 +149,8 @@ SYMBOLS = {
     "csts_colsum_workspace": (sz, [i64, i64, i64]),
     "csts_colsum": (_I, [vp, _I, vp, vp, i64, i64, i64, vp, sz, vp]),
     "csts_axpby": (_I, [vp, _I, vp, _I, vp, _I, i64, _F, _F, vp]),
+    "csts_rows_gather": (_I, [C.POINTER(KvRowsGeom), vp, _I, vp, vp]),
+    "csts_rows_scatter_add": (_I, [C.POINTER(KvRowsGeom), vp, _I, vp, _I, vp]),
     "csts_scale_rows": (_I, [vp, _I, vp, i64, vp, _I, i64, i64, vp]),
     "csts_add2": (_I, [vp, _I, vp, _I, vp, vp, i64, vp]),
     "csts_add2_scaled_copy": (_I, [vp, _I, vp, _I, vp, vp, vp, i64, i64, vp]),

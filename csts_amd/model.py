@@ -158,7 +158,13 @@ class Block(nn.Module):
                                addend=x_add)
         w16 = lambda lin: getattr(lin, "_w16", None)      # bf16 shadow maintained by CSTS._refresh_w16 (bf16 mode)
         w16t = lambda lin: getattr(lin, "_w16t", None)    # its [in][out] twin (training): the data gradients run as NT GEMMs
-        qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv), w16t=w16t(a.qkv))
+        kvc = None
+        if ops.kv_compact_ok(thw, self.stride_kv, self.has_pool_kv) and not spatial_audio_attn and not want_attn:
+            # K/V pools with spatial stride >= 4 read (3/s)^2 of the token rows: k|v only for those (ops.QkvCompactFn)
+            qkv, kvc = ops.qkv_compact(xn, a.qkv.weight, a.qkv.bias, thw, self.stride_kv, out_dt=rt.act_dt, compute=rt.compute,
+                                       w16=w16(a.qkv), w16t=w16t(a.qkv))
+        else:
+            qkv = ops.linear(xn, a.qkv.weight, a.qkv.bias, out_dt=rt.act_dt, compute=rt.compute, w16=w16(a.qkv), w16t=w16t(a.qkv))
         mask_mode, mT, mHW = L.MASK_NONE, 0, 0
         if self.kind == "spatial":
             mask_mode, mT, mHW = L.MASK_SPATIAL, thw[0], thw[1] * thw[2]
@@ -174,7 +180,7 @@ class Block(nn.Module):
             wq.weight if wq is not None else None, nq.weight if nq is not None else None, nq.bias if nq is not None else None,
             pk.weight if pk is not None else None, nk.weight if nk is not None else None, nk.bias if nk is not None else None,
             pv.weight if pv is not None else None, nv.weight if nv is not None else None, nv.bias if nv is not None else None,
-            meta)
+            meta, kvc=kvc)
         res_up = None
         if self.kind == "dec":
             q_thw = [t * s for t, s in zip(thw, self.stride_q)]

@@ -966,7 +966,10 @@ class AttnInnerFn(Function):
     kind: 'enc' | 'dec' | 'plain'.  Returns o (B, Nq, C)."""
 
     @staticmethod
-    def forward(ctx, qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta):
+    def forward(ctx, qkv, kvc, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta):
+        """kvc is None: qkv is the (B, N, 3C) output of the qkv Linear.  kvc given (qkv_compact): `qkv` holds q only, (B, N, C),
+        and kvc = k|v (B, Nc, 2C) on the COMPACT grid of the rows the K/V pools read (csts_kv_rows_geom): the pools then run
+        over that grid with stride (1, 3, 3) -- the same taps, the same arithmetic."""
         _need_gpu(qkv)
         (B, N, Cc, H, thw, kind, stride_q, stride_kv, has_pool_q, has_pool_kv, mask_mode, mask_T, mask_HW, act_dt) = meta
         qkv = qkv.contiguous()
@@ -975,22 +978,30 @@ class AttnInnerFn(Function):
         lib = _lib()
         s = _stream()
         saved = {}
+        QW = Cc if kvc is not None else 3 * Cc          # row width of the tensor that holds q
+        if kvc is not None:
+            kvc = kvc.contiguous()
+            kv_thw = [thw[0]] + list(kv_compact_dims(thw, stride_kv))
+            assert has_pool_kv and kv_thw[0] * kv_thw[1] * kv_thw[2] == kvc.shape[1] and kvc.shape[2] == 2 * Cc
+            kv_src, kv_off, kv_w, kv_n, kv_stride = kvc, (0, Cc), 2 * Cc, kvc.shape[1], (1, 3, 3)
+        else:
+            kv_thw, kv_src, kv_off, kv_w, kv_n, kv_stride = list(thw), qkv, (Cc, 2 * Cc), 3 * Cc, N, stride_kv
 
         def slot_view(slot):   # (tensor, elem offset, strides) of q/k/v inside the qkv buffer
-            return (qkv, slot * Cc, (N * 3 * Cc, 3 * Cc, HD), N)
+            return (qkv, slot * Cc, (N * QW, QW, HD), N)
 
         def pooled(slot, w, gamma, beta, stride, transposed):
             if transposed:   # decoder q: ConvTranspose3d, fine = output grid
                 fine_thw = [t * st for t, st in zip(thw, stride)]
                 Nf = fine_thw[0] * fine_thw[1] * fine_thw[2]
-                g = _conv_geom(B, Cc, HD, fine_thw, stride, Nf * Cc, Cc, N * 3 * Cc, 3 * Cc)
+                g = _conv_geom(B, Cc, HD, fine_thw, stride, Nf * Cc, Cc, N * QW, QW)
                 c = torch.empty(B, Nf, Cc, dtype=qkv.dtype, device=dev)
                 L.check(lib.csts_dwconv_transposed(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(w), _p(c), _dt(c), s),
                         "csts_dwconv_transposed")
                 n_out = Nf
                 out_thw = fine_thw
             else:
-                g = _conv_geom(B, Cc, HD, list(thw), stride, N * 3 * Cc, 3 * Cc, 0, Cc)
+                g = _conv_geom(B, Cc, HD, list(thw), stride, N * QW, QW, 0, Cc)
                 n_out = g.Tc * g.Hc * g.Wc
                 g.coarse_batch_stride = n_out * Cc
                 c = torch.empty(B, n_out, Cc, dtype=qkv.dtype, device=dev)
@@ -1004,7 +1015,10 @@ class AttnInnerFn(Function):
         def pooled_fused(slots, ws_, gammas, betas, stride):
             """Conv-pool + LayerNorm(hd) of 1 or 2 slots that share the geometry in ONE launch (csts_pool_ln_fwd)."""
             ns = len(slots)
-            g = _conv_geom(B, Cc, HD, list(thw), stride, N * 3 * Cc, 3 * Cc, 0, Cc)
+            if slots[0] == 0:       # q: from the tensor that holds q
+                src, offs, g = qkv, (0,), _conv_geom(B, Cc, HD, list(thw), stride, N * QW, QW, 0, Cc)
+            else:                   # k | v: from the qkv buffer, or from the compact k|v tensor with the compact grid's stride
+                src, offs, g = kv_src, kv_off, _conv_geom(B, Cc, HD, kv_thw, kv_stride, kv_n * kv_w, kv_w, 0, Cc)
             n_out = g.Tc * g.Hc * g.Wc
             g.coarse_batch_stride = n_out * Cc
             rows = B * n_out * H
@@ -1015,7 +1029,7 @@ class AttnInnerFn(Function):
             pa = L.PoolLnArgs()
             pa.geom, pa.nslots, pa.dt, pa.eps = g, ns, _dt(qkv), 1e-5
             for i, slot in enumerate(slots):
-                pa.fine[i], pa.weight[i], pa.gamma[i], pa.beta[i] = _p(qkv, slot * Cc), _p(ws_[i]), _p(gammas[i]), _p(betas[i])
+                pa.fine[i], pa.weight[i], pa.gamma[i], pa.beta[i] = _p(src, offs[i]), _p(ws_[i]), _p(gammas[i]), _p(betas[i])
                 pa.conv_out[i], pa.y[i], pa.mean[i], pa.rstd[i] = _p(c[i]), _p(y[i]), _p(mean[i]), _p(rstd[i])
             L.check(lib.csts_pool_ln_fwd(C.byref(pa), s), "csts_pool_ln_fwd")
             for i, slot in enumerate(slots):
@@ -1051,7 +1065,7 @@ class AttnInnerFn(Function):
         ctx.meta = meta
         ctx.saved_slots = saved
         ctx.descr = (qd, kd, vd, Nq, Nk)
-        ctx.save_for_backward(qkv, o, lse, wq, gq, wk, gk, wv, gv)
+        ctx.save_for_backward(qkv, o, lse, wq, gq, wk, gk, wv, gv, kvc)
         ctx.params = (wq, gq, bq, wk, gk, bk, wv, gv, bv)
         ctx.mark_non_differentiable(lse)
         ctx.set_materialize_grads(False)     # no zero-filled d(lse) tensor per backward
@@ -1060,7 +1074,7 @@ class AttnInnerFn(Function):
     @staticmethod
     def backward(ctx, do, _dlse):
         (B, N, Cc, H, thw, kind, stride_q, stride_kv, has_pool_q, has_pool_kv, mask_mode, mask_T, mask_HW, act_dt) = ctx.meta
-        qkv, o, lse, wq, gq, wk, gk, wv, gv = ctx.saved_tensors
+        qkv, o, lse, wq, gq, wk, gk, wv, gv, kvc = ctx.saved_tensors
         qd, kd, vd, Nq, Nk = ctx.descr
         saved = ctx.saved_slots
         HD = Cc // H
@@ -1069,13 +1083,19 @@ class AttnInnerFn(Function):
         s = _stream()
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
+        QW = Cc if kvc is not None else 3 * Cc
+        if kvc is not None:             # compact k|v: its gradient has the compact grid's rows only
+            dkvc = torch.empty_like(kvc)
+            kv_fine, kv_dfine, kv_off = kvc, dkvc, (0, Cc)
+        else:
+            dkvc, kv_fine, kv_dfine, kv_off = None, qkv, dqkv, (Cc, 2 * Cc)
         delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
 
         def grad_target(slot, n_rows):   # where attention bwd writes d(q|k|v)
             if slot in saved:
                 t = torch.empty(B, n_rows, Cc, dtype=qkv.dtype, device=dev)
                 return t, 0, (n_rows * Cc, Cc, HD)
-            return dqkv, slot * Cc, (N * 3 * Cc, 3 * Cc, HD)
+            return dqkv, slot * Cc, (N * QW, QW, HD)
 
         tq = grad_target(0, Nq)
         if "kv" in saved:               # dK | dV stacked like the saved pooled pair
@@ -1150,13 +1170,14 @@ class AttnInnerFn(Function):
                 _defer(lws[nbytes:], dgb[1], nrow, 2 * HD)
             vp2 = C.c_void_p * 2
             L.check(lib.csts_dwconv_transposed2(C.byref(g), vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), vp2(_p(wk), _p(wv)),
-                                                vp2(_p(dqkv, Cc), _p(dqkv, 2 * Cc)), _dt(dqkv), s), "csts_dwconv_transposed2")
+                                                vp2(_p(kv_dfine, kv_off[0]), _p(kv_dfine, kv_off[1])), _dt(kv_dfine), s),
+                    "csts_dwconv_transposed2")
             wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
             wws = _ws(2 * wsz, dev)
             dw = torch.empty(2, HD * 27, dtype=torch.float32, device=dev)
             dwp = vp2(None, None) if defer else vp2(_p(dw[0]), _p(dw[1]))
-            L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(qkv, Cc), _p(qkv, 2 * Cc)), _dt(qkv), vp2(_p(dc2[0]), _p(dc2[1])),
-                                           _dt(dc2), dwp, _p(wws), wws.numel(), s), "csts_dwconv_wgrad2")
+            L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(kv_fine, kv_off[0]), _p(kv_fine, kv_off[1])), _dt(kv_fine),
+                                           vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), dwp, _p(wws), wws.numel(), s), "csts_dwconv_wgrad2")
             if defer:
                 nrow = wsz // (HD * 27 * 4)
                 _defer(wws[:wsz], dw[0], nrow, HD * 27)
@@ -1180,11 +1201,121 @@ class AttnInnerFn(Function):
         gq_ = grads.get(0, (None, None, None))
         gk_ = grads.get(1, (None, None, None))
         gv_ = grads.get(2, (None, None, None))
-        return (dqkv, gq_[0], gq_[1], gq_[2], gk_[0], gk_[1], gk_[2], gv_[0], gv_[1], gv_[2], None)
+        return (dqkv, dkvc, gq_[0], gq_[1], gq_[2], gk_[0], gk_[1], gk_[2], gv_[0], gv_[1], gv_[2], None)
 
 
-def attention_inner(qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta):
-    return AttnInnerFn.apply(qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta)
+def attention_inner(qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta, kvc=None):
+    return AttnInnerFn.apply(qkv, kvc, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta)
+
+
+# ----------------------------------------------------------------------------------------- qkv Linear, k|v on the rows that are read
+KV_COMPACT_MIN_STRIDE = int(os.environ.get("CSTS_KV_COMPACT", "4"))     # 0 = off; pools with spatial stride >= this take the compact path
+
+
+def kv_compact_dims(thw, stride_kv):
+    """(Hc, Wc) of the compact grid of the token rows a 3x3x3 pool with stride (1, s, s), padding 1 reads (csts_kv_rows_geom):
+    3 cells per output cell minus the padding cell in front, minus the last one when it falls outside the grid."""
+    out = []
+    for n, st in zip(thw[1:], stride_kv[1:]):
+        no = (n - 1) // st + 1
+        out.append(3 * no - 1 - (1 if (no - 1) * st + 1 > n - 1 else 0))
+    return tuple(out)
+
+
+def kv_compact_ok(thw, stride_kv, has_pool_kv) -> bool:
+    return bool(has_pool_kv and KV_COMPACT_MIN_STRIDE > 0 and stride_kv[0] == 1 and stride_kv[1] >= max(3, KV_COMPACT_MIN_STRIDE)
+                and stride_kv[2] >= max(3, KV_COMPACT_MIN_STRIDE))
+
+
+def _kv_rows_geom(B, Cc, thw, stride_kv) -> L.KvRowsGeom:
+    g = L.KvRowsGeom()
+    g.B, g.C, g.T, g.H, g.W = B, Cc, thw[0], thw[1], thw[2]
+    g.sh, g.sw = stride_kv[1], stride_kv[2]
+    g.Hc, g.Wc = kv_compact_dims(thw, stride_kv)
+    return g
+
+
+class QkvCompactFn(Function):
+    """The qkv Linear of a block whose K/V pools have spatial stride s >= 4 (attention.py:88,130 feeding :104-116): the pools
+    are 3x3x3 convs with stride (1, s, s), so only (3/s)^2 of the token rows of k and v are ever read -- 14 % at s = 8, 3.5 % at
+    s = 16.  q = x Wq^T + bq over all rows; k|v = x[rows] Wkv^T + bkv over the gathered rows only, laid out on the compact grid
+    the pools then walk with stride (1, 3, 3).  Rows of a Linear are independent: the values that ARE computed equal the
+    reference's.  Backward: dx = dq Wq + scatter_add(dkv Wkv); dW = [dq^T x ; dkv^T x[rows]]."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, thw, stride_kv, out_dt: int, compute: int, w16, w16t):
+        _need_gpu(x, W)
+        x = x.contiguous()
+        B, N, K = x.shape
+        Cc = W.shape[0] // 3
+        assert W.shape[1] == K and N == thw[0] * thw[1] * thw[2]
+        g = _kv_rows_geom(B, K, thw, stride_kv)
+        Nc = g.T * g.Hc * g.Wc
+        xk = torch.empty(B, Nc, K, dtype=x.dtype, device=x.device)
+        L.check(_lib().csts_rows_gather(C.byref(g), _p(x), _dt(x), _p(xk), _stream()), "csts_rows_gather")
+        Wop = w16 if (w16 is not None and compute == BF16) else W.contiguous()
+        q = torch.empty(B, N, Cc, dtype=torch_dtype(out_dt), device=x.device)
+        kv = torch.empty(B, Nc, 2 * Cc, dtype=torch_dtype(out_dt), device=x.device)
+        gemm(L.GEMM_NT, x, 0, K, Wop, 0, K, q, Cc, B * N, Cc, K, compute=compute, bias=(b[:Cc] if b is not None else None))
+        gemm(L.GEMM_NT, xk, 0, K, Wop, Cc * K, K, kv, 2 * Cc, B * Nc, 2 * Cc, K, compute=compute,
+             bias=(b[Cc:] if b is not None else None))
+        ctx.save_for_backward(x, xk, Wop)
+        ctx.params = (W, b)
+        ctx.w16t = w16t if (w16t is not None and compute == BF16 and Wop is w16) else None
+        ctx.meta = (B, N, Nc, K, Cc, compute, g)
+        return q, kv
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        x, xk, W = ctx.saved_tensors
+        B, N, Nc, K, Cc, compute, g = ctx.meta
+        Wp, bp = ctx.params
+        dq, dkv = dq.contiguous(), dkv.contiguous()
+        Wt = ctx.w16t
+        dx = torch.empty_like(x)
+        dxk = torch.empty(B, Nc, K, dtype=torch.float32, device=x.device)     # fp32: one rounding when it joins dx
+        if Wt is not None and dq.dtype == torch.bfloat16 and USE_W16T:         # NT on the [in][out] twin (columns 0..C | C..3C)
+            gemm(L.GEMM_NT, dq, 0, Cc, Wt, 0, 3 * Cc, dx, K, B * N, K, Cc, compute=compute)
+            gemm(L.GEMM_NT, dkv, 0, 2 * Cc, Wt, Cc, 3 * Cc, dxk, K, B * Nc, K, 2 * Cc, compute=compute)
+        else:
+            gemm(L.GEMM_NN, dq, 0, Cc, W, 0, K, dx, K, B * N, K, Cc, compute=compute)
+            gemm(L.GEMM_NN, dkv, 0, 2 * Cc, W, Cc * K, K, dxk, K, B * Nc, K, 2 * Cc, compute=compute)
+        L.check(_lib().csts_rows_scatter_add(C.byref(g), _p(dxk), _dt(dxk), _p(dx), _dt(dx), _stream()), "csts_rows_scatter_add")
+        # weight / bias gradients: rows 0..C from all tokens, rows C..3C from the gathered ones, into ONE gradient tensor
+        dW = db = None
+        queued = False
+        if compute == BF16 and GROUP_WGRADS != "never" and (GROUP_WGRADS != "capture" or torch.cuda.is_current_stream_capturing()) \
+                and DEFER_REDUCTIONS and x.dtype == torch.bfloat16 and Cc % 8 == 0 and K % 8 == 0 and B * Nc >= 256 \
+                and Wp.dtype == torch.float32 and _can_defer(Wp, bp):
+            dWf = _grad_buffer(Wp, (3 * Cc, K), x.device)
+            dbf = _grad_buffer(bp, (3 * Cc,), x.device) if bp is not None else None
+            _wgq.append((dq, x, dWf[:Cc], dbf[:Cc] if dbf is not None else None, B * N, Cc, K))
+            _wgq.append((dkv, xk, dWf[Cc:], dbf[Cc:] if dbf is not None else None, B * Nc, 2 * Cc, K))
+            _assign_later(Wp, dWf)
+            _assign_later(bp, dbf)
+            cur = torch.cuda.current_stream()
+            _wg_prod[cur.cuda_stream] = cur
+            queued = True
+        if not queued:
+            dW = torch.empty(3 * Cc, K, dtype=torch.float32, device=x.device)
+            db = torch.empty(3 * Cc, dtype=torch.float32, device=x.device) if bp is not None else None
+            for dy_, x_, r0, nr, tok in ((dq, x, 0, Cc, B * N), (dkv, xk, Cc, 2 * Cc, B * Nc)):
+                split = _wgrad_split(nr, K, tok)
+                det = split > 1 and _lib().csts_gemm_splitk_workspace(nr, K, tok, split) <= SPLITK_WS_LIMIT
+                part = dW[r0:r0 + nr]
+                if split > 1 and not det:
+                    part.zero_()
+                cs = gemm(L.GEMM_TN, dy_, 0, nr, x_, 0, K, part, K, nr, K, tok, compute=compute, split_k=split, deterministic=det,
+                          want_colsum=db is not None)
+                if db is not None:
+                    db[r0:r0 + nr].copy_(cs if cs is not None else colsum(dy_, 1, tok, nr))
+            dW = dW.to(Wp.dtype)
+        return dx, dW, db, None, None, None, None, None, None
+
+
+def qkv_compact(x, W, b, thw, stride_kv, *, out_dt, compute, w16=None, w16t=None):
+    """(q (B, N, C), k|v (B, Nc, 2C) on the compact grid) -- see QkvCompactFn."""
+    return QkvCompactFn.apply(x, W, b, list(thw), tuple(stride_kv), out_dt, compute, w16, w16t)
 
 
 def attention_probs(qkv, B, N, Cc, H, lse, mask_mode, mask_T, mask_HW):

@@ -136,6 +136,10 @@ class FusedAdamW:
         a.beta1, a.beta2, a.eps, a.max_grad_norm = self.betas[0], self.betas[1], self.eps, self.max_grad_norm
         L.check(L.load().csts_adamw_step(C.byref(a), torch.cuda.current_stream().cuda_stream), "csts_adamw_step")
 
+    def step_count(self) -> int:
+        """AdamW steps taken so far (host sync: logging / checkpoint bookkeeping only)."""
+        return int(float(self.state_t[0]))
+
     def reset_state(self):
         """Forget the moments and the step count (a fresh optimizer over the same parameters)."""
         self.exp_avg.zero_()

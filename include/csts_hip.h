@@ -236,6 +236,17 @@ int csts_add2_scaled_copy(const void* a, int a_dt, const void* b, int b_dt, floa
                           int64_t elems_per_scale, int64_t n, hipStream_t stream);   /* out = a + b (fp32) and optionally its bf16 copy: the two gradients of an encoder
                                       * feature that the decoder skip re-uses (custom_multimodal_builder.py:467-479) */
 
+/* ---- Rows a strided K/V pool reads.  The K and V pools are 3x3x3 depthwise convs with stride (1, s, s), padding 1
+ *      (attention.py:11-49,104-116): output cell o of an axis reads fine cells o*s - 1, o*s, o*s + 1, so for s >= 3 only
+ *      (3/s)^2 of the token rows of k|v are ever consumed (14 % at s = 8, 3.5 % at s = 16).  Those rows form a COMPACT grid
+ *      (T, Hc, Wc): compact cell ch <-> fine cell ((ch + 1) / 3) * s + (ch + 1) % 3 - 1, Hc = 3 * ceil(H / s) - 1 (minus one
+ *      more when the last cell would fall outside H), and the pool over it is the SAME conv with stride (1, 3, 3): the k|v
+ *      halves of the qkv Linear are computed for these rows only (rows are independent: identical values).
+ *      gather: dst[b,t,ch,cw,:] = src[b,t,h,w,:]; scatter_add (data gradient back to all rows): dst[b,t,h,w,:] += src[b,t,ch,cw,:]. */
+typedef struct { int B, C, T, H, W, sh, sw, Hc, Wc; } csts_kv_rows_geom;
+int csts_rows_gather(const csts_kv_rows_geom* g, const void* src, int dt, void* dst, hipStream_t stream);
+int csts_rows_scatter_add(const csts_kv_rows_geom* g, const void* src, int src_dt, void* dst, int dst_dt, hipStream_t stream);
+
 int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
                     int64_t M, int64_t N, hipStream_t stream);   /* drop-path backward (common.py:46-59) */
 

@@ -541,6 +541,78 @@ def gen_checkpoint():
     shutil.rmtree(tmp)
 
 
+def _autocast_fixture(m, batch, names, dtype, alpha=0.05):
+    """The reference's OWN mixed-precision error on this path: the same model, weights and batch once in fp32 and once under
+    ``torch.autocast(dtype)`` exactly as the training loop wraps forward + losses (tools/train_avgaze_net.py:70-88; CPU
+    autocast, the only one this container can run).  Stored: the autocast outputs (heat maps, arg-max) and the error of every
+    quantity the GPU tests bar against the fp32 run -- these numbers are what "no worse than the reference's autocast" means."""
+    def run(ctx, scale=1.0):
+        with ctx:
+            logits, v, a = m([batch["video"]], batch["audio"], return_embed=True)
+            p = ref_utils.frame_softmax(logits, temperature=2)
+            kld = ref_losses.KLDiv()(p, batch["labels_hm"])
+            nce = ref_losses.EgoNCE()(ref_utils.sim_matrix(v, a))
+            loss = kld + alpha * nce
+        # fp16: GradScaler semantics (train_avgaze_net.py:99-109,277): backward of scale * loss (initial scale 2^16), unscale_,
+        # and on an inf / nan gradient the step is skipped and the scale halved -- replayed here until the gradients are finite
+        while True:
+            m.zero_grad()
+            (loss.float() * scale).backward(retain_graph=True)
+            finite = all(bool(torch.isfinite(p_.grad).all()) for p_ in m.parameters() if p_.grad is not None)
+            if finite or scale == 1.0:
+                break
+            scale *= 0.5
+        named = dict(m.named_parameters())
+        g = {n: named[n].grad.detach().double().clone() / scale for n in names}
+        total = float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in m.parameters() if p_.grad is not None))) / scale
+        return dict(loss_scale=scale, logits=logits.detach().float(), heat=p.detach().float(), v=v.detach().float(), a=a.detach().float(),
+                    kld=float(kld), nce=float(nce), loss=float(loss), g=g, total=total)
+    import contextlib
+    ref = run(contextlib.nullcontext())
+    amp = run(torch.autocast("cpu", dtype=dtype), 65536.0 if dtype == torch.float16 else 1.0)
+
+    def rel(x, y):
+        return float((x.double() - y.double()).norm() / y.double().norm())
+    B, T = ref["heat"].shape[0], ref["heat"].shape[2]
+    am_ref = ref["heat"].reshape(B, T, -1).argmax(-1)
+    am_amp = amp["heat"].reshape(B, T, -1).argmax(-1)
+    cos = [float((amp["g"][n] * ref["g"][n]).sum() / (amp["g"][n].norm() * ref["g"][n].norm() + 1e-300)) for n in names]
+    return dict(
+        heat_amp=t2n(amp["heat"]).astype(np.float16), heat_ref=t2n(ref["heat"]).astype(np.float32),
+        logits_ref=t2n(ref["logits"]).astype(np.float32), argmax_amp=t2n(am_amp).astype(np.int32), argmax_ref=t2n(am_ref).astype(np.int32),
+        heat_rel_l2=rel(amp["heat"], ref["heat"]), logits_rel_l2=rel(amp["logits"], ref["logits"]),
+        v_emb_rel_l2=rel(amp["v"], ref["v"]), a_emb_rel_l2=rel(amp["a"], ref["a"]),
+        argmax_agree=float((am_ref == am_amp).float().mean()),
+        loss_ref=ref["loss"], loss_amp=amp["loss"], kld_ref=ref["kld"], kld_amp=amp["kld"], nce_ref=ref["nce"], nce_amp=amp["nce"],
+        grad_names=np.array(names),
+        grad_norm_ref=np.array([float(ref["g"][n].norm()) for n in names]),
+        grad_norm_amp=np.array([float(amp["g"][n].norm()) for n in names]),
+        grad_rel_l2=np.array([rel(amp["g"][n], ref["g"][n]) for n in names]), grad_cos=np.array(cos),
+        grad_total_norm_ref=ref["total"], grad_total_norm_amp=amp["total"], dtype=str(dtype), loss_scale=amp["loss_scale"])
+
+
+def gen_autocast():
+    """what the reference's mixed precision itself costs, at the fixture batches of the fp32
+    goldens (same seeds), so that the bf16 compute mode is barred against the reference's autocast and not against itself."""
+    torch.set_num_threads(8)
+    m = load_seeded(CSTS(make_cfg(8))).eval()
+    save("autocast_bf16_T8_B2.npz", **_autocast_fixture(m, O.synthetic_batch(2, 8, 256, seed=1000), GRAD_NAMES, torch.bfloat16))
+    save("autocast_fp16_T8_B2.npz", **_autocast_fixture(m, O.synthetic_batch(2, 8, 256, seed=1000), GRAD_NAMES, torch.float16))
+    del m
+    m = load_seeded(CSTS(make_cfg(16))).eval()
+    save("autocast_bf16_T16_B2.npz", **_autocast_fixture(m, O.synthetic_batch(2, 16, 256, seed=1004), GRAD_NAMES, torch.bfloat16))
+    del m
+    cfg = get_cfg()
+    cfg.merge_from_file("/root/reference/configs/Aria/CSTS_Aria_Gaze_Forecast.yaml")
+    cfg.NUM_GPUS = 0
+    cfg.MODEL.LOSS_FUNC = "kldiv+egonce"
+    cfg.DATA.NUM_FRAMES = 32
+    m = load_seeded(CSTS(cfg)).eval()
+    b = O.synthetic_batch(1, 32, 256, seed=1003)
+    save("autocast_fp16_T32_B1_aria.npz", **_autocast_fixture(m, b, T32_GRAD_NAMES, torch.float16))
+    save("autocast_bf16_T32_B1_aria.npz", **_autocast_fixture(m, b, T32_GRAD_NAMES, torch.bfloat16))
+
+
 def gen_lr():
     from slowfast.utils import lr_policy
     cfg = make_cfg(8)
@@ -572,3 +644,5 @@ if __name__ == "__main__":
         gen_train_saa()
     if "bench" in what:
         gen_bench_expected()
+    if "autocast" in what:
+        gen_autocast()

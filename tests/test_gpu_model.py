@@ -1,7 +1,9 @@
 """GPU parity tests, model level: the HIP CSTS model against (a) the golden fixtures captured from the reference and
 (b) the CPU oracle on the same seeded weights/inputs.  Bars (BASELINE.json north_star): fp32 mode heatmaps within
 1e-3 rel-L2 of the reference, per-frame argmax bit-exact; bf16 mode is reported against looser, stated tolerances
-(the reference's own bf16 autocast deviates 6.8e-3 on logits / 7.6e-4 on heatmaps)."""
+(the reference's own bf16 autocast on the fixture weights / batches deviates 8.4e-3 ... 9.8e-3 on logits and 3.4e-3 on
+heatmaps from its fp32 run: tests/golden/autocast_bf16_*.npz; SURVEY.md D3's 7.6e-4 was measured on default-initialised
+weights and Gaussian inputs)."""
 import os
 
 import numpy as np
@@ -163,9 +165,10 @@ def test_full_model_bf16_mode_reported_tolerances():
     e_logits, e_heat = rel_l2(logits, g["logits"]), rel_l2(heat, g["heat"])
     agree = float((heat.reshape(2, 8, -1).argmax(-1).cpu().numpy() == g["argmax"]).mean())
     print(f"\n[bf16 mode] logits rel-L2 {e_logits:.3e}  heatmap rel-L2 {e_heat:.3e}  argmax agreement {agree:.3f}")
-    # measured 4.7e-3 / 1.7e-3 / 1.0: bars at ~2 x (bf16 operands, fp32 accumulate / residual stream / softmax)
-    assert e_logits < 1e-2 and e_heat < 3.5e-3
-    assert agree >= 0.9375
+    # measured 4.7e-3 / 1.7e-3 / 1.0; the reference's own bf16 autocast on these weights and this batch: 9.8e-3 / 3.4e-3 / 1.0
+    # (tests/golden/autocast_bf16_T8_B2.npz; test_bf16_mode_no_worse_than_reference_autocast holds the mode to those)
+    assert e_logits < 6e-3 and e_heat < 2e-3
+    assert agree == 1.0
 
 
 def test_droppath_train_mode_fp32():
@@ -331,6 +334,49 @@ def test_train_bf16_vs_reference_golden(T_, fixture, seed):
     loss, kld, nce, preds = _train_pass(m, cfg, dev_batch(2, T_, seed))
     _check_train_fixture(m, g, loss, kld, nce, preds, loss_tol=1e-3, norm_tol=3.6e-2, cos_min=0.983, total_tol=1e-2,
                          argmax_min=0.9375, label=f"bf16 T{T_} B2")
+
+
+@pytest.mark.parametrize("T_,amp_fixture,seed,B", [(8, "autocast_bf16_T8_B2.npz", 1000, 2), (16, "autocast_bf16_T16_B2.npz", 1004, 2)])
+def test_bf16_mode_no_worse_than_reference_autocast(T_, amp_fixture, seed, B):
+    """VERDICT round 3 item 2.  `autocast_bf16_*.npz` (oracle/gen_golden.py::gen_autocast) holds what the REFERENCE's own mixed
+    precision costs on this path: the imported reference model, same seeded weights and batch, once in fp32 and once under
+    torch.autocast(bfloat16) wrapped around forward + losses exactly as tools/train_avgaze_net.py:70-88 does.  Measured there:
+    heat maps 3.4e-3 rel-L2 of its own fp32 run (logits 8.4e-3 ... 9.8e-3), arg-max 16/16 at T = 8 and 29/32 at T = 16, total
+    gradient norm off by 0.5 % / 3.2 %.  This build's bf16 mode against the same fp32 outputs: 1.7e-3 / 4.7e-3, 16/16 and 31/32,
+    0.2 % / 0.4 % -- half the reference's error.  Bar: every forward quantity and the gradient norms NO WORSE than the
+    reference's autocast (x 1.0 for the forward, x 1.25 for the median gradient-norm error)."""
+    a = _load(amp_fixture)
+    m, cfg = make_model("bf16", T_)
+    batch = dev_batch(B, T_, seed)
+    loss, kld, nce, preds = _train_pass(m, cfg, batch)
+    with torch.no_grad():
+        logits, v, e = m([batch["video"]], batch["audio"], return_embed=True)
+    heat_ref, logits_ref = torch.from_numpy(a["heat_ref"]), torch.from_numpy(a["logits_ref"])
+    e_heat, e_logits = rel_l2(preds, heat_ref), rel_l2(logits, logits_ref)
+    am = preds.reshape(B, T_, -1).argmax(-1).cpu().numpy()
+    agree = float((am == a["argmax_ref"]).mean())
+    e_loss = abs(float(loss) - float(a["loss_ref"])) / float(a["loss_ref"])
+    ref_loss_err = abs(float(a["loss_amp"]) - float(a["loss_ref"])) / float(a["loss_ref"])
+    named = dict(m.named_parameters())
+    names = [str(n) for n in a["grad_names"]]
+    keep = [i for i, n in enumerate(names) if n != "classifier.bias" and a["grad_norm_ref"][i] > 0]     # shift-invariant softmax: true gradient 0
+    ours = np.array([abs(float(named[names[i]].grad.double().norm()) / a["grad_norm_ref"][i] - 1.0) for i in keep])
+    theirs = np.abs(a["grad_norm_amp"][keep] / a["grad_norm_ref"][keep] - 1.0)
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
+    e_total = abs(total / float(a["grad_total_norm_ref"]) - 1.0)
+    ref_total = abs(float(a["grad_total_norm_amp"]) / float(a["grad_total_norm_ref"]) - 1.0)
+    print(f"\n[bf16 mode vs the reference's bf16 autocast, T{T_} B{B}] heat rel-L2 {e_heat:.3e} (reference autocast {float(a['heat_rel_l2']):.3e})  "
+          f"logits {e_logits:.3e} ({float(a['logits_rel_l2']):.3e})  argmax {agree:.4f} ({float(a['argmax_agree']):.4f})  "
+          f"loss err {e_loss:.2e} ({ref_loss_err:.2e})  grad-norm err median {np.median(ours):.2e} ({np.median(theirs):.2e}) "
+          f"max {ours.max():.2e} ({theirs.max():.2e})  total norm {e_total:.2e} ({ref_total:.2e})")
+    assert e_heat <= float(a["heat_rel_l2"]) and e_logits <= float(a["logits_rel_l2"])
+    assert agree >= float(a["argmax_agree"])
+    assert e_loss <= max(ref_loss_err, 1e-5)
+    assert np.median(ours) <= 1.25 * np.median(theirs) and ours.max() <= 1.25 * theirs.max()
+    assert e_total <= max(ref_total, 5e-3)
+    # north-star bar for reference: 1e-3 on the heat maps is an fp32-mode bar (met at 4e-7); bf16 operands cannot reach it --
+    # the reference's own autocast is at 3.4e-3 -- so the bf16 mode is held to 2e-3 absolute here (measured 1.7e-3)
+    assert e_heat < 2e-3
 
 
 def test_bf16_mode_gradients_all_tensors_vs_fp32_mode():

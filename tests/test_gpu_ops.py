@@ -225,6 +225,98 @@ def test_attention_inner(case, compute):
             assert rel_l2(P[pfx + s].grad, Pr[pfx + s].grad) < tol * 3, pfx + s
 
 
+# ------------------------------------------------------------------------------ k|v only for the rows the pools read
+KV_CASES = [  # (name, B, thw, C, heads, kind, stride_q, stride_kv)
+    ("enc_s8", 2, (2, 32, 32), 96, 1, "enc", (1, 1, 1), (1, 8, 8)),
+    ("enc_s4_poolq", 1, (2, 16, 16), 192, 2, "enc", (1, 2, 2), (1, 4, 4)),
+    ("enc_s8_ragged", 1, (4, 14, 14), 96, 1, "enc", (1, 1, 1), (1, 8, 8)),      # BASELINE config 1 grid: last tap outside
+    ("enc_s4_odd", 1, (3, 9, 13), 192, 2, "enc", (1, 1, 1), (1, 4, 4)),
+    ("dec_s16", 1, (2, 32, 32), 192, 2, "dec", (2, 1, 1), (1, 16, 16)),
+    ("dec_s4_hd192", 1, (2, 8, 8), 384, 2, "dec", (1, 2, 2), (1, 4, 4)),
+]
+
+
+def _fine_index(ch, s):
+    return ((ch + 1) // 3) * s + (ch + 1) % 3 - 1
+
+
+@pytest.mark.parametrize("case", KV_CASES, ids=[c[0] for c in KV_CASES])
+def test_kv_rows_gather_scatter(case):
+    """csts_rows_gather / csts_rows_scatter_add against index arithmetic in torch; the compact grid holds exactly the rows a
+    3x3x3 pool with stride (1, s, s), padding 1 reads (attention.py:11-49)."""
+    import ctypes as C
+    name, B, thw, Cc, H, kind, sq, skv = case
+    T, Hh, Ww = thw
+    Hc, Wc = ops.kv_compact_dims(thw, skv)
+    hs = [_fine_index(c, skv[1]) for c in range(Hc)]
+    ws_ = [_fine_index(c, skv[2]) for c in range(Wc)]
+    read_h = sorted({o * skv[1] + k for o in range((Hh - 1) // skv[1] + 1) for k in (-1, 0, 1) if 0 <= o * skv[1] + k < Hh})
+    read_w = sorted({o * skv[2] + k for o in range((Ww - 1) // skv[2] + 1) for k in (-1, 0, 1) if 0 <= o * skv[2] + k < Ww})
+    assert hs == read_h and ws_ == read_w
+    g = ops._kv_rows_geom(B, Cc, thw, skv)
+    for dt in (torch.float32, torch.bfloat16):
+        x = rnd(B, T, Hh, Ww, Cc, seed=2).to(dt)
+        out = torch.empty(B, T, Hc, Wc, Cc, device=DEV, dtype=dt)
+        L.check(L.load().csts_rows_gather(C.byref(g), x.data_ptr(), ops._dt(x), out.data_ptr(), torch.cuda.current_stream().cuda_stream), "gather")
+        ref = x[:, :, hs][:, :, :, ws_]
+        assert torch.equal(out, ref)
+        src = rnd(B, T, Hc, Wc, Cc, seed=3)
+        dst = rnd(B, T, Hh, Ww, Cc, seed=4).to(dt)
+        want = dst.float().clone()
+        want[:, :, torch.tensor(hs, device=DEV)[:, None], torch.tensor(ws_, device=DEV)[None, :]] += src
+        L.check(L.load().csts_rows_scatter_add(C.byref(g), src.data_ptr(), L.F32, dst.data_ptr(), ops._dt(dst), torch.cuda.current_stream().cuda_stream), "scatter")
+        assert torch.equal(dst, want.to(dt))
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+@pytest.mark.parametrize("case", KV_CASES, ids=[c[0] for c in KV_CASES])
+def test_qkv_compact_equals_full_qkv(case, compute):
+    """qkv Linear + pooled attention through the compact k|v path (ops.qkv_compact -> attention_inner(kvc=...)) against the
+    full path (ops.linear -> attention_inner): the rows of a Linear are independent and the pools read the same taps, so the
+    forward is BIT-IDENTICAL in both compute modes; gradients agree to rounding (the data gradient adds its two parts in another
+    order) and match torch autograd of the reference formulation to the usual bars."""
+    name, B, thw, Cc, H, kind, sq, skv = case
+    HD = Cc // H
+    N = thw[0] * thw[1] * thw[2]
+    dt = tdt(compute)
+    use_q = kind == "dec" or sq != (1, 1, 1)
+    meta = (B, N, Cc, H, list(thw), kind, sq, skv, use_q, True, L.MASK_NONE, 0, 0, compute)
+
+    def run(compact):
+        x = rnd(B, N, Cc, seed=1).to(dt).requires_grad_(True)
+        W = rnd(3 * Cc, Cc, seed=2, scale=Cc ** -0.5).requires_grad_(True)
+        b = (0.1 * rnd(3 * Cc, seed=3)).requires_grad_(True)
+        P = {}
+        for i, s_ in enumerate("qkv"):
+            P["w" + s_] = rnd(HD, 1, 3, 3, 3, seed=10 + i, scale=0.2).requires_grad_(True)
+            P["g" + s_] = (1 + 0.1 * rnd(HD, seed=20 + i)).requires_grad_(True)
+            P["b" + s_] = (0.1 * rnd(HD, seed=30 + i)).requires_grad_(True)
+        args = ([P["wq"], P["gq"], P["bq"]] if use_q else [None, None, None]) + [P["wk"], P["gk"], P["bk"], P["wv"], P["gv"], P["bv"]]
+        w16 = W.detach().to(torch.bfloat16) if compute == L.BF16 else None
+        if compact:
+            assert ops.kv_compact_ok(thw, skv, True)
+            q, kvc = ops.qkv_compact(x, W, b, thw, skv, out_dt=compute, compute=compute, w16=w16)
+            assert q.shape == (B, N, Cc) and kvc.shape[2] == 2 * Cc and kvc.shape[1] < N
+            o, _ = ops.attention_inner(q, *args, meta, kvc=kvc)
+        else:
+            qkv = ops.linear(x, W, b, out_dt=compute, compute=compute, w16=w16)
+            o, _ = ops.attention_inner(qkv, *args, meta)
+        go = rnd(*o.shape, seed=5).to(dt)
+        o.backward(go)
+        grads = {"x": x.grad, "W": W.grad, "b": b.grad}
+        grads.update({k: v.grad for k, v in P.items() if v.grad is not None})
+        return o.detach(), grads
+
+    o_c, g_c = run(True)
+    o_f, g_f = run(False)
+    assert torch.equal(o_c, o_f), "forward must be bit-identical"
+    tol = 2e-5 if compute == L.F32 else 2e-2
+    for k in g_f:
+        if k == "bk":        # exactly zero in exact arithmetic (softmax shift invariance): rounding noise on both sides
+            continue
+        assert rel_l2(g_c[k].float(), g_f[k].float()) < tol, (k, rel_l2(g_c[k].float(), g_f[k].float()))
+
+
 @pytest.mark.parametrize("compute", [L.F32, L.BF16])
 def test_attention_spatial_mask_and_probs(compute):
     B, T, Hh, Ww, Cc, H = 2, 2, 4, 4, 768, 8
