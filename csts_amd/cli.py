@@ -65,7 +65,8 @@ def _is_master():
 
 def _log(stats: dict):
     if _is_master():
-        print("json_stats: " + json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in stats.items()}),
+        # six significant digits (a learning rate of 9.97e-5 must not print as 0.0001)
+        print("json_stats: " + json.dumps({k: (float(f"{v:.6g}") if isinstance(v, float) else v) for k, v in stats.items()}),
               flush=True)
 
 

@@ -489,12 +489,17 @@ def _join_wgrad_side():
 
 # ----------------------------------------------------------------------------------------- raw wrappers
 AUTO_SPLIT_SMALL_M = True
+MID_M_SPLIT = int(os.environ.get("CSTS_MID_M_SPLIT", "1"))
 
 
 def _auto_split(layout, M, N, K, compute):
     """Deterministic split-K for activation GEMMs with a handful of rows (embedding projections and similarity matrices
     of the EgoNCE loss: M = batch; the temporal-fusion block: M = B*2T'): one or two row tiles leave 1..24 workgroups
     walking the whole K serially (55-100 us per call measured); slabs + the finishing pass spread K over the chip."""
+    if layout != L.GEMM_TN and compute == BF16 and MID_M_SPLIT > 1 and 1024 <= M <= 4096 and K >= 2304 and N <= 1024:
+        # the 768-channel stage at b = 4 (M = 2048 tokens): fc2 / the qkv data gradient are 64-96 output tiles on 256 CUs with a
+        # 36-48 step k-loop each -- cut the loop so that every CU has a tile (deterministic slabs + finishing pass)
+        return MID_M_SPLIT
     if layout == L.GEMM_TN or M > 128:
         return 1
     ksteps = -(-K // (64 if compute == BF16 else 32))
@@ -1209,7 +1214,7 @@ def attention_inner(qkv, wq, gq, bq, wk, gk, bk, wv, gv, bv, meta, kvc=None):
 
 
 # ----------------------------------------------------------------------------------------- qkv Linear, k|v on the rows that are read
-KV_COMPACT_MIN_STRIDE = int(os.environ.get("CSTS_KV_COMPACT", "4"))     # 0 = off; pools with spatial stride >= this take the compact path
+KV_COMPACT_MIN_STRIDE = int(os.environ.get("CSTS_KV_COMPACT", "8"))     # 0 = off; pools with spatial stride >= this take the compact path
 
 
 def kv_compact_dims(thw, stride_kv):

@@ -54,10 +54,10 @@ def test_run_net_train_checkpoint_resume_eval(tmp_path):
     for r in iters:
         assert np.isfinite(r["loss"]) and np.isfinite(r["kldiv_loss"]) and np.isfinite(r["nce_loss"])
         assert abs(r["loss"] - (r["kldiv_loss"] + 0.05 * r["nce_loss"])) < 1e-4
-        assert abs(r["lr_device"] - r["lr"]) <= 1e-6 * r["lr"]          # the captured optimizer kernels read the schedule's value
+        assert abs(r["lr_device"] - r["lr"]) <= 2e-6 * r["lr"]          # the captured optimizer kernels read the schedule's value
     # cosine schedule at epoch 0.0 and 0.5 against the values the reference's lr_policy produced (tests/golden/lr_schedule.npz)
-    assert abs(iters[0]["lr"] - lr_at[0.0]) <= 1e-9 + 1e-6 * lr_at[0.0]
-    assert abs(iters[STEPS // 2]["lr"] - lr_at[0.5]) <= 1e-9 + 1e-6 * lr_at[0.5]
+    assert abs(iters[0]["lr"] - lr_at[0.0]) <= 2e-6 * lr_at[0.0]
+    assert abs(iters[STEPS // 2]["lr"] - lr_at[0.5]) <= 2e-6 * lr_at[0.5]
     assert iters[-1]["loss"] < iters[0]["loss"] + 0.5                     # AdamW at 1e-4 does not blow the loss up
     ck = _of(recs, "checkpoint")
     assert len(ck) == 1 and ck[0]["epoch"] == 1 and ck[0]["optimizer_steps"] == STEPS
@@ -83,8 +83,8 @@ def test_run_net_train_checkpoint_resume_eval(tmp_path):
     assert start2["start_epoch"] == 2 and start2["resumed"] is True and start2["optimizer_steps"] == STEPS
     iters2 = _of(recs2, "train_iter")
     assert all(r["epoch"] == 2 for r in iters2) and len(iters2) == STEPS
-    assert abs(iters2[0]["lr"] - lr_at[1.0]) <= 1e-9 + 1e-6 * lr_at[1.0]
-    assert all(abs(r["lr_device"] - r["lr"]) <= 1e-6 * r["lr"] for r in iters2)
+    assert abs(iters2[0]["lr"] - lr_at[1.0]) <= 2e-6 * lr_at[1.0]
+    assert all(abs(r["lr_device"] - r["lr"]) <= 2e-6 * r["lr"] for r in iters2)
     ck2 = _of(recs2, "checkpoint")
     assert len(ck2) == 1 and ck2[0]["epoch"] == 2 and ck2[0]["optimizer_steps"] == 2 * STEPS
     assert len(_of(recs2, "val_epoch")) == 1

