@@ -35,6 +35,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tools"))      # tools/work_model.py: algorithmic bytes / flop per C-ABI entry
 
 import torch  # noqa: E402
 
@@ -232,6 +233,20 @@ class GemmTimer:
                 f.write(f"{'NT NN TN'.split()[lay]} {M} {N} {K} {sp} {n} {sec*1e3:.3f} {sec/n*1e6:.1f} {fl*n/sec/1e12:.1f} {by*n/sec/1e9:.0f} {name}\n")
 
 
+def _work(name, args):
+    if name == "csts_gemm":
+        a = args[0]._obj
+        esz = lambda dt: 4 if dt == 0 else 2
+        byt = a.M * a.K * esz(a.a_dt) + a.N * a.K * esz(a.b_dt) + a.M * a.N * esz(a.c_dt)
+        if a.aux:
+            byt += a.M * a.N * esz(a.aux_dt)
+        if a.residual:
+            byt += (a.res_row_mod if a.res_row_mod else a.M) * a.N * esz(a.r_dt)
+        return byt, 2.0 * a.M * a.N * a.K
+    import work_model
+    return work_model.work(name, args)
+
+
 class OpTimer:
     """HIP-event timing of EVERY C-ABI entry point (per-family device time of one eager single-stream step)."""
 
@@ -252,7 +267,7 @@ class OpTimer:
                 e0.record()
                 rc = fn(*a)
                 e1.record()
-                rec.append((name, e0, e1))
+                rec.append((name, e0, e1, _work(name, a)))
                 return rc
             return timed
 
@@ -268,14 +283,38 @@ class OpTimer:
         from csts_amd import lib as L
         L._lib = self._orig
 
-    def summary(self, steps):
+    def summary(self, steps, extra_work=None):
+        """Per C-ABI entry: calls, device ms (HIP events around each call of an eager single-stream step: 8-12 % above the
+        graph replay), and -- where tools/work_model.py knows the entry -- the ALGORITHMIC bytes / flop of those calls (every
+        operand once) with the roofline fractions they give: bytes / ms / 8 TB/s, flop / ms / 2.5 PF.
+        extra_work: {entry: (bytes, flop)} for entries whose work is not visible in the call arguments (grouped weight
+        gradients: device item tables; the optimizer: device tensor tables)."""
         torch.cuda.synchronize()
         agg = {}
-        for name, e0, e1 in self.rec:
-            a = agg.setdefault(name[5:], [0, 0.0])
+        for name, e0, e1, w in self.rec:
+            a = agg.setdefault(name[5:], [0, 0.0, 0.0, 0.0, True])
             a[0] += 1
             a[1] += e0.elapsed_time(e1)
-        return {k: {"calls": v[0] // steps, "ms": round(v[1] / steps, 3)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+            if w is None:
+                a[4] = False
+            else:
+                a[2] += w[0]
+                a[3] += w[1]
+        for k, (b, f) in (extra_work or {}).items():
+            if k in agg:
+                agg[k][2], agg[k][3], agg[k][4] = b * steps, f * steps, True
+        out = {}
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            d = {"calls": v[0] // steps, "ms": round(v[1] / steps, 3)}
+            if v[4] and v[1] > 0 and (v[2] > 0 or v[3] > 0):
+                sec = v[1] / 1e3
+                d["algorithmic_bytes"] = int(v[2] / steps)
+                d["algorithmic_flop"] = int(v[3] / steps)
+                d["hbm_frac"] = round(v[2] / sec / 8e12, 4)
+                d["mfma_frac"] = round(v[3] / sec / 2.5e15, 4)
+                d["bound"] = "hbm" if d["hbm_frac"] >= d["mfma_frac"] else "mfma"
+            out[k] = d
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -305,11 +344,12 @@ def _host_cpu():
     return model, max(1, len(phys) or len(allowed)), len(allowed)
 
 
-def cpu_baseline(frames, mode, quick, budget_s=150.0):
+def cpu_baseline(frames, mode, quick, budget_s=150.0, batch=4):
     """The CPU oracle (a port of the reference path to plain PyTorch fp32 ops, pinned to the reference by
     tests/test_oracle_golden.py) on the host cores: 1 warm-up + min of 3 per configuration.
-    `value` = the train step (fwd + loss + bwd, no optimizer) -- or the forward in --mode fwd -- at the benchmarked token
-    grid, B = 2 (EgoNCE is identically 0 at B = 1); the table adds 8 x 256^2 at B = 1 / 2 / 4, forward and train."""
+    `value` = the train step (fwd + loss + bwd, no optimizer) -- or the forward in --mode fwd -- on THE GPU LINE'S OWN
+    CONFIGURATION: the benchmarked token grid at the benchmarked per-GPU batch (16 x 256^2, B = 4 by default; 1 warm-up + min of
+    2, ~40 s); the table adds 16 x 256^2 B = 2 and 8 x 256^2 at B = 1 / 2 / 4, forward and train, while the time budget lasts."""
     from oracle import csts_oracle as O
     model, phys, logical = _host_cpu()
     # these op sizes stop scaling well before a big host's core count (EPYC 9575F box: 26.8 s per 16x256^2 B=2 train step
@@ -343,14 +383,17 @@ def cpu_baseline(frames, mode, quick, budget_s=150.0):
         return best
 
     train = mode == "train"
-    head = run(frames, 2, train)
-    out = {"value": round(2 / head, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+    head = run(frames, batch, train, reps=2)
+    out = {"value": round(batch / head, 4), "unit": "clips/s", "cores": threads, "kind": "port",
            "cpu_model": model, "physical_cores_visible": phys, "logical_cpus_visible": logical,
            "sample": f"CPU oracle (plain PyTorch fp32 ops), {'train step: fwd + KLDiv + 0.05 EgoNCE + bwd, no optimizer' if train else 'eval forward'}, "
-                     f"B=2, {frames}x256^2, 1 warm-up + min of 3: {head:.2f} s per step, {threads} threads"}
+                     f"B={batch}, {frames}x256^2 (the GPU line's configuration), 1 warm-up + min of 2: {head:.2f} s per step, {threads} threads"}
     if not quick:
-        table = {}
-        for B in (1, 2, 4):
+        table = {f"{frames}x256^2 B={batch} {'train' if train else 'fwd'}": {"s_per_step": round(head, 3), "clips_per_s": round(batch / head, 3)}}
+        if batch != 2 and time.time() - t_start < budget_s:
+            t = run(frames, 2, train, reps=1)
+            table[f"{frames}x256^2 B=2 {'train' if train else 'fwd'}"] = {"s_per_step": round(t, 3), "clips_per_s": round(2 / t, 3)}
+        for B in (4, 2, 1):
             for what, tr in (("fwd", False), ("train", True)):
                 if time.time() - t_start > budget_s:
                     break
@@ -662,25 +705,42 @@ def main():
             torch.cuda._sleep(spin)
             eager_step()
         gt.remove()
-        if args.op_breakdown:
+        per_entry = None
+        if train:
+            # every C-ABI entry of one eager single-stream step with its algorithmic bytes / flop (tools/work_model.py)
             ot = OpTimer()
             ot.install()
             torch.cuda._sleep(spin)
             eager_step()
             t_ev0, t_ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ot.rec.clear()
+            _ops.WG_STATS = []
             torch.cuda._sleep(spin)
             t_ev0.record()
             eager_step()
             t_ev1.record()
             ot.remove()
-            ops_ms = ot.summary(1)
+            extra = {}
+            for entry, byt, fl in (_ops.WG_STATS or []):
+                e = extra.setdefault(entry[5:], [0.0, 0.0])
+                e[0] += byt
+                e[1] += fl
+            _ops.WG_STATS = None
+            import work_model
+            n_par = sum(p.numel() for p in core.parameters())
+            n_sh = sum(l.weight.numel() for l in (getattr(core, "_w16_all", None) or []))
+            extra["adamw_step"] = work_model.work_adamw(n_par, n_sh)
+            ops_ms = per_entry = ot.summary(1, extra)
             tot = t_ev0.elapsed_time(t_ev1)
-            with open(args.op_breakdown if rank == 0 else os.devnull, "w") as f:
-                f.write(f"single-stream eager step {tot:.2f} ms; C-ABI kernels {sum(v['ms'] for v in ops_ms.values()):.2f} ms; "
-                        f"torch-native remainder (autograd adds, casts, fills) {tot - sum(v['ms'] for v in ops_ms.values()):.2f} ms\n")
-                for k, v in ops_ms.items():
-                    f.write(f"{k:28s} {v['calls']:5d} calls {v['ms']:8.3f} ms\n")
+            if args.op_breakdown:
+                with open(args.op_breakdown if rank == 0 else os.devnull, "w") as f:
+                    f.write(f"single-stream eager step {tot:.2f} ms; C-ABI kernels {sum(v['ms'] for v in ops_ms.values()):.2f} ms; "
+                            f"torch-native remainder (autograd adds, casts, fills) {tot - sum(v['ms'] for v in ops_ms.values()):.2f} ms\n")
+                    f.write("entry                        calls        ms   algorithmic MB   GFLOP   hbm_frac(8 TB/s)  mfma_frac(2.5 PF)\n")
+                    for k, v in ops_ms.items():
+                        f.write(f"{k:28s} {v['calls']:5d} calls {v['ms']:8.3f} ms" + (
+                            f"  {v['algorithmic_bytes'] / 1e6:10.1f} MB {v['algorithmic_flop'] / 1e9:9.1f}  {v['hbm_frac']:8.3f} {v['mfma_frac']:8.3f}  {v['bound']}"
+                            if "hbm_frac" in v else "") + "\n")
         core.two_streams = two
         _ops.GROUP_WGRADS = _mode
         agg = gt.summary()
@@ -735,6 +795,12 @@ def main():
                 "per_kernel": {k: {"launches_per_step": v[0] // 2, "avg_us": round(v[3] / v[0] * 1e6, 1),
                                    "tflops": round(v[1] / v[3] / 1e12, 1), "ms_per_step": round(v[3] / 2 * 1e3, 3)}
                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3])[:8]}}
+        if per_entry is not None:
+            # every C-ABI entry point of one step (non-GEMM kernels included): calls, eager-event ms, algorithmic bytes / flop
+            # (tools/work_model.py: every operand once) and the roofline fractions they give
+            roof["per_entry"] = {k: v for k, v in list(per_entry.items())[:24]}
+            roof["per_entry_note"] = ("HIP events around each C-ABI call of one eager single-stream step (8-12 % above the graph replay); "
+                                      "hbm_frac = algorithmic bytes / ms / 8 TB/s, mfma_frac = algorithmic flop / ms / 2.5 PF")
     if dist_path:
         torch.distributed.barrier()
 
@@ -781,7 +847,7 @@ def main():
             out["roofline"] = roof
         if world == 1 and not dist_path and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.frames, args.mode, args.quick_cpu_baseline)
+                out["cpu_baseline"] = cpu_baseline(args.frames, args.mode, args.quick_cpu_baseline, batch=args.batch_per_gpu)
             except Exception as e:  # keep the line valid even if the host runs out of memory
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         sys.stdout.flush()

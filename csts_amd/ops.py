@@ -292,6 +292,7 @@ WGRAD8 = os.environ.get("CSTS_WGRAD8", "1") != "0"
 WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "8192"))
 WGRAD_CHUNK = int(os.environ.get("CSTS_WGRAD_CHUNK", "8192"))   # tokens per work item (measured per step: 4096 -> 24.93 ms, 8192 -> 24.95, 16384 -> 25.47)
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
+WG_STATS = None         # a list while bench.py instruments a step: (C-ABI entry, algorithmic bytes, flop) per grouped launch
 _wg_tables = {}
 # Optional: every WG_FLUSH_GFLOP of queued work goes out as its own grouped launch on a SIDE stream, beside the rest of
 # backward (the idea: backward's kernels are small, and the audio trunk on its own stream was worth 8 ms of a 41 ms step).
@@ -468,6 +469,10 @@ def flush_wgrads(side: bool = False):
         arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
         with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
             ptr = tab.upload(arr.tobytes())
+            if WG_STATS is not None:      # dY + X read once, dW written once; 2 tokens N K flop
+                WG_STATS.append(("csts_wgrad_grouped8" if rows == 192 else "csts_wgrad_grouped",
+                                 sum(t[4] * t[5] * t[0].element_size() + t[4] * t[6] * 2 + t[5] * t[6] * 4 for t in probs),
+                                 sum(2.0 * t[4] * t[5] * t[6] for t in probs)))
             if rows == 192:
                 L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
             else:
