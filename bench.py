@@ -55,7 +55,8 @@ def parse():
     p.add_argument("--crop", type=int, default=256, choices=[256, 224],
                    help="224 = labelled EXTENSION (fusion kernels follow the final grid, parity unpinned: the reference rejects it)")
     p.add_argument("--batch-per-gpu", type=int, default=4)
-    p.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--compute", default="bf16", choices=["bf16", "fp32", "fp16"],
+                   help="bf16: the headline mode; fp32: the parity-certified mode; fp16: the reference's autocast arithmetic + dynamic loss scaling")
     p.add_argument("--median-steps", type=int, default=50, help="single steps timed with HIP events for median_step_ms")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--quick-cpu-baseline", action="store_true", help="only the headline CPU sample (B=2 at the benchmarked grid)")
@@ -136,7 +137,8 @@ class GemmTimer:
         if not sel:
             return 0, None, None
         dev = torch.device("cuda", torch.cuda.current_device())
-        tdt = lambda dt: torch.float32 if dt == 0 else torch.bfloat16
+        from csts_amd import lib as _L
+        tdt = lambda dt: torch.float32 if dt == 0 else _L.half_dtype()
         pool, rot = {}, {}
 
         def buf(key, numel, dt, fill):
@@ -344,7 +346,7 @@ def _host_cpu():
     return model, max(1, len(phys) or len(allowed)), len(allowed)
 
 
-def cpu_baseline(frames, mode, quick, budget_s=150.0, batch=4):
+def cpu_baseline(frames, mode, quick, budget_s=110.0, batch=4):
     """The CPU oracle (a port of the reference path to plain PyTorch fp32 ops, pinned to the reference by
     tests/test_oracle_golden.py) on the host cores: 1 warm-up + min of 3 per configuration.
     `value` = the train step (fwd + loss + bwd, no optimizer) -- or the forward in --mode fwd -- on THE GPU LINE'S OWN
@@ -769,7 +771,7 @@ def main():
                 replay = {"error": repr(e)}
         tot_sec = sum(a[3] for a in agg.values())
         tot_fl = sum(a[1] for a in agg.values())
-        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else 157.3
+        peak = PEAK_BF16_TFLOPS if args.compute in ("bf16", "fp16") else 157.3      # dense f16 MFMA rate == bf16 rate on gfx950
         traffic = None
         try:     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py), same command, same kernel
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

@@ -121,7 +121,8 @@ def train(cfg):
     dev = torch.device("cuda", torch.cuda.current_device())
     steps = cfg.CSTS_AMD.STEPS_PER_EPOCH
     from . import checkpoint as ck
-    start_epoch = ck.load_train_checkpoint(cfg, model, optimizer)          # train_avgaze_net.py:280
+    scaler = T.scaler_of(optimizer)        # fp16 mode: GradScaler state (train_avgaze_net.py:277), saved as "scaler_state"
+    start_epoch = ck.load_train_checkpoint(cfg, model, optimizer, scaler=scaler)          # train_avgaze_net.py:280
     _log({"_type": "train_start", "start_epoch": start_epoch + 1, "resumed": start_epoch > 0,
           "optimizer_steps": int(optimizer.step_count()) if hasattr(optimizer, "step_count") else None})
     model.train()
@@ -151,12 +152,13 @@ def train(cfg):
                     raise RuntimeError("ERROR: Got NaN losses")      # misc.check_nan_losses (misc.py:26-33)
                 _log({"_type": "train_iter", "epoch": epoch + 1, "iter": it + 1, "lr": lr,
                       "lr_device": float(optimizer.param_groups[0]["lr"]),        # what the (captured) optimizer kernels read
+                      "loss_scale": scaler.get_scale() if scaler is not None else None,
                       "loss": lv,
                       "kldiv_loss": float(vals[1]), "nce_loss": float(vals[2]) if nce is not None else None})
         torch.cuda.synchronize()
         _log({"_type": "train_epoch", "epoch": epoch + 1, "clips_per_s": steps * b * world / (time.time() - t0)})
         if getattr(cfg.CSTS_AMD, "SAVE_CHECKPOINTS", False) and is_checkpoint_epoch(cfg, epoch):
-            path = ck.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, epoch, cfg)  # train_avgaze_net.py:337-346 (0.75 GB + moments)
+            path = ck.save_checkpoint(cfg.OUTPUT_DIR, model, optimizer, epoch, cfg, scaler=scaler)  # train_avgaze_net.py:337-346 (0.75 GB + moments)
             _log({"_type": "checkpoint", "epoch": epoch + 1, "path": path,
                   "optimizer_steps": int(optimizer.step_count()) if hasattr(optimizer, "step_count") else None})
         if is_eval_epoch(cfg, epoch):                                         # train_avgaze_net.py:338,355-356

@@ -106,7 +106,7 @@ def get_cfg() -> CfgNode:
     c.LOG_MODEL_INFO = True
     c.DIST_BACKEND = "nccl"          # == RCCL on ROCm
     # this implementation's switches
-    c.CSTS_AMD = _node(COMPUTE="auto",               # "fp32": exact-fp32 MFMA parity mode ; "bf16": throughput mode ; "auto": by TRAIN.MIXED_PRECISION (model.resolve_compute)
+    c.CSTS_AMD = _node(COMPUTE="auto",               # "fp32": exact-fp32 MFMA parity mode ; "bf16": throughput mode ; "fp16": the reference's autocast arithmetic + dynamic loss scaling ; "auto": by TRAIN.MIXED_PRECISION (model.resolve_compute)
                        SYNTHETIC_DATA=True,          # the data pipeline is out of scope: synthetic clips
                        STEPS_PER_EPOCH=50,
                        EPOCHS_THIS_RUN=0,            # > 0: stop this invocation after that many epochs (pre-emption; the next one auto-resumes)

@@ -134,7 +134,7 @@ __device__ __forceinline__ void score(f32x16& acc, const typename El<F32>::T* X,
 #pragma unroll
     for (int s = 0; s < HD / 16; ++s) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xb + 16 * s);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fr.b[s], acc, 0, 0, 0);
+      acc = CSTS_MFMA16(a, fr.b[s], acc, 0, 0, 0);
     }
   }
 }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void pv(f32x16 (&out)[HD / 32], const typename El<F32
         bf16x8 a;
         a[0] = b0[0]; a[1] = b0[1]; a[2] = b0[2]; a[3] = b0[3];
         a[4] = b1[0]; a[5] = b1[1]; a[6] = b1[2]; a[7] = b1[3];
-        out[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, out[d], 0, 0, 0);
+        out[d] = CSTS_MFMA16(a, bp, out[d], 0, 0, 0);
       }
     }
   }
@@ -189,7 +189,7 @@ template <int HD> struct ScoreOps {          // A operands of score(): 32 rows x
 template <int HD>
 __device__ __forceinline__ void score_regs(f32x16& acc, const ScoreOps<HD>& x, const RowFrag<HD, false>& fr) {
 #pragma unroll
-  for (int s = 0; s < HD / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.a[s], fr.b[s], acc, 0, 0, 0);
+  for (int s = 0; s < HD / 16; ++s) acc = CSTS_MFMA16(x.a[s], fr.b[s], acc, 0, 0, 0);
 }
 template <int HD> struct PvOps {             // transposed A operands of pv(): the same 32 rows, read column-wise
   s16x4 t[2][HD / 32][2];
@@ -220,7 +220,7 @@ __device__ __forceinline__ void pv_regs(f32x16 (&out)[HD / 32], const PvOps<HD>&
       bf16x8 a;
       a[0] = b0[0]; a[1] = b0[1]; a[2] = b0[2]; a[3] = b0[3];
       a[4] = b1[0]; a[5] = b1[1]; a[6] = b1[2]; a[7] = b1[3];
-      out[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, out[d], 0, 0, 0);
+      out[d] = CSTS_MFMA16(a, bp, out[d], 0, 0, 0);
     }
   }
 }
@@ -715,10 +715,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_fast_kernel(AttnP p) {
       if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
       const bf16x8 a = ring[g % (DEPTH + 1)];
       if constexpr (g < SCB) {
-        S[g / NS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf.b[g % NS], S[g / NS], 0, 0, 0);
+        S[g / NS] = CSTS_MFMA16(a, qf.b[g % NS], S[g / NS], 0, 0, 0);
       } else {
         constexpr int j = g - SCB, u = j / (2 * ND), s2 = (j % (2 * ND)) / ND, d = j % ND;
-        O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp[u][s2], O[d], 0, 0, 0);
+        O[d] = CSTS_MFMA16(a, bp[u][s2], O[d], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -955,11 +955,11 @@ __global__ __launch_bounds__(256, (KT == 2 ? 2 : 1)) void attn_dq_fast_kernel(At
       if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
       const bf16x8 a = ring[g % (DEPTH + 1)];
       if constexpr (!is_pv) {
-        if constexpr (k < NS) S[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf.b[k], S[par], 0, 0, 0);
-        else dP[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dof.b[k - NS], dP[par], 0, 0, 0);
+        if constexpr (k < NS) S[par] = CSTS_MFMA16(a, qf.b[k], S[par], 0, 0, 0);
+        else dP[par] = CSTS_MFMA16(a, dof.b[k - NS], dP[par], 0, 0, 0);
       } else {
         constexpr int s2 = k / ND, d = k % ND;
-        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp[par][s2], acc[d], 0, 0, 0);
+        acc[d] = CSTS_MFMA16(a, bp[par][s2], acc[d], 0, 0, 0);
       }
       // the dS pieces of the unit whose SC block came just before this block
       if constexpr (bi == 1) {                                       // dS(0) under SC(1): one piece per slot
@@ -1113,12 +1113,12 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
         if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
         const bf16x8 a = ring[g % (DEPTH + 1)];
         if constexpr (!is_pv) {
-          if constexpr (k < NS) S[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf.b[k], S[par], 0, 0, 0);
-          else dP[par] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, vf.b[k - NS], dP[par], 0, 0, 0);
+          if constexpr (k < NS) S[par] = CSTS_MFMA16(a, kf.b[k], S[par], 0, 0, 0);
+          else dP[par] = CSTS_MFMA16(a, vf.b[k - NS], dP[par], 0, 0, 0);
         } else {
           constexpr int idx = k % (2 * ND), s2 = idx / ND, d = idx % ND;
-          if constexpr (k < 2 * ND) dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpS[par][s2], dV[d], 0, 0, 0);
-          else dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bpD[par][s2], dK[d], 0, 0, 0);
+          if constexpr (k < 2 * ND) dV[d] = CSTS_MFMA16(a, bpS[par][s2], dV[d], 0, 0, 0);
+          else dK[d] = CSTS_MFMA16(a, bpD[par][s2], dK[d], 0, 0, 0);
         }
         // the softmax backward of the unit whose S / dP block came just before this block
         if constexpr (bi >= 1 && k < 8) {

@@ -8,16 +8,46 @@
 
 #include "../../include/csts_hip.h"
 
+// The 16-bit activation type of this BUILD.  libcsts_hip.so: bfloat16 (the throughput mode, CSTS_AMD.COMPUTE bf16);
+// libcsts_hip_f16.so (-DCSTS_HALF_F16, `make f16`): IEEE half -- the arithmetic of the reference's own mixed precision,
+// torch.cuda.amp.autocast = fp16 + GradScaler (tools/train_avgaze_net.py:70,99-109,277).  Same kernels, same MFMA rate
+// (v_mfma_f32_32x32x16_f16), same bytes; the enum value CSTS_BF16 then means "the 16-bit type of the build" (CSTS_HALF) and
+// csts_half_kind() tells a caller which one a library holds.  The type keeps its short name in the sources.
+#ifdef CSTS_HALF_F16
+typedef _Float16 bf16;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define CSTS_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define CSTS_MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
+
+// 16-bit element(s) held as raw bits -> float: element 0 / 1 of a 32-bit pair, or one 16-bit value
+__device__ __forceinline__ float h16_lo(unsigned v) {
+#ifdef CSTS_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu));
+#else
+  return __uint_as_float(v << 16);
+#endif
+}
+__device__ __forceinline__ float h16_hi(unsigned v) {
+#ifdef CSTS_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16));
+#else
+  return __uint_as_float(v & 0xffff0000u);
+#endif
+}
 
 // ---------------------------------------------------------------- errors
 void csts_set_error(const std::string& s);

@@ -179,10 +179,10 @@ __global__ __launch_bounds__(NT_) void gemm_kernel(Params p) {
       for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 a0 = frag_bf16<A_KC>(Ab, wm * 64, ks, lane), a1 = frag_bf16<A_KC>(Ab, wm * 64 + 32, ks, lane);
         bf16x8 b0 = frag_bf16<B_KC>(Bb, wn * 64, ks, lane), b1 = frag_bf16<B_KC>(Bb, wn * 64 + 32, ks, lane);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        acc[0][0] = CSTS_MFMA16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = CSTS_MFMA16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = CSTS_MFMA16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = CSTS_MFMA16(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
   }
@@ -490,8 +490,8 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
       b[1] = OB::frag(Bs, wn * 64 + 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
+        acc[i][0] = CSTS_MFMA16(a[i], b[0], acc[i][0], 0, 0, 0);
+        acc[i][1] = CSTS_MFMA16(a[i], b[1], acc[i][1], 0, 0, 0);
       }
     }
   }
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(256, (G3Occ<MT, S>::WG)) void gemm3_kernel(Params p
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][0], fa[ks & 1][i], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & 1][1], fa[ks & 1][i], acc[i][1], 0, 0, 0);
+          acc[i][0] = CSTS_MFMA16(fb[ks & 1][0], fa[ks & 1][i], acc[i][0], 0, 0, 0);
+          acc[i][1] = CSTS_MFMA16(fb[ks & 1][1], fa[ks & 1][i], acc[i][1], 0, 0, 0);
         }
       }
       if (refill) {                                  // advance the producer
@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(256, (MT == 4) ? 2 : ((MT == 2) ? 3 : 4)) void wgra
       b[1] = OB::frag(Bs, wn * 64 + 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0], acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
+        acc[i][0] = CSTS_MFMA16(a[i], b[0], acc[i][0], 0, 0, 0);
+        acc[i][1] = CSTS_MFMA16(a[i], b[1], acc[i][1], 0, 0, 0);
       }
     }
   }

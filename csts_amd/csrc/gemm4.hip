@@ -226,7 +226,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks & (DB - 1)][j], fa[ks & (DB - 1)][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = CSTS_MFMA16(fb[ks & (DB - 1)][j], fa[ks & (DB - 1)][i], acc[i][j], 0, 0, 0);
         if (DB == 1 && ks + 1 < NKS) frags(ks + 1, 0);
       }
       if (refill) advance();

@@ -13,7 +13,7 @@ constexpr int LN_BWD_WAVES = 8;  // 512-thread blocks: few, fat partial rows for
 // compile-time dtypes: no branch sits between a load and the next one, so a wave keeps R rows x NV loads in flight
 template <bool F32> __device__ __forceinline__ float ldt(const void* p, int64_t i) {
   if constexpr (F32) return reinterpret_cast<const float*>(p)[i];
-  else return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+  else return h16_lo((unsigned)reinterpret_cast<const unsigned short*>(p)[i]);
 }
 template <bool F32> __device__ __forceinline__ void stt(void* p, int64_t i, float v) {
   if constexpr (F32) reinterpret_cast<float*>(p)[i] = v;
@@ -200,10 +200,10 @@ template <bool F32> __device__ __forceinline__ void ld8t(const void* p, int64_t 
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
   } else {
     const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p) + i);
-    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
-    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
-    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+    o[0] = h16_lo(r.x); o[1] = h16_hi(r.x);
+    o[2] = h16_lo(r.y); o[3] = h16_hi(r.y);
+    o[4] = h16_lo(r.z); o[5] = h16_hi(r.z);
+    o[6] = h16_lo(r.w); o[7] = h16_hi(r.w);
   }
 }
 template <bool F32> __device__ __forceinline__ void st8t(void* p, int64_t i, const float (&o)[8]) {

@@ -104,8 +104,8 @@ template <bool F32> __device__ __forceinline__ Raw4<F32> raw4_load(const void* b
 template <bool F32> __device__ __forceinline__ void raw4_cvt(const Raw4<F32>& r, float (&o)[4]) {
   if constexpr (F32) { o[0] = r.v.x; o[1] = r.v.y; o[2] = r.v.z; o[3] = r.v.w; }
   else {
-    o[0] = __uint_as_float(r.v.x << 16); o[1] = __uint_as_float(r.v.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.v.y << 16); o[3] = __uint_as_float(r.v.y & 0xffff0000u);
+    o[0] = h16_lo(r.v.x); o[1] = h16_hi(r.v.x);
+    o[2] = h16_lo(r.v.y); o[3] = h16_hi(r.v.y);
   }
 }
 template <bool F32> __device__ __forceinline__ void st4t(void* base, int i, const float (&o)[4]) {
@@ -142,10 +142,10 @@ template <bool F32> __device__ __forceinline__ void raw8_cvt(const Raw8<F32>& r,
   if constexpr (F32) {
     o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
   } else {
-    o[0] = __uint_as_float(r.a.x << 16); o[1] = __uint_as_float(r.a.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.a.y << 16); o[3] = __uint_as_float(r.a.y & 0xffff0000u);
-    o[4] = __uint_as_float(r.a.z << 16); o[5] = __uint_as_float(r.a.z & 0xffff0000u);
-    o[6] = __uint_as_float(r.a.w << 16); o[7] = __uint_as_float(r.a.w & 0xffff0000u);
+    o[0] = h16_lo(r.a.x); o[1] = h16_hi(r.a.x);
+    o[2] = h16_lo(r.a.y); o[3] = h16_hi(r.a.y);
+    o[4] = h16_lo(r.a.z); o[5] = h16_hi(r.a.z);
+    o[6] = h16_lo(r.a.w); o[7] = h16_hi(r.a.w);
   }
 }
 template <bool F32> __device__ __forceinline__ void st8t(void* base, int64_t i, const float (&o)[8]) {
@@ -597,7 +597,7 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
       c0 = v.x; c1 = v.y;
     } else {
       const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16*>(cb) + (bt - b * ntok) * cts + c);
-      c0 = __uint_as_float(v << 16); c1 = __uint_as_float(v & 0xffff0000u);
+      c0 = h16_lo(v); c1 = h16_hi(v);
     }
     if constexpr (FF32) {
       float2 raw[27];
@@ -636,8 +636,8 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
           for (int kw = 0; kw < 3; ++kw) {
             const int tap = kt * 9 + kh * 3 + kw;
             const unsigned r = (tv[kt] && hv[kh] && xv[kw]) ? raw[tap] : 0u;
-            a0[tap] += __uint_as_float(r << 16) * c0;
-            a1[tap] += __uint_as_float(r & 0xffff0000u) * c1;
+            a0[tap] += h16_lo(r) * c0;
+            a1[tap] += h16_hi(r) * c1;
           }
     }
     ow += tstep;

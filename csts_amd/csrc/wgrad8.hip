@@ -182,7 +182,7 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // operands swapped: see the epilogue
+        for (int j = 0; j < 3; ++j) acc[i][j] = CSTS_MFMA16(b[j], a[i], acc[i][j], 0, 0, 0);   // operands swapped: see the epilogue
     }
     W8_STAMP();
   }

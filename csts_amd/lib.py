@@ -8,8 +8,39 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+_lib = None
+
+
+class CstsError(RuntimeError):
+    pass
+
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSTS_HIP_LIB") or os.path.join(_HERE, "libcsts_hip.so")   # override: A/B runs of two builds on one box
+# The 16-bit activation type is a property of the LIBRARY BUILD (csts_amd/csrc/common.h): libcsts_hip.so = bfloat16,
+# libcsts_hip_f16.so = IEEE half (the same sources with -DCSTS_HALF_F16).  One process runs ONE of them: set_half() picks it
+# before the first load (CSTS_AMD.COMPUTE fp16 does, model.Runtime), and a later request for the other kind raises.
+HALF = os.environ.get("CSTS_HALF", "bf16")
+_PATHS = {"bf16": LIB_PATH, "fp16": os.environ.get("CSTS_HIP_LIB_F16") or os.path.join(_HERE, "libcsts_hip_f16.so")}
+
+
+def set_half(kind: str):
+    """Select the 16-bit type of this process ("bf16" | "fp16").  Must happen before the library is loaded with the other kind."""
+    global HALF, LIB_PATH
+    if kind not in _PATHS:
+        raise ValueError(f"16-bit type must be 'bf16' or 'fp16', got {kind!r}")
+    if _lib is not None and kind != HALF:
+        raise CstsError(f"this process already runs the {HALF} kernel library; the {kind} build is a different shared object "
+                        "(one 16-bit activation type per process: start a new process for the other mode)")
+    HALF = kind
+    LIB_PATH = _PATHS[kind]
+
+
+def half_dtype():
+    """torch dtype of the enum value BF16 (= CSTS_HALF, the 16-bit type of the loaded build)."""
+    import torch
+    return torch.float16 if HALF == "fp16" else torch.bfloat16
+
 
 ABI_VERSION = 3   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
 F32, BF16 = 0, 1
@@ -99,7 +130,8 @@ class OptArgs(C.Structure):
     _fields_ = [("chunk_tensor", vp), ("chunk_off", vp), ("nchunks", C.c_int), ("chunk_elems", C.c_int),
                 ("tensors", vp), ("grads", vp), ("ntensors", C.c_int),
                 ("partial", vp), ("state", vp), ("lr", vp),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_grad_norm", C.c_float)]
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_grad_norm", C.c_float),
+                ("grad_dt", C.c_int), ("scaler", vp), ("growth", C.c_float), ("backoff", C.c_float), ("growth_interval", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/csts_hip.h declares
@@ -111,6 +143,7 @@ class TransposeTile(C.Structure):
 SYMBOLS = {
     "csts_last_error": (C.c_char_p, []),
     "csts_abi_version": (_I, []),
+    "csts_half_kind": (_I, []),
     "csts_gemm": (_I, [C.POINTER(GemmArgs), vp]),
     "csts_gemm_splitk_workspace": (sz, [i64, i64, i64, _I]),
     "csts_gemm_v2_eligible": (_I, [C.POINTER(GemmArgs)]),
@@ -181,11 +214,6 @@ SYMBOLS = {
     "csts_adaptive_f1": (_I, [vp, vp, vp, vp, _I, i64, _I, _I, vp, vp, sz, vp]),
 }
 
-_lib = None
-
-
-class CstsError(RuntimeError):
-    pass
 
 
 def load() -> C.CDLL:
@@ -194,6 +222,8 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if HALF not in _PATHS:
+        raise CstsError(f"CSTS_HALF must be 'bf16' or 'fp16', got {HALF!r}")
     if not os.path.exists(LIB_PATH):
         raise CstsError(f"{LIB_PATH} not found: the HIP kernel library is required (no CPU fallback). "
                         "Build it with `make -C csts_amd/csrc` (hipcc --offload-arch=gfx950).")
@@ -204,6 +234,8 @@ def load() -> C.CDLL:
             raise CstsError(f"{LIB_PATH} does not export {name}: stale build?")
         fn.restype = res
         fn.argtypes = args
+    if lib.csts_half_kind() != (1 if HALF == "fp16" else 0):
+        raise CstsError(f"{LIB_PATH} holds the {'fp16' if lib.csts_half_kind() else 'bf16'} kernels but this process selected {HALF}")
     got = lib.csts_abi_version()
     if got != ABI_VERSION:
         # a stale / alternate build reads the argument structs with another layout (e.g. a pre-res_up library would read

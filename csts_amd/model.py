@@ -44,22 +44,26 @@ _log = logging.getLogger("csts_amd")
 
 
 def resolve_compute(cfg) -> str:
-    """CSTS_AMD.COMPUTE ("fp32" | "bf16" | "auto") together with the reference's TRAIN.MIXED_PRECISION key
+    """CSTS_AMD.COMPUTE ("fp32" | "bf16" | "fp16" | "auto") together with the reference's TRAIN.MIXED_PRECISION key
     (slowfast/config/defaults.py:79; tools/train_avgaze_net.py:70,99-109,277: torch.cuda.amp.autocast = fp16 + GradScaler).
-    There is no fp16 mode here: MIXED_PRECISION True selects the bf16 mode -- bf16 MFMA operands with fp32 accumulation,
-    fp32 master weights, residual stream, LayerNorm statistics, softmax and losses, i.e. the tensors autocast keeps in fp32
-    -- and no loss scaling is applied (or needed: bf16 has fp32's exponent range, so GradScaler's overflow / skipped-step
-    logic has nothing to act on).  "auto" follows the key: False -> fp32 (the reference's default arithmetic), True -> bf16.
-    The key is never ignored silently: the mapping is logged."""
+    "fp16" IS that arithmetic: IEEE-half MFMA operands with fp32 accumulation, fp32 master weights / residual stream / LayerNorm
+    statistics / softmax / losses (what autocast keeps in fp32), dynamic loss scaling with skipped steps (optim.FusedAdamW).
+    "bf16" is the throughput mode the benchmark is quoted in: bfloat16 operands, same fp32 set, no loss scaling (fp32's exponent
+    range).  "auto" follows the key: False -> fp32 (the reference's default arithmetic), True -> bf16 (north_star's dtype; set
+    COMPUTE fp16 for the reference's own).  The key is never ignored silently: the mapping is logged."""
     amd = getattr(cfg, "CSTS_AMD", None)
     compute = str(getattr(amd, "COMPUTE", "auto") if amd is not None else "auto").lower()
     mp = bool(getattr(getattr(cfg, "TRAIN", None), "MIXED_PRECISION", False))
     if compute == "auto":
         compute = "bf16" if mp else "fp32"
     if mp:
-        if compute == "bf16":
+        if compute == "fp16":
+            _log.warning("TRAIN.MIXED_PRECISION True with CSTS_AMD.COMPUTE fp16: the reference's fp16 autocast + GradScaler arithmetic "
+                         "(fp32 master weights / residual stream / statistics / losses, dynamic loss scaling in the optimizer kernels)")
+        elif compute == "bf16":
             _log.warning("TRAIN.MIXED_PRECISION True: the reference's fp16 autocast + GradScaler runs here as the bf16 compute mode "
-                         "(fp32 master weights / residual stream / statistics / losses, no loss scaling: bf16 has fp32's exponent range)")
+                         "(fp32 master weights / residual stream / statistics / losses, no loss scaling: bf16 has fp32's exponent range); "
+                         "CSTS_AMD.COMPUTE fp16 selects the reference's own fp16 arithmetic")
         else:
             _log.warning("TRAIN.MIXED_PRECISION True but CSTS_AMD.COMPUTE is %r: the explicit compute mode wins, no mixed precision", compute)
     return compute
@@ -70,10 +74,17 @@ class Runtime:
 
     def __init__(self, compute: str):
         compute = str(compute).lower()
-        if compute not in ("fp32", "bf16"):
-            raise ValueError(f"CSTS_AMD.COMPUTE must be 'fp32' or 'bf16', got {compute!r}")
+        if compute not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"CSTS_AMD.COMPUTE must be 'fp32', 'bf16' or 'fp16', got {compute!r}")
         self.name = compute
+        if compute != "fp32":
+            # the 16-bit type is a property of the kernel library build: bf16 -> libcsts_hip.so, fp16 -> libcsts_hip_f16.so (one
+            # per process, lib.set_half raises when the other one is already loaded); the enum value L.BF16 means "16-bit"
+            L.set_half(compute)
         self.compute = L.F32 if compute == "fp32" else L.BF16
+        # fp16: the reference's mixed precision (torch.cuda.amp.autocast + GradScaler, tools/train_avgaze_net.py:70,99-109,277):
+        # the training harness multiplies the loss by a dynamic scale and the optimizer kernels unscale / skip / update it
+        self.loss_scaling = compute == "fp16"
         self.act_dt = self.compute            # dtype of GEMM inputs / q,k,v / MLP hidden
         self.stream_dt = L.F32                # residual stream, LN statistics, softmax, losses
 
@@ -360,7 +371,7 @@ class CSTS(nn.Module):
         shadowed = self._w16_all
         stale = [l for l in shadowed if getattr(l, "_w16", None) is None or l._w16.device != l.weight.device]
         for l in stale:
-            l._w16 = torch.empty(l.weight.shape, dtype=torch.bfloat16, device=l.weight.device)
+            l._w16 = torch.empty(l.weight.shape, dtype=L.half_dtype(), device=l.weight.device)
             l._w16_ver = -1
         # With csts_amd.optim.FusedAdamW the optimizer kernel itself rewrites the shadows (w16_external): only an
         # out-of-band weight change (load_state_dict, manual edit: bumps _version) needs a refresh here.
@@ -375,7 +386,7 @@ class CSTS(nn.Module):
             ts = getattr(self, "_w16t_set", None)
             if ts is None or ts.pairs[0][0].device != lins[0]._w16.device or any(l._w16 is not p_[0] for l, p_ in zip(lins, ts.pairs)):
                 for l in lins:
-                    l._w16t = torch.empty(l.weight.shape[1], l.weight.shape[0], dtype=torch.bfloat16, device=l.weight.device)
+                    l._w16t = torch.empty(l.weight.shape[1], l.weight.shape[0], dtype=L.half_dtype(), device=l.weight.device)
                 ts = self._w16t_set = ops._TransposeSet([(l._w16, l._w16t) for l in lins])
             ts.refresh()
 

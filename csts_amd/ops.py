@@ -29,13 +29,13 @@ def _lib():
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype == L.half_dtype():       # bfloat16, or float16 in a process that runs the fp16 build (lib.set_half)
         return BF16
-    raise L.CstsError(f"unsupported dtype {t.dtype}")
+    raise L.CstsError(f"unsupported dtype {t.dtype} (this process runs the {L.HALF} kernel library)")
 
 
 def torch_dtype(dt: int):
-    return torch.float32 if dt == F32 else torch.bfloat16
+    return torch.float32 if dt == F32 else L.half_dtype()
 
 
 try:
@@ -314,7 +314,7 @@ def queue_wgrad(dY, X, tokens, N, K, Wp, bp):
     above).  Returns False when the problem has to run in line."""
     if GROUP_WGRADS == "never" or (GROUP_WGRADS == "capture" and not torch.cuda.is_current_stream_capturing()):
         return False
-    if not (DEFER_REDUCTIONS and X.dtype == torch.bfloat16 and dY.dtype in (torch.float32, torch.bfloat16)
+    if not (DEFER_REDUCTIONS and X.dtype == L.half_dtype() and dY.dtype in (torch.float32, L.half_dtype())
             and N % 8 == 0 and K % 8 == 0 and dY.is_contiguous() and X.is_contiguous() and tokens >= 256):
         return False
     if Wp is None or Wp.dtype != torch.float32 or tuple(Wp.shape) != (N, K) or not _can_defer(Wp, bp):
@@ -607,7 +607,7 @@ def _ln_bwd_call(dy, x, gamma, mean, rstd, addend, rows, Cc, what, want16=False,
     want16: also emit a bf16 copy of dx, attached as dx._csts_bf16, for the weight/data-gradient GEMMs that read it next
     (LinearFn / MlpFn backward pick it up; any other consumer simply ignores the attribute)."""
     dx = torch.empty_like(x)
-    dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (want16 and BF16_GRAD_COPY) else None
+    dx16 = torch.empty(x.shape, dtype=L.half_dtype(), device=x.device) if (want16 and BF16_GRAD_COPY) else None
     dgb = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
     nbytes = _lib().csts_layernorm_bwd_workspace(rows, Cc)
     ws = _ws(nbytes, x.device)
@@ -740,7 +740,7 @@ class LayerNormFn(Function):
             if dpass.dtype != x.dtype:
                 dpass = dpass.to(x.dtype)
         dx, dgb = _ln_bwd_call(dy, x, gamma, mean, rstd, dpass, rows, Cc, "csts_layernorm_bwd",
-                               want16=(x.dtype == torch.float32 and dy.dtype == torch.bfloat16), params=ctx.params,
+                               want16=(x.dtype == torch.float32 and dy.dtype == L.half_dtype()), params=ctx.params,
                                copy_scale=ctx.copy_scale, dy2=dy2)
         if dgb is None:                     # finished and assigned by the end-of-backward flush
             return both(dx)
@@ -829,7 +829,7 @@ class LinearFn(Function):
 def _dgrad(dy, W, Wt, dx, M, N, K, compute, epilogue=L.EPI_NONE, aux=None):
     """dx[M,K] = dy[M,N] W[N,K].  With the [K][N] twin of the bf16 shadow (csts_transpose_multi) and a bf16 dy this is an
     NT GEMM -- both operands contiguous along the reduction, the forward's kernels -- else NN on W itself."""
-    if Wt is not None and dy.dtype == torch.bfloat16 and USE_W16T:
+    if Wt is not None and dy.dtype == L.half_dtype() and USE_W16T:
         gemm(L.GEMM_NT, dy, 0, N, Wt, 0, N, dx, K, M, K, N, compute=compute, epilogue=epilogue, aux=aux)
     else:
         gemm(L.GEMM_NN, dy, 0, N, W, 0, K, dx, K, M, K, N, compute=compute, epilogue=epilogue, aux=aux)
@@ -847,7 +847,7 @@ class _TransposeSet:
         tiles = []
         for src, dst in self.pairs:
             R, Cc = src.shape
-            assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and tuple(dst.shape) == (Cc, R)
+            assert src.dtype == L.half_dtype() and dst.dtype == L.half_dtype() and tuple(dst.shape) == (Cc, R)
             assert R % 8 == 0 and Cc % 8 == 0 and src.is_contiguous() and dst.is_contiguous()
             for r0 in range(0, R, 64):
                 for c0 in range(0, Cc, 64):
@@ -1284,7 +1284,7 @@ class QkvCompactFn(Function):
         Wt = ctx.w16t
         dx = torch.empty_like(x)
         dxk = torch.empty(B, Nc, K, dtype=torch.float32, device=x.device)     # fp32: one rounding when it joins dx
-        if Wt is not None and dq.dtype == torch.bfloat16 and USE_W16T:         # NT on the [in][out] twin (columns 0..C | C..3C)
+        if Wt is not None and dq.dtype == L.half_dtype() and USE_W16T:         # NT on the [in][out] twin (columns 0..C | C..3C)
             gemm(L.GEMM_NT, dq, 0, Cc, Wt, 0, 3 * Cc, dx, K, B * N, K, Cc, compute=compute)
             gemm(L.GEMM_NT, dkv, 0, 2 * Cc, Wt, Cc, 3 * Cc, dxk, K, B * Nc, K, 2 * Cc, compute=compute)
         else:
@@ -1295,7 +1295,7 @@ class QkvCompactFn(Function):
         dW = db = None
         queued = False
         if compute == BF16 and GROUP_WGRADS != "never" and (GROUP_WGRADS != "capture" or torch.cuda.is_current_stream_capturing()) \
-                and DEFER_REDUCTIONS and x.dtype == torch.bfloat16 and Cc % 8 == 0 and K % 8 == 0 and B * Nc >= 256 \
+                and DEFER_REDUCTIONS and x.dtype == L.half_dtype() and Cc % 8 == 0 and K % 8 == 0 and B * Nc >= 256 \
                 and Wp.dtype == torch.float32 and _can_defer(Wp, bp):
             dWf = _grad_buffer(Wp, (3 * Cc, K), x.device)
             dbf = _grad_buffer(bp, (3 * Cc,), x.device) if bp is not None else None
@@ -1692,7 +1692,7 @@ class TapFn(Function):
         da, db = da.contiguous(), db.contiguous()
         out = torch.empty(da.shape, dtype=torch.float32, device=da.device)
         want16 = ctx.compute == BF16 and BF16_GRAD_COPY
-        out16 = torch.empty(da.shape, dtype=torch.bfloat16, device=da.device) if want16 else None
+        out16 = torch.empty(da.shape, dtype=L.half_dtype(), device=da.device) if want16 else None
         cs = ctx.copy_scale if out16 is not None else None
         if cs is not None:
             rows = da.numel() // da.shape[-1]
@@ -1765,7 +1765,7 @@ class ClassifierFn(Function):
         if ctx.compute == BF16 and BF16_GRAD_COPY and dz.dtype == torch.float32:
             # the last decoder block has no drop-path and nothing else would give its GEMMs a bf16 copy of this gradient:
             # without one its two data-gradient GEMMs and its weight gradients stream the fp32 tensor (M = 262 k rows)
-            dz16 = torch.empty(dz.shape, dtype=torch.bfloat16, device=dz.device)
+            dz16 = torch.empty(dz.shape, dtype=L.half_dtype(), device=dz.device)
             L.check(_lib().csts_rowdot_dx(_p(dl), _p(wf), _p(dz16), BF16, M, Cc, _stream()), "csts_rowdot_dx(bf16)")
             _attach16(dz, dz16)
         dw = colsum(z, 1, M, Cc, row_weight=dl).view(wshape)

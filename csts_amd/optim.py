@@ -22,7 +22,8 @@ CHUNK = 65536        # elements per workgroup: 256 KiB of fp32 gradient
 
 class FusedAdamW:
     def __init__(self, param_groups: List[Dict], lr: float, betas=(0.9, 0.999), eps: float = 1e-8, max_grad_norm: float = 0.0,
-                 shadows: Dict[int, torch.Tensor] = None):
+                 shadows: Dict[int, torch.Tensor] = None, loss_scaling: bool = False, init_scale: float = 65536.0,
+                 growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
         """param_groups: [{"params": [...], "weight_decay": wd}, ...]; shadows: id(param) -> bf16 tensor kept equal
         to the parameter (the GEMMs' bf16 operand)."""
         self.param_groups = [dict(g) for g in param_groups]
@@ -46,7 +47,13 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros(o, dtype=torch.float32, device=self.device)
         self._m = [self.exp_avg[a:a + p.numel()] for a, p in zip(offs, params)]
         self._v = [self.exp_avg_sq[a:a + p.numel()] for a, p in zip(offs, params)]
-        self.state_t = torch.zeros(3, dtype=torch.float32, device=self.device)     # step, grad norm, clip coefficient
+        self.state_t = torch.zeros(4, dtype=torch.float32, device=self.device)     # step, grad norm, clip coefficient, skipped
+        # dynamic loss scaling (torch.cuda.amp.GradScaler defaults; tools/train_avgaze_net.py:277): {scale, growth tracker} on the
+        # device -- the training harness multiplies the loss by loss_scale before backward, the kernels unscale, detect non-finite
+        # gradients, skip the step and update the scale (scaler.unscale_ / step / update, train_avgaze_net.py:101-109)
+        self.scaler_t = torch.tensor([float(init_scale), 0.0], dtype=torch.float32, device=self.device) if loss_scaling else None
+        self.scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
+        self.grad_dt = L.F32          # L.BF16: every gradient handed to step() is in the library's 16-bit type (16-bit buckets)
         # tables
         wd_of = {id(p): float(g["weight_decay"]) for g in self.param_groups for p in g["params"]}
         tt = (L.OptTensor * len(params))()
@@ -55,7 +62,7 @@ class FusedAdamW:
         for i, p in enumerate(params):
             sh = shadows.get(id(p))
             if sh is not None:
-                assert sh.dtype == torch.bfloat16 and sh.numel() == p.numel() and sh.is_contiguous() and sh.device == p.device
+                assert sh.dtype == L.half_dtype() and sh.numel() == p.numel() and sh.is_contiguous() and sh.device == p.device
                 self._shadow_refs.append(sh)
             tt[i].p, tt[i].m, tt[i].v = p.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr()
             tt[i].w16 = sh.data_ptr() if sh is not None else None
@@ -106,8 +113,8 @@ class FusedAdamW:
             if g is None:
                 ptrs.append(0)
                 continue
-            if g.dtype != torch.float32 or not g.is_contiguous():
-                raise L.CstsError("FusedAdamW needs fp32 contiguous gradients")
+            if g.dtype != (torch.float32 if self.grad_dt == L.F32 else L.half_dtype()) or not g.is_contiguous():
+                raise L.CstsError("FusedAdamW needs contiguous gradients of its grad_dt (fp32, or all 16-bit)")
             if p.data_ptr() != self._param_ptrs[i]:
                 raise L.CstsError("a parameter was re-allocated after the optimizer was built (rebuild the optimizer)")
             ptrs.append(g.data_ptr())
@@ -134,7 +141,31 @@ class FusedAdamW:
         a.tensors, a.grads, a.ntensors = self._tensors.data_ptr(), self._grads_dev.data_ptr(), len(self.params)
         a.partial, a.state, a.lr = self._partial.data_ptr(), self.state_t.data_ptr(), self._lr.data_ptr()
         a.beta1, a.beta2, a.eps, a.max_grad_norm = self.betas[0], self.betas[1], self.eps, self.max_grad_norm
+        a.grad_dt = self.grad_dt
+        if self.scaler_t is not None:
+            a.scaler = self.scaler_t.data_ptr()
+            a.growth, a.backoff, a.growth_interval = self.scaler_cfg
         L.check(L.load().csts_adamw_step(C.byref(a), torch.cuda.current_stream().cuda_stream), "csts_adamw_step")
+
+    @property
+    def loss_scale(self):
+        """Device scalar the loss is multiplied by before backward (None without loss scaling)."""
+        return self.scaler_t[0] if self.scaler_t is not None else None
+
+    def scaler_state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict() layout (the reference stores it as "scaler_state", checkpoint.py:133-134)."""
+        if self.scaler_t is None:
+            return {}
+        sc, tr = self.scaler_t.tolist()
+        g, b, gi = self.scaler_cfg
+        return {"scale": sc, "growth_factor": g, "backoff_factor": b, "growth_interval": gi, "_growth_tracker": int(tr)}
+
+    def load_scaler_state_dict(self, sd):
+        if self.scaler_t is None or not sd:
+            return
+        self.scaler_t.copy_(torch.tensor([float(sd["scale"]), float(sd.get("_growth_tracker", 0))]))
+        self.scaler_cfg = (float(sd.get("growth_factor", self.scaler_cfg[0])), float(sd.get("backoff_factor", self.scaler_cfg[1])),
+                           int(sd.get("growth_interval", self.scaler_cfg[2])))
 
     def step_count(self) -> int:
         """AdamW steps taken so far (host sync: logging / checkpoint bookkeeping only)."""

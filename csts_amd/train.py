@@ -78,13 +78,45 @@ def construct_optimizer(model, cfg, capturable: bool = False, device_fused: bool
             shadows = {id(l.weight): l._w16 for l in (getattr(core, "_w16_all", None) or getattr(core, "_w16_lins", []))}
             core.w16_external = True
         return FusedAdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, max_grad_norm=float(cfg.SOLVER.CLIP_GRAD_L2NORM or 0.0),
-                          shadows=shadows)
+                          shadows=shadows, loss_scaling=bool(getattr(getattr(core, "rt", None), "loss_scaling", False)))
     kw = {}
     if fused and capturable:      # lr lives in a device tensor so that a captured step can follow the schedule
         kw = {"capturable": True}
         lr0 = torch.tensor(float(cfg.SOLVER.BASE_LR), dtype=torch.float32, device=groups[0]["params"][0].device)
         return torch.optim.AdamW(groups, lr=lr0, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY, fused=True, **kw)
     return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, weight_decay=cfg.SOLVER.WEIGHT_DECAY, fused=fused)
+
+
+class LossScaler:
+    """The reference's `scaler` object (torch.cuda.amp.GradScaler, tools/train_avgaze_net.py:277) for the fp16 compute mode: the
+    state lives on the device inside FusedAdamW (its kernels unscale, skip and update); this view gives the harness scale() and
+    the checkpoint code state_dict() / load_state_dict() ("scaler_state", slowfast/utils/checkpoint.py:133-134,351-352)."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+
+    def scale(self, loss):
+        return loss * self.opt.loss_scale
+
+    def get_scale(self) -> float:
+        return float(self.opt.loss_scale)
+
+    def state_dict(self):
+        return self.opt.scaler_state_dict()
+
+    def load_state_dict(self, sd):
+        self.opt.load_scaler_state_dict(sd)
+
+
+def scaler_of(optimizer):
+    """LossScaler when the optimizer carries dynamic loss scaling (CSTS_AMD.COMPUTE fp16), else None."""
+    return LossScaler(optimizer) if getattr(optimizer, "loss_scale", None) is not None else None
+
+
+def backward_scaled(loss, optimizer):
+    """scaler.scale(loss).backward() (train_avgaze_net.py:99) -- plain loss.backward() without loss scaling."""
+    sc = getattr(optimizer, "loss_scale", None) if optimizer is not None else None
+    (loss if sc is None else loss * sc).backward()
 
 
 def compute_loss(cfg, model, video, audio, labels_hm, keep_masks=None):
@@ -115,7 +147,7 @@ def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: O
         for p in model.parameters():
             p.grad = None
     loss, kld, nce, _ = compute_loss(cfg, model, batch["video"], batch["audio"], batch["labels_hm"], keep_masks)
-    loss.backward()
+    backward_scaled(loss, optimizer)
     if isinstance(model, GradAllReduce):
         model.finish()
     if optimizer is not None:
@@ -195,6 +227,7 @@ class _TrainStateSnapshot:
         self.opt = optimizer
         if hasattr(optimizer, "exp_avg"):                       # csts_amd.optim.FusedAdamW
             self.opt_state = (optimizer.exp_avg.clone(), optimizer.exp_avg_sq.clone(), optimizer.state_t.clone(), optimizer._lr.clone())
+            self.scaler = optimizer.scaler_t.clone() if getattr(optimizer, "scaler_t", None) is not None else None
         else:
             import copy
             self.opt_state = copy.deepcopy(optimizer.state_dict())
@@ -206,6 +239,8 @@ class _TrainStateSnapshot:
         if hasattr(self.opt, "exp_avg"):
             a, b, c, d = self.opt_state
             self.opt.exp_avg.copy_(a); self.opt.exp_avg_sq.copy_(b); self.opt.state_t.copy_(c); self.opt._lr.copy_(d)
+            if self.scaler is not None:
+                self.opt.scaler_t.copy_(self.scaler)
         else:
             self.opt.load_state_dict(self.opt_state)
         if self.rng is not None:
@@ -259,7 +294,7 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss, kld, nce, _ = compute_loss(self.cfg, self.model, self.static["video"], self.static["audio"],
                                          self.static["labels_hm"])
-        loss.backward()
+        backward_scaled(loss, self.opt)
         if isinstance(self.model, GradAllReduce):
             self.model.finish()
         _clip_and_step(self.cfg, self.model, self.opt)
@@ -408,7 +443,7 @@ class SegmentedTrainStep:
             preds = losses.frame_softmax(leaves[0], temperature=2)
             kld = losses.get_loss_func(cfg.MODEL.LOSS_FUNC)()(preds, self.static["labels_hm"])
             loss, nce = kld, None
-        loss.backward()
+        backward_scaled(loss, self.opt)
         for buf, leaf in zip(self.douts, leaves):
             buf.copy_(leaf.grad)
         return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)

@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-enum { CSTS_F32 = 0, CSTS_BF16 = 1 };
+enum { CSTS_F32 = 0, CSTS_BF16 = 1, CSTS_HALF = 1 };   /* CSTS_HALF: the 16-bit type of the build (see csts_half_kind) */
 enum { CSTS_GEMM_NT = 0, CSTS_GEMM_NN = 1, CSTS_GEMM_TN = 2 };
 enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
@@ -38,6 +38,7 @@ enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 #define CSTS_ABI_VERSION 3
 const char* csts_last_error(void);
 int csts_abi_version(void);
+int csts_half_kind(void);   /* the 16-bit type behind CSTS_BF16 in THIS library: 0 bfloat16 (libcsts_hip.so), 1 IEEE half (libcsts_hip_f16.so) */
 
 /* ---- GEMM: nn.Linear (attention.py:88-89,130,159; common.py:20-33; custom_multimodal_builder.py:223-224),
  *      the (1,8,8) fusion Conv3d as a skinny GEMM (custom_multimodal_builder.py:227-229) and the patch-embed
@@ -307,9 +308,16 @@ typedef struct {
   const int32_t* chunk_tensor; const int64_t* chunk_off; int nchunks; int chunk_elems;
   const csts_opt_tensor* tensors; const void* const* grads; int ntensors;
   float* partial;              /* fp32[nchunks] workspace */
-  float* state;                /* fp32[3] */
+  float* state;                /* fp32[4]: step count, total gradient norm, clip coefficient (x 1 / loss scale), skipped (0 / 1) */
   const float* lr;
   float beta1, beta2, eps, max_grad_norm;   /* max_grad_norm <= 0: no clipping */
+  int grad_dt;                 /* dtype of EVERY gradient: CSTS_F32, or CSTS_BF16 = the library's 16-bit type (data-parallel buckets that
+                                * travelled in 16 bits: read once, accumulated in fp32 here) */
+  /* optional dynamic loss scaling, torch.cuda.amp.GradScaler (tools/train_avgaze_net.py:99-109,277): scaler = fp32[2] device
+   * {scale, growth tracker}.  Gradients are the gradients of scale * loss: the norm / clip / update use g / scale
+   * (scaler.unscale_); a non-finite norm SKIPS the step (no parameter, moment or step-count change; state[3] = 1) and multiplies
+   * the scale by backoff; growth_interval consecutive good steps multiply it by growth (scaler.update()). */
+  float* scaler; float growth, backoff; int growth_interval;
 } csts_opt_args;
 int csts_adamw_step(const csts_opt_args* args, hipStream_t stream);
 

@@ -4,6 +4,7 @@ logic over a 2-process gloo group."""
 import json
 import os
 import re
+import subprocess
 import sys
 
 import numpy as np
@@ -27,6 +28,21 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), name
     assert handle.csts_last_error() is not None
+    assert handle.csts_half_kind() == 0 and lib.half_dtype() == torch.bfloat16
+    m = re.search(r"#define CSTS_ABI_VERSION (\d+)", hdr)
+    assert m and int(m.group(1)) == lib.ABI_VERSION           # the binding mirrors THIS header's struct layouts
+    with pytest.raises(lib.CstsError):                        # one 16-bit kernel library per process
+        lib.set_half("fp16")
+
+
+def test_fp16_library_exports_every_declared_symbol_in_a_fresh_process():
+    """libcsts_hip_f16.so (the same sources with IEEE half as the 16-bit type, CSTS_AMD.COMPUTE fp16) loads, exports every
+    declared symbol and reports its kind; selected per process (CSTS_HALF / lib.set_half)."""
+    code = ("import torch; from csts_amd import lib; lib.set_half('fp16'); h = lib.load(); "
+            "assert h.csts_half_kind() == 1 and h.csts_abi_version() == lib.ABI_VERSION and lib.half_dtype() == torch.float16; "
+            "assert all(hasattr(h, n) for n in lib.SYMBOLS); print('ok', len(lib.SYMBOLS))")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith("ok"), p.stderr[-2000:]
 
 
 def test_bad_call_is_rejected_with_message_and_no_gpu_needed():

@@ -22,10 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 4
 
 
-def _run_net(out_dir, extra=()):
+def _run_net(out_dir, extra=(), mp=("TRAIN.MIXED_PRECISION", "True")):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "run_net.py"), "--cfg", os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
            "NUM_GPUS", "1", "TRAIN.BATCH_SIZE", "4", "MODEL.LOSS_FUNC", "kldiv+egonce", "MODEL.LOSS_ALPHA", "0.05",
-           "TRAIN.MIXED_PRECISION", "True", "CSTS_AMD.STEPS_PER_EPOCH", str(STEPS), "CSTS_AMD.SAVE_CHECKPOINTS", "True",
+           *mp, "CSTS_AMD.STEPS_PER_EPOCH", str(STEPS), "CSTS_AMD.SAVE_CHECKPOINTS", "True",
            "TRAIN.CHECKPOINT_PERIOD", "1", "TRAIN.EVAL_PERIOD", "1", "CSTS_AMD.EPOCHS_THIS_RUN", "1", "LOG_PERIOD", "1",
            "OUTPUT_DIR", str(out_dir)] + list(extra)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
@@ -95,4 +95,28 @@ def test_run_net_train_checkpoint_resume_eval(tmp_path):
     assert sd2["epoch"] == 1 and float(sd2["optimizer_state"]["state"][0]["step"]) == 2 * STEPS
     assert not torch.equal(sd2["model_state"]["blocks.3.mlp.fc1.weight"], first_w)      # training continued from the checkpoint
     for f in os.listdir(os.path.join(str(tmp_path), "checkpoints")):                    # 2.3 GB each
+        os.remove(os.path.join(str(tmp_path), "checkpoints", f))
+
+
+def test_run_net_fp16_checkpoint_carries_scaler_state(tmp_path):
+    """CSTS_AMD.COMPUTE fp16 through the entry point: the loss scale is logged, the checkpoint holds "scaler_state" in
+    torch.cuda.amp.GradScaler's layout (slowfast/utils/checkpoint.py:133-134), and the resumed run starts from it."""
+    fp16 = ("TRAIN.MIXED_PRECISION", "True", "CSTS_AMD.COMPUTE", "fp16")
+    recs, err = _run_net(tmp_path, ["TEST.ENABLE", "False"], mp=fp16)
+    assert "fp16 autocast + GradScaler arithmetic" in err
+    iters = _of(recs, "train_iter")
+    assert len(iters) == STEPS and all(np.isfinite(r["loss"]) and r["loss_scale"] >= 1024.0 for r in iters)
+    path = os.path.join(str(tmp_path), "checkpoints", "checkpoint_epoch_00001.pyth")
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sc = sd["scaler_state"]
+    assert set(sc) >= {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    assert sc["scale"] == iters[-1]["loss_scale"] or sc["scale"] in (0.5 * iters[-1]["loss_scale"], 2.0 * iters[-1]["loss_scale"])
+    assert sc["growth_factor"] == 2.0 and sc["backoff_factor"] == 0.5 and sc["growth_interval"] == 2000
+    del sd
+    recs2, _ = _run_net(tmp_path, ["TEST.ENABLE", "False"], mp=fp16)
+    st = _of(recs2, "train_start")[0]
+    assert st["resumed"] is True and st["start_epoch"] == 2
+    it2 = _of(recs2, "train_iter")
+    assert it2[0]["loss_scale"] == sc["scale"] and all(np.isfinite(r["loss"]) for r in it2)
+    for f in os.listdir(os.path.join(str(tmp_path), "checkpoints")):
         os.remove(os.path.join(str(tmp_path), "checkpoints", f))
