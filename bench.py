@@ -67,6 +67,8 @@ def parse():
                    help="run the N>1 code path (RCCL process group, graph chain + eager collectives) with ONE rank")
     p.add_argument("--trunk-cut", type=int, default=None,
                    help="data-parallel graph chain: second autograd cut in front of this video block (default CSTS_AMD.TRUNK_CUT = 3; 0 = off)")
+    p.add_argument("--bucket-dtype", default=None, choices=["fp32", "bf16", "fp16"],
+                   help="data-parallel gradient buckets: fp32 (default) or the 16-bit type of the compute mode (half the xGMI bytes)")
     p.add_argument("--eager-dist", action="store_true",
                    help="N>1: the eager step with hook-driven gradient buckets (GradAllReduce) instead of the graph chain")
     p.add_argument("--no-graph", action="store_true", help="do not capture anything into HIP graphs")
@@ -549,6 +551,8 @@ def main():
             "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute]
     if args.trunk_cut is not None:
         opts += ["CSTS_AMD.TRUNK_CUT", args.trunk_cut]
+    if args.bucket_dtype is not None:
+        opts += ["CSTS_AMD.GRAD_BUCKET_DTYPE", args.bucket_dtype]
     if args.one_stream:
         opts += ["CSTS_AMD.TWO_STREAMS", False]
     if S != 256:
@@ -823,6 +827,7 @@ def main():
                        "mode": args.mode, "global_batch": b * world, "frames": args.frames, "crop": S, "parallelism": f"dp{world}",
                        "step": step_kind, "hip_graph": step_kind != "eager", "rccl_ranks": rccl_ranks,
                        **({"trunk_cut": int(graphed.trunk_cut)} if hasattr(graphed, "trunk_cut") else {}),
+                       **({"grad_bucket_dtype": ("16-bit" if graphed.bucket16 else "fp32")} if hasattr(graphed, "bucket16") else {}),
                        "dist_backend": (torch.distributed.get_backend() if dist_path else None),
                        "note": ("256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)" if S == 256 else
                                 "EXTENSION, parity unpinned: 224^2 with (1,7,7) fusion kernels (CSTS_AMD.FUSION_KERNEL_FROM_GRID); "

@@ -112,6 +112,7 @@ def get_cfg() -> CfgNode:
                        EPOCHS_THIS_RUN=0,            # > 0: stop this invocation after that many epochs (pre-emption; the next one auto-resumes)
                        EVAL_STEPS=2,                 # synthetic validation iterations of the periodic eval pass (TRAIN.EVAL_PERIOD)
                        GRAD_BUCKET_MB=64,
+                       GRAD_BUCKET_DTYPE="fp32",     # "bf16" / "fp16": data-parallel gradient buckets travel in the library's 16-bit type (half the xGMI bytes), fp32 accumulation in the optimizer
                        TRUNK_CUT=3,                  # data-parallel graph chain: second autograd cut in front of this video block (0 = trunks in one piece)
                        TWO_STREAMS=True,             # audio trunk on a second HIP stream, concurrent with the video trunk
                        SAVE_CHECKPOINTS=False,       # write checkpoints/checkpoint_epoch_XXXXX.pyth (reference wire format) every CHECKPOINT_PERIOD

@@ -407,6 +407,18 @@ __global__ __launch_bounds__(256) void axpby_kernel(const void* __restrict__ a, 
     st_from_f32(out, o_dt, i, v);
   }
 }
+// the same, 8 elements per thread (n % 8 == 0, 16-byte aligned operands): the 16-bit gradient buckets cast 188 M elements per step
+__global__ __launch_bounds__(256) void axpby8_kernel(const void* __restrict__ a, int a_dt, const void* __restrict__ b, int b_dt,
+                                                     void* __restrict__ out, int o_dt, int64_t total8, float alpha, float beta) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8], w[8];
+    ld8_as_f32(a, a_dt, i * 8, v);
+    if (b) ld8_as_f32(b, b_dt, i * 8, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = b ? alpha * v[j] + beta * w[j] : alpha * v[j];
+    st8_from_f32(out, o_dt, i * 8, v);
+  }
+}
 // out = a + b in fp32 and, optionally, its bf16 copy (gradient of a residual-stream tensor with two consumers); 4 per thread
 // copy_scale (optional): the bf16 copy (only the copy) is multiplied by copy_scale[i / elems_per_scale] -- the per-sample
 // drop-path scale of the branch that consumes this gradient next (see csts_layernorm_bwd_ex); elems_per_scale % 4 == 0
@@ -861,6 +873,9 @@ extern "C" int csts_token_mean_bwd(const float* dout, float* dx, int64_t B, int 
 extern "C" int csts_axpby(const void* a, int a_dt, const void* b, int b_dt, void* out, int out_dt, int64_t n, float alpha,
                           float beta, hipStream_t stream) {
   CSTS_REQUIRE(a && out && n > 0, "bad args");
+  if (n % 8 == 0 && aligned16(a) && aligned16(out) && (b == nullptr || aligned16(b)))
+    hipLaunchKernelGGL(axpby8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, a, a_dt, b, b_dt, out, out_dt, n / 8, alpha, beta);
+  else
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, a_dt, b, b_dt, out, out_dt, n, alpha, beta);
   CSTS_LAUNCH_CHECK();
   return 0;

@@ -1717,6 +1717,17 @@ def cast(x: torch.Tensor, dt: int) -> torch.Tensor:
     return out
 
 
+def cast_into(dst: torch.Tensor, src: torch.Tensor, scale: float = 1.0):
+    """dst = scale * src across dtypes (flat gradient buckets: fp32 -> the 16-bit type before the all-reduce).  GPU: one
+    vectorised csts_axpby launch; CPU tensors (the gloo tests of the bucket logic): torch."""
+    assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    if not dst.is_cuda:
+        dst.copy_(src if scale == 1.0 else src * scale)
+        return dst
+    L.check(_lib().csts_axpby(_p(src), _dt(src), None, 0, _p(dst), _dt(dst), src.numel(), float(scale), 0.0, _stream()), "csts_axpby(cast)")
+    return dst
+
+
 def reweight(x, w, T, HW):
     return ReweightFn.apply(x, w, T, HW)
 

@@ -54,6 +54,8 @@ class FusedAdamW:
         self.scaler_t = torch.tensor([float(init_scale), 0.0], dtype=torch.float32, device=self.device) if loss_scaling else None
         self.scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
         self.grad_dt = L.F32          # L.BF16: every gradient handed to step() is in the library's 16-bit type (16-bit buckets)
+        self._ext_grads = None        # index -> tensor: gradients read from there instead of p.grad (torch refuses a .grad whose
+                                      # dtype differs from the parameter's, so 16-bit bucket views cannot be p.grad)
         # tables
         wd_of = {id(p): float(g["weight_decay"]) for g in self.param_groups for p in g["params"]}
         tt = (L.OptTensor * len(params))()
@@ -105,11 +107,21 @@ class FusedAdamW:
         """Total L2 gradient norm of the last step (device scalar; what clip_grad_norm_ returns)."""
         return self.state_t[1]
 
+    def set_external_grads(self, grads_by_param=None, grad_dt=None):
+        """grads_by_param: {id(param): tensor} -- step() reads these instead of p.grad (data-parallel buckets in 16 bits);
+        None restores p.grad.  grad_dt: L.F32 | L.BF16 (the library's 16-bit type) of EVERY gradient."""
+        if grads_by_param is None:
+            self._ext_grads, self.grad_dt = None, L.F32
+            return
+        self._ext_grads = {i: grads_by_param[id(p)] for i, p in enumerate(self.params) if id(p) in grads_by_param}
+        if grad_dt is not None:
+            self.grad_dt = grad_dt
+
     @torch.no_grad()
     def step(self):
         ptrs = []
         for i, p in enumerate(self.params):
-            g = p.grad
+            g = p.grad if self._ext_grads is None else self._ext_grads.get(i)
             if g is None:
                 ptrs.append(0)
                 continue

@@ -362,10 +362,28 @@ class SegmentedTrainStep:
         # gradient buckets in the order their backward segments finish
         self.buckets = [self.head_params, self.trunk_params] + ([self.early_params] if trunk_cut else [])
         self._avg = None
+        # CSTS_AMD.GRAD_BUCKET_DTYPE: "fp32" (default) or "bf16" / "fp16" / "half" = the 16-bit type of the kernel library: the
+        # buckets travel over xGMI in 16 bits (376 MB instead of 753 MB per step) and the optimizer kernels read them as they
+        # arrive, accumulating in fp32 (csts_opt_args.grad_dt).  Gradients are still PRODUCED in fp32 (weight gradients
+        # accumulate over up to 262 k tokens); one cast per bucket sits at the end of its backward graph.
+        self.bucket16 = str(getattr(getattr(cfg, "CSTS_AMD", None), "GRAD_BUCKET_DTYPE", "fp32")).lower() in ("bf16", "fp16", "half")
         if self.dist:
             import torch.distributed as dist
             self._avg = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else None
             self.flat = [self._flat_for(ps) for ps in self.buckets]
+            if self.bucket16:
+                from . import lib as L
+                self.flat16 = []
+                for (f32, _), ps in zip(self.flat, self.buckets):
+                    f16 = torch.zeros(f32.numel(), dtype=L.half_dtype(), device=f32.device)
+                    o, views = 0, []
+                    for p in ps:
+                        views.append(f16[o:o + p.numel()].view_as(p))
+                        o += (p.numel() + 3) // 4 * 4
+                    self.flat16.append((f16, views))
+                if hasattr(optimizer, "set_external_grads"):     # FusedAdamW reads the 16-bit buckets directly (fp32 accumulation)
+                    optimizer.set_external_grads({id(p): v for (_, views), ps in zip(self.flat16, self.buckets)
+                                                  for p, v in zip(ps, views)}, L.BF16)
         self.events = None
         self.graphs = {}
         if not use_graphs:
@@ -418,7 +436,7 @@ class SegmentedTrainStep:
 
     def _all_reduce(self, k):
         import torch.distributed as dist
-        flat = self.flat[k][0]
+        flat = (self.flat16 if self.bucket16 else self.flat)[k][0]
         if self._avg is not None:
             return dist.all_reduce(flat, op=self._avg, async_op=True)
         flat /= dist.get_world_size()
@@ -476,6 +494,9 @@ class SegmentedTrainStep:
                 src.append(p.grad)
         if dst:
             torch._foreach_copy_(dst, src)
+        if self.bucket16:           # the bucket leaves in 16 bits: one cast at the end of this backward segment
+            from . import ops
+            ops.cast_into(self.flat16[k][0], self.flat[k][0])
 
     def _chain_body(self, capture):
         core, cfg = self.core, self.cfg
@@ -556,12 +577,26 @@ class SegmentedTrainStep:
             for w in works:
                 w.wait()
             self._raw_grads = [p.grad for ps in self.buckets for p in ps]   # graph-owned: keep them alive
+            self._bucket16_back()
             for k, ps in enumerate(self.buckets):
                 for p, v in zip(ps, self.flat[k][1]):
                     p.grad = v
         self._segment("opt", lambda: _clip_and_step(cfg, self.model, self.opt), capture)
         del cut, cut2
         return res
+
+    def _bucket16_back(self):
+        """16-bit buckets with an optimizer that reads p.grad (stock torch optimizers; the gloo CPU tests): the averaged 16-bit
+        values go back into the fp32 bucket views.  FusedAdamW reads the 16-bit buckets itself (set_external_grads): p.grad then
+        keeps this rank's LOCAL fp32 gradients and averaged_grads() returns what the optimizer consumes."""
+        if self.dist and self.bucket16 and not hasattr(self.opt, "set_external_grads"):
+            for k in range(len(self.buckets)):
+                self.flat[k][0].copy_(self.flat16[k][0])
+
+    def averaged_grads(self):
+        """{parameter: the averaged gradient tensor the optimizer reads} of the last step (views of the buckets)."""
+        src = self.flat16 if (self.bucket16 and hasattr(self.opt, "set_external_grads")) else self.flat
+        return {p: v for (_, views), ps in zip(src, self.buckets) for p, v in zip(ps, views)}
 
     def _from_early(self, t, cut2):
         """Is head-boundary tensor t produced in front of the inner cut (the features tapped off the early stages)?  Its
@@ -611,6 +646,7 @@ class SegmentedTrainStep:
                 works.append(self._all_reduce(2))
         for w in works:
             w.wait()
+        self._bucket16_back()
         mark(4)
         self.graphs["opt"].replay()
         mark(5)

@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, trunk_cut, compute, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6]
+    bucket_dtype = sys.argv[7] if len(sys.argv) > 7 else "fp32"
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -34,7 +35,7 @@ def main():
 
     cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
                     ["NUM_GPUS", 1, "MODEL.LOSS_FUNC", "kldiv+egonce", "DATA.NUM_FRAMES", 8, "CSTS_AMD.COMPUTE", compute,
-                     "CSTS_AMD.TRUNK_CUT", trunk_cut])
+                     "CSTS_AMD.TRUNK_CUT", trunk_cut, "CSTS_AMD.GRAD_BUCKET_DTYPE", bucket_dtype])
     core = build_model(cfg)
     core.load_state_dict(O.seeded_params(8, 256), strict=True)
     core.eval()                                        # drop-path off: the fixture is an eval-mode forward + backward
@@ -53,13 +54,16 @@ def main():
     res = {"loss": float(loss), "kld": float(kld), "nce": float(nce), "n_buckets": len(step.flat)}
     ptrs = [(f.data_ptr(), f.data_ptr() + f.numel() * 4) for f, _ in step.flat]
     names, norms, total = [], [], 0.0
+    avg = step.averaged_grads()        # what the optimizer graph reads: views of the fp32 buckets (= p.grad) or of the 16-bit ones
+    res["bucket_dtype"] = str(next(iter(avg.values())).dtype)
     for n, p in core.named_parameters():
         assert p.grad is not None and any(lo <= p.grad.data_ptr() < hi for lo, hi in ptrs), n      # views of the flat buckets
-        g = p.grad.double()
+        assert bucket_dtype != "fp32" or avg[p].data_ptr() == p.grad.data_ptr()
+        g = avg[p].double()
         names.append(n)
         norms.append(float(g.norm()))
         total += float((g * g).sum())
-        res["g__" + n] = p.grad.flatten()[:64].float().cpu().numpy()
+        res["g__" + n] = avg[p].flatten()[:64].float().cpu().numpy()
     res["grad_names"] = np.array(names)
     res["grad_norms"] = np.array(norms)
     res["grad_total_norm"] = total ** 0.5

@@ -361,7 +361,7 @@ def _toy_loss(gathered_fn):
     return loss_fn
 
 
-def _dist_worker_segmented(rank, world, port, q, trunk_cut=0):
+def _dist_worker_segmented(rank, world, port, q, trunk_cut=0, bucket_dtype="fp32"):
     """csts_amd.train.SegmentedTrainStep (the data-parallel step: forward | eager losses + embedding all-gather | backward
     head | all-reduce(head bucket) | backward trunk | all-reduce(trunk bucket) | optimizer) run WITHOUT graphs on 2 gloo
     ranks: the gradients the optimizer sees must equal those of ONE process on the concatenated batch, p.grad must be
@@ -374,21 +374,22 @@ def _dist_worker_segmented(rank, world, port, q, trunk_cut=0):
         from csts_amd import distributed as du
         from csts_amd import train as T
         from csts_amd.config import load_yaml
-        cfg = load_yaml(YAML, ["NUM_GPUS", 0, "MODEL.LOSS_FUNC", "kldiv+egonce", "SOLVER.CLIP_GRAD_L2NORM", None])
+        cfg = load_yaml(YAML, ["NUM_GPUS", 0, "MODEL.LOSS_FUNC", "kldiv+egonce", "SOLVER.CLIP_GRAD_L2NORM", None,
+                               "CSTS_AMD.GRAD_BUCKET_DTYPE", bucket_dtype])
         torch.manual_seed(7)
         net = _ToySegModel()
         g = torch.Generator().manual_seed(123)
-        full = {"video": torch.randn(4, 3, 6, generator=g), "audio": torch.randn(4, 3, 6, generator=g),
-                "labels_hm": torch.randn(4, 3, 5, generator=g)}
+        nb = 2 * world
+        full = {"video": torch.randn(nb, 3, 6, generator=g), "audio": torch.randn(nb, 3, 6, generator=g),
+                "labels_hm": torch.randn(nb, 3, 5, generator=g)}
         mine = {k: v[2 * rank:2 * rank + 2] for k, v in full.items()}
         # single-process reference on the concatenated batch (mean over the global batch = mean of the per-rank means)
         import copy
         ref = copy.deepcopy(net)
         out = ref([full["video"]], full["audio"], return_embed=True)
-        l0 = (out[0][:2] - full["labels_hm"][:2]).pow(2).mean()
-        l1 = (out[0][2:] - full["labels_hm"][2:]).pow(2).mean()
+        lr_ = [(out[0][2 * r:2 * r + 2] - full["labels_hm"][2 * r:2 * r + 2]).pow(2).mean() for r in range(world)]
         loss_ref, _, nce_ref = _toy_loss(lambda ts: ts)([out[0], out[1], out[2]], {"labels_hm": full["labels_hm"]})
-        ((l0 + l1) / 2 + 0.05 * nce_ref).backward()
+        (sum(lr_) / world + 0.05 * nce_ref).backward()
         wrapped = du.GradAllReduce(net, bucket_mb=1)
         opt = torch.optim.SGD(net.parameters(), lr=0.1)
         seg = T.SegmentedTrainStep(cfg, wrapped, opt, mine, use_graphs=False, loss_fn=_toy_loss(du.all_gather_with_grad),
@@ -399,13 +400,18 @@ def _dist_worker_segmented(rank, world, port, q, trunk_cut=0):
         ok_hooks = not wrapped.hooks_enabled
         flat_rng = [(f.data_ptr(), f.data_ptr() + 4 * f.numel()) for f, _ in seg.flat]
         ok_view = all(any(lo <= p.grad.data_ptr() < hi for lo, hi in flat_rng) for p in net.parameters())
-        ok_grad = all(torch.allclose(p.grad, r.grad, atol=1e-6) for p, r in zip(net.parameters(), ref.parameters()))
+        if bucket_dtype == "fp32":
+            close = lambda x, y: torch.allclose(x, y, atol=1e-6)
+        else:       # buckets travelled in bf16: equal to bf16 rounding (two roundings: the cast and the sum over ranks)
+            assert seg.bucket16 and seg.flat16[0][0].dtype == torch.bfloat16
+            close = lambda x, y: bool(((x - y).abs() <= 2.0 ** -6 * y.abs() + 2.0 ** -8 * y.abs().max() + 1e-7).all())
+        ok_grad = all(close(p.grad, r.grad) for p, r in zip(net.parameters(), ref.parameters()))
         ok_nce = abs(float(nce) - float(nce_ref)) < 1e-5          # every rank sees the global similarity matrix
-        ok_step = all(torch.allclose(p, b - 0.1 * r.grad, atol=1e-6) for p, b, r in zip(net.parameters(), before, ref.parameters()))
+        ok_step = all(close((b - p) / 0.1, r.grad) for p, b, r in zip(net.parameters(), before, ref.parameters()))
         flatw = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
         both = [torch.empty_like(flatw) for _ in range(world)]
         dist.all_gather(both, flatw)
-        ok_same = torch.equal(both[0], both[1])
+        ok_same = all(torch.equal(both[0], b_) for b_ in both[1:])
         q.put((rank, ok_hooks, ok_view, ok_grad, ok_nce, ok_step, ok_same))
     except Exception as e:
         import traceback
@@ -431,6 +437,29 @@ def test_two_rank_gloo_segmented_data_parallel_step(trunk_cut):
     for r in res:
         assert r[1], ("hook-driven buckets must be off", r)
         assert r[2], "p.grad must be views of the flat buckets"
+        assert r[3], ("averaged gradients != single-process gradients on the concatenated batch", r[6])
+        assert r[4], "EgoNCE over the gathered embeddings"
+        assert r[5] and r[6] is True, ("optimizer step / replicas diverged", r)
+
+
+@pytest.mark.parametrize("bucket_dtype", ["fp32", "bf16"])
+def test_four_rank_gloo_segmented_step_and_16bit_buckets(bucket_dtype):
+    """W = 4: every rank takes ITS OWN rows of the gathered EgoNCE embeddings' gradient, the averaged
+    bucket gradients equal ONE process on the concatenated batch of 8 -- exactly with fp32 buckets, to bf16 rounding with
+    CSTS_AMD.GRAD_BUCKET_DTYPE bf16 (the buckets travel in 16 bits, half the xGMI bytes) -- and the replicas stay identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + (os.getpid() % 2000) + (700 if bucket_dtype == "bf16" else 0)
+    procs = [ctx.Process(target=_dist_worker_segmented, args=(r, 4, port, q, 1, bucket_dtype)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1, 2, 3]
+    for r in res:
+        assert r[1] and r[2], r
         assert r[3], ("averaged gradients != single-process gradients on the concatenated batch", r[6])
         assert r[4], "EgoNCE over the gathered embeddings"
         assert r[5] and r[6] is True, ("optimizer step / replicas diverged", r)

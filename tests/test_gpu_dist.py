@@ -30,11 +30,11 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run_ranks(tmp_path, trunk_cut, compute, world=2, timeout=900):
+def _run_ranks(tmp_path, trunk_cut, compute, world=2, timeout=900, bucket_dtype="fp32"):
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, str(trunk_cut), compute, outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, str(trunk_cut), compute, outs[r], bucket_dtype],
                               env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     try:
@@ -101,6 +101,27 @@ def test_two_process_graph_chain_bf16_mode(tmp_path):
             assert abs(norm_of[n] - ref_norm) <= 4e-2 * ref_norm, (n, norm_of[n], ref_norm)
     tot, ref_tot = float(r0["grad_total_norm"]), float(g["grad_total_norm"])
     assert abs(tot - ref_tot) < 1e-2 * ref_tot
+    for k in ("param_sum", "param_abs_sum", "param_heads"):
+        assert np.array_equal(r0[k], r1[k]), k
+
+
+def test_two_process_graph_chain_16bit_buckets(tmp_path):
+    """CSTS_AMD.GRAD_BUCKET_DTYPE bf16 through the real chain: the buckets leave each backward graph in 16 bits (half the xGMI
+    bytes), are averaged in 16 bits and read by the optimizer kernels directly (fp32 accumulation, csts_opt_args.grad_dt).  The
+    averaged gradients equal the reference's B = 2 gradients to the bf16-mode bars, the clip kernel sees the same norm, the
+    replicas stay bit-identical."""
+    g = np.load(os.path.join(GOLDEN, "model_T8_B2.npz"), allow_pickle=False)
+    r0, r1 = _run_ranks(tmp_path, 3, "bf16", bucket_dtype="bf16")
+    assert str(r0["bucket_dtype"]) == "torch.bfloat16"
+    assert np.array_equal(r0["grad_norms"], r1["grad_norms"])
+    norm_of = dict(zip([str(n) for n in r0["grad_names"]], r0["grad_norms"]))
+    for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if n != "classifier.bias":
+            assert abs(norm_of[n] - ref_norm) <= 4e-2 * ref_norm, (n, norm_of[n], ref_norm)
+    tot, ref_tot = float(r0["grad_total_norm"]), float(g["grad_total_norm"])
+    assert abs(tot - ref_tot) < 1e-2 * ref_tot
+    assert abs(float(r0["clip_norm_seen"]) - ref_tot) < 1e-2 * ref_tot
+    assert float(r0["weights_moved_by_lr0"]) == 0.0
     for k in ("param_sum", "param_abs_sum", "param_heads"):
         assert np.array_equal(r0[k], r1[k]), k
 
