@@ -551,6 +551,10 @@ def main():
             "DATA.NUM_FRAMES", args.frames, "CSTS_AMD.COMPUTE", args.compute]
     if args.trunk_cut is not None:
         opts += ["CSTS_AMD.TRUNK_CUT", args.trunk_cut]
+    if args.bucket_dtype is None and args.compute != "fp32":
+        # 16-bit compute modes: the gradient buckets travel in the same 16-bit type (half the xGMI bytes; the optimizer kernels
+        # accumulate in fp32) -- stated in config.grad_bucket_dtype; --bucket-dtype fp32 restores the reference's fp32 all-reduce
+        args.bucket_dtype = args.compute
     if args.bucket_dtype is not None:
         opts += ["CSTS_AMD.GRAD_BUCKET_DTYPE", args.bucket_dtype]
     if args.one_stream:
