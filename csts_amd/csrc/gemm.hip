@@ -1153,6 +1153,10 @@ bool pick4(const csts_gemm_args* a, int split, int* variant) {
     // short K, many row tiles, whole tiles: the wave-specialised form (4 producer waves; gemm4.hip) -- OFF by default:
     // -4 .. -11 % on six of ten isolated cases, but +0.18 ms per step inside the two-stream step (one 12-wave workgroup per
     // CU), profiles/r3_shortk_gemm_stamps.txt.  CSTS_GEMM4_SPLIT=1 switches it on for A/B runs.
+    // experiment (CSTS_GEMM4_SHORTK=64): K <= 192 on a 4-stage ring -- every k-tile of the NEXT tile is requested before this
+    // tile's epilogue stores, and the store-aware waits (gemm4.hip kstep) then never drain a store
+    static const int shortk = [] { const char* e = getenv("CSTS_GEMM4_SHORTK"); return e ? atoi(e) : 0; }();
+    if (shortk == 64 && a->K <= 192 && a->M >= 32768) { *variant = 64; return true; }
     static const bool split_on = [] { const char* e = getenv("CSTS_GEMM4_SPLIT"); return e && e[0] == '1'; }();
     if (split_on && a->K <= 192 && a->M % 128 == 0 && a->M >= 32768 && a->row_scale == nullptr) *variant = 83;
     return true;

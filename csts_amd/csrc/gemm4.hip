@@ -61,6 +61,7 @@ template <int WM, int MT, int NT, int S, int FORM, int NP = 0>
 __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, NP>::WPS)) void gemm4_kernel(Params p) {
   typedef G4<WM, MT, NT, S, NP> G;
   constexpr bool KTAIL = false;        // K % 64 != 0 is not instantiated (the library never picks this kernel for it)
+  const bool STORE_AWARE = p.store_aware != 0;     // A/B switch (CSTS_GEMM4_STORE_AWARE=0): wave-uniform
   constexpr int BM = G::BM, BN = G::BN, A_BYTES = G::A_BYTES, STAGE = G::STAGE, NA = G::NA, NB = G::NB, LPT = G::LPT;
   __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE];
 
@@ -178,15 +179,25 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int64_t m0 = (t / p.ntiles_n) * BM + wm * 32 * MT + (lane & 31), n0 = (t % p.ntiles_n) * BN + wn * 32 * NT + 4 * hi;
 
-    auto kstep = [&](auto nks_tag) {
+    auto kstep = [&](auto nks_tag, int kt) {
       constexpr int NKS = decltype(nks_tag)::value;
-      // k-tile cidx has landed once at most `ahead` younger k-tiles (LPT instructions each) are outstanding; epilogue
-      // stores issued meanwhile are younger still, so the count only ever over-waits
+      // k-tile cidx has landed once at most `ahead` younger k-tiles (LPT instructions each) are outstanding -- PLUS, for the
+      // first S - 1 k-tiles of a tile (their loads were issued before the previous tile's epilogue), that epilogue's stores:
+      // vector memory retires in order on one counter, so a count without them drained every store of the previous tile
+      // before the first MFMA of the next one (EPI_ST is exact for the straight-line forms; 0 = over-wait for the generic one)
       if constexpr (NP == 0) {
+        constexpr int EPI_ST = (FORM == 0) ? 0 : MT * NT * (FORM == 2 ? 4 : 2);
+        static_assert(2 * LPT + EPI_ST <= 63, "vmcnt immediate");
         const int ahead = min(S - 2, total_k - 1 - cidx);
-        if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
-        else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
-        else wait_vm<0>();
+        if (EPI_ST > 0 && STORE_AWARE && t != t_first && kt < S - 1) {
+          if (S >= 4 && ahead == 2) wait_vm<2 * LPT + EPI_ST>();
+          else if (S >= 3 && ahead >= 1) wait_vm<LPT + EPI_ST>();
+          else wait_vm<EPI_ST>();
+        } else {
+          if (S >= 4 && ahead == 2) wait_vm<2 * LPT>();
+          else if (S >= 3 && ahead >= 1) wait_vm<LPT>();
+          else wait_vm<0>();
+        }
       }
       G4_STAMP();      // own share landed
       __builtin_amdgcn_s_barrier();                  // every wave's share landed; everyone is done with the previous stage
@@ -232,11 +243,11 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
       if (refill) advance();
       G4_STAMP();      // fragment reads + MFMAs + refill issue of this k-step
     };
-    for (int kt = 0; kt < nk_full; ++kt) kstep(std::integral_constant<int, 4>());
+    for (int kt = 0; kt < nk_full; ++kt) kstep(std::integral_constant<int, 4>(), kt);
     if constexpr (KTAIL) {                                           // K % 64 = 16, 32 or 48 (K % 16 == 0)
-      if (k_tail == 1) kstep(std::integral_constant<int, 1>());
-      else if (k_tail == 2) kstep(std::integral_constant<int, 2>());
-      else if (k_tail == 3) kstep(std::integral_constant<int, 3>());
+      if (k_tail == 1) kstep(std::integral_constant<int, 1>(), nk_full);
+      else if (k_tail == 2) kstep(std::integral_constant<int, 2>(), nk_full);
+      else if (k_tail == 3) kstep(std::integral_constant<int, 3>(), nk_full);
     }
 
     G4_STAMP();        // epilogue begins
@@ -427,7 +438,7 @@ struct Variant { int code, wm, mt, nt, s; };
 // last column: the specialised epilogue forms exist (the variants the library picks by itself)
 #define G4_VARIANTS(X) \
   X(2, 4, 2, 2, 2, false) X(3, 4, 2, 2, 3, false) X(12, 4, 2, 3, 2, false) X(22, 4, 2, 4, 2, false) \
-  X(32, 4, 1, 2, 2, true) X(33, 4, 1, 2, 3, true) X(34, 4, 1, 2, 4, false) X(62, 4, 1, 3, 2, true) X(63, 4, 1, 3, 3, true) X(42, 4, 1, 4, 2, false) \
+  X(32, 4, 1, 2, 2, true) X(33, 4, 1, 2, 3, true) X(34, 4, 1, 2, 4, true) X(62, 4, 1, 3, 2, true) X(63, 4, 1, 3, 3, true) X(64, 4, 1, 3, 4, true) X(42, 4, 1, 4, 2, false) \
   X(52, 2, 2, 2, 2, false)
 
 }  // namespace
@@ -435,6 +446,11 @@ struct Variant { int code, wm, mt, nt, s; };
 // wave-specialised variants (4 producer waves, 3-stage ring, one workgroup per CU): 83 = 128 x 192, 84 = 128 x 128
 bool csts_gemm4_launch(const csts_gemm_params& p0, const csts_gemm_args* a, int variant, int wpc, hipStream_t s) {
   csts_gemm_params p = p0;
+  // OFF by default: measured neutral on the 2-stage ring (21.63 vs 21.63 ms per step, profiles/r4_gemm4_store_aware_ab.txt) and
+  // mixed with the 4-stage short-K ring (CSTS_GEMM4_SHORTK=64: -16 .. -18 % on two shapes, +6 .. +10 % on the DGELU forms, the
+  // largest fc1 + GELU unchanged at 2.96 TB/s) -- the drain of the previous tile's stores is NOT what holds these GEMMs at 3 TB/s
+  static const int store_aware = [] { const char* e = getenv("CSTS_GEMM4_STORE_AWARE"); return (e && e[0] == '1') ? 1 : 0; }();
+  p.store_aware = store_aware;
   p.stamps = (a != nullptr && a->workspace != nullptr && a->ws_bytes >= 8192) ? reinterpret_cast<unsigned long long*>(a->workspace) : nullptr;
   if (variant == 83) return launch4<4, 1, 3, 3, true, 4>(p, 1, s);
   if (variant == 84) return launch4<4, 1, 2, 3, true, 4>(p, 1, s);

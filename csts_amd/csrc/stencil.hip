@@ -197,6 +197,12 @@ constexpr int WPAD = 4;
 // Coalesced global reads, 12 per thread IN FLIGHT before the first LDS store (a plain load -> store loop waits for every
 // load on its own: 11 round trips in a row for a 96-channel table on 256 threads, and this table is the first thing every
 // workgroup of the stencil kernels needs); the (conflicting) transposition is paid in LDS.
+// SPLIT8 (pool_ln_fwd_kernel: a lane owns 8 consecutive channels and reads them as two 16-byte pieces): inside a tap row the
+// FIRST four channels of every 8-channel group are stored next to each other, then all the second fours -- channel 8 i + j sits
+// at 4 i + j (j < 4) or HD / 2 + 4 i + j - 4 -- so that each of the two ds_read_b128 of a tap is one contiguous run over the
+// lanes (the straight layout put consecutive lanes 32 bytes apart: two lanes per bank pair on every read, 3.6 conflict cycles
+// per LDS instruction by SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS).
+template <bool SPLIT8 = false>
 __device__ __forceinline__ void stage_weight_rows(const float* __restrict__ w, float* wl, int HD, int nthr, int tid) {
   const int n = HD * 27;
   // (channel, tap) of element i = tid + u * nthr WITHOUT a division per element (the stencil kernels are bound by VALU
@@ -213,7 +219,7 @@ __device__ __forceinline__ void stage_weight_rows(const float* __restrict__ w, f
     }
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
-      if (base + u * nthr < n) wl[k * (HD + WPAD) + c] = v[u];
+      if (base + u * nthr < n) wl[k * (HD + WPAD) + (SPLIT8 ? ((c & 4) ? (HD >> 1) + ((c >> 3) << 2) + (c & 3) : ((c >> 3) << 2) + (c & 3)) : c)] = v[u];
       k += dr; c += dq;
       if (k >= 27) { k -= 27; ++c; }
     }
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   const Geom& g = rg.g;
   const int HD = g.HD, H = g.C / HD;
   {   // stage both slots' weights (tap-major, one zero row each)
-    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
+    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows<true>(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
     __syncthreads();
   }
   const int lane_in = threadIdx.x % GL;
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
     }
     const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
-    const float* wls = wl + slot * 28 * (HD + WPAD) + c8;
+    const float* wls = wl + slot * 28 * (HD + WPAD) + (c8 >> 1);      // SPLIT8 layout: first fours at 4 i, second fours at HD / 2 + 4 i
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // 9 taps (one temporal slice) in flight at a time: a 128-register budget, FOUR workgroups per CU, so the 1024-workgroup
     // launches of the 384-channel stages are resident at once.  (All 27 taps at once -- one memory round trip per item
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
         for (int kw = 0; kw < 3; ++kw) {
           const int tap = (tvk && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
           const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD)]);
-          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD) + 4]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD) + (HD >> 1)]);
           float v[8];
           raw8_cvt<F32>(raw[kh * 3 + kw], v);
           acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;
