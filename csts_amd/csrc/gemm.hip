@@ -516,6 +516,7 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
   // ---------------- epilogue through LDS, 64 rows (one 32-row MFMA tile of each wave row) at a time
   float* Cs = reinterpret_cast<float*>(smem_raw);
   const bool first_split = (blockIdx.y == 0);
+  const bool RES_LINES = p.res_lines != 0;
   const int col = (tid & 15) * 8;
   const int64_t n = n0 + col;
   float bias[8];
@@ -540,11 +541,49 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
           Cs[((unit & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS_LD + wn * 64 + nt * 32 + (lane & 31)] = acc[mt][nt][r];
     }
     __syncthreads();
-    if (n >= p.N) continue;
     // Residual-stream form (fp32 C = (acc + bias) * row_scale + residual: proj / fc2 forward, skip projections), whole row
     // groups: straight-line code with every load of the group -- the residual runs and the per-row drop-path scales -- issued
-    // BEFORE its first store.  The generic loop below loads, waits and stores row by row: vector memory retires in order, so
-    // the wait for row i + 1's residual is also a wait for row i's stores (one full store round trip per row).
+    // BEFORE its first store (vector memory retires in order: a wait for row i + 1's residual is also a wait for row i's stores).
+    // Round 4: a lane owns ONE 16-byte run and the 32 lanes of a half-wave cover a whole 512-byte tile row, so every load and
+    // store instruction touches whole 128-byte lines.  Before, a lane owned 8 consecutive floats as two float4: each
+    // instruction then touched only the first (or second) 16 bytes of every 32 -- half of every line, twice -- and
+    // tools/traffic_mix.hip measures what that costs with no arithmetic at all: 2.6-3.2 TB/s against 5.1-5.8 TB/s for the same
+    // bytes in whole lines (profiles/r4_traffic_mix.txt).  Same values in the same order: bit-identical.
+    if (p.residual != nullptr && p.res_row_mod == 0 && p.ru_To == 0 && p.epilogue == CSTS_EPI_NONE && p.split_k == 1 &&
+        p.c_dt == CSTS_F32 && p.r_dt == CSTS_F32 && m0 + g * 64 + 64 <= p.M && RES_LINES) {            // block-uniform
+      constexpr int RPP = NTHR / 32;            // rows per pass
+      constexpr int NI = 64 / RPP;
+      const int col4 = (tid & 31) * 4;
+      const int64_t n4 = n0 + col4;
+      if (n4 < p.N) {
+        const float* __restrict__ res = reinterpret_cast<const float*>(p.residual);
+        float* __restrict__ Cf = reinterpret_cast<float*>(p.C);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias != nullptr) b4 = *reinterpret_cast<const float4*>(p.bias + n4);
+        float4 rr[NI];
+        float sc[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int64_t m = m0 + g * 64 + (tid >> 5) + RPP * i;
+          rr[i] = *reinterpret_cast<const float4*>(res + m * p.ldr + n4);
+          sc[i] = p.row_scale != nullptr ? p.row_scale[m / p.rows_per_scale] : 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int row = (tid >> 5) + RPP * i;
+          const int64_t m = m0 + g * 64 + row;
+          const float4 c = *reinterpret_cast<const float4*>(&Cs[row * CS_LD + col4]);
+          float v[4] = {c.x + b4.x, c.y + b4.y, c.z + b4.z, c.w + b4.w};
+          if (p.row_scale != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= sc[i];
+          }
+          *reinterpret_cast<float4*>(Cf + m * p.ldc + n4) = make_float4(v[0] + rr[i].x, v[1] + rr[i].y, v[2] + rr[i].z, v[3] + rr[i].w);
+        }
+      }
+      continue;
+    }
+    if (n >= p.N) continue;
     if (p.residual != nullptr && p.res_row_mod == 0 && p.ru_To == 0 && p.epilogue == CSTS_EPI_NONE && p.split_k == 1 &&
         p.c_dt == CSTS_F32 && p.r_dt == CSTS_F32 && m0 + g * 64 + 64 <= p.M) {            // block-uniform
       constexpr int NI = 1024 / NTHR;
@@ -1286,6 +1325,8 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
   p.rows_per_scale = a->rows_per_scale > 0 ? a->rows_per_scale : 1;
   p.a_dt = a->a_dt; p.b_dt = a->b_dt; p.c_dt = a->c_dt; p.aux_dt = a->aux_dt; p.r_dt = a->r_dt;
   p.epilogue = a->epilogue; p.split_k = split;
+  static const int res_lines = [] { const char* e = getenv("CSTS_GEMM_RES_LINES"); return (e && e[0] == '0') ? 0 : 1; }();
+  p.res_lines = res_lines;
   p.ru_Ti = p.ru_Hi = p.ru_Wi = p.ru_To = p.ru_Ho = p.ru_Wo = p.ru_lw = p.ru_lh = p.ru_lt = 0;
   if (a->res_up[3] > 0) {
     const int Ti = a->res_up[0], Hi = a->res_up[1], Wi = a->res_up[2], To = a->res_up[3], Ho = a->res_up[4], Wo = a->res_up[5];

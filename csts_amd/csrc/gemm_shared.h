@@ -11,6 +11,7 @@ struct csts_gemm_params {
   int a_dt, b_dt, c_dt, aux_dt, r_dt, epilogue, split_k, a_vec, b_vec, ntiles_n;
   int64_t ntiles;   // gemm3 (persistent): output tiles of the whole problem
   unsigned long long* stamps;   // gemm3 built with -DCSTS_GEMM3_STAMPS: cycle stamps of two workgroups (diagnostics)
+  int res_lines;                // gemm2: fp32 residual-stream epilogue in whole 128-byte lines (A/B switch CSTS_GEMM_RES_LINES=0)
   int store_aware;              // gemm4: k-tile waits that leave the previous tile's epilogue stores in flight (see kstep)
   // trilinear-upsampled residual (csts_gemm_args.res_up): coarse / fine grids, log2 of the (power-of-two) fine sizes
   int ru_Ti, ru_Hi, ru_Wi, ru_To, ru_Ho, ru_Wo, ru_lw, ru_lh, ru_lt;
