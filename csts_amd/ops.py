@@ -155,6 +155,11 @@ def reset_deferred():
         for st in _wg_side.values():
             st.synchronize()
         _wg_side_used[0] = False
+    if _sw_used[0]:
+        for st in _sw_side.values():
+            st.synchronize()
+        _sw_used[0] = False
+    _sw_keep.clear()
     _deferred.clear()
     _assign.clear()
     _wgq.clear()
@@ -239,6 +244,7 @@ def flush_deferred():
     _deferred_task[0] = -1
     flush_wgrads()
     _join_wgrad_side()
+    _join_stencil_side()
     if not _deferred:
         _hand_over()
         return
@@ -480,6 +486,40 @@ def flush_wgrads(side: bool = False):
     if side:
         _wg_pending.append((q, keep))      # alive until the final callback has joined the side stream
     del q, keep
+
+
+# Stencil weight gradients (csts_dwconv_wgrad / _wgrad2: 34 launches of ~24 us per step, latency-bound, 0.16 of the HBM roofline)
+# feed nothing but the end-of-backward reduction: with deferred reductions they run on a SIDE stream beside the rest of backward
+# (one side stream per producing stream: the audio trunk's backward has its own) and are joined by the final flush.
+STENCIL_WGRAD_SIDE = os.environ.get("CSTS_STENCIL_WGRAD_SIDE", "0") == "1"     # MEASURED SLOWER (21.3 -> 22.2 ms per step, profiles/r4_stencil_wgrad_side_ab.txt): 34 fork / join pairs inside the captured graph cost more than the overlap returns; off
+_sw_side = {}            # raw id of the producing stream -> side stream
+_sw_used = [False]
+_sw_keep = []            # tensors read / written on a side stream, alive until the join
+
+
+def _stencil_side(*tensors):
+    """Side stream for a stencil weight-gradient launch issued from the current stream, already waiting for everything queued on
+    it so far; `tensors` (operands, workspace) are kept alive and marked as used there."""
+    cur = torch.cuda.current_stream()
+    st = _sw_side.get(cur.cuda_stream)
+    if st is None:
+        st = _sw_side[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
+    st.wait_stream(cur)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(st)
+            _sw_keep.append(t)
+    _sw_used[0] = True
+    return st
+
+
+def _join_stencil_side():
+    if _sw_used[0]:
+        cur = torch.cuda.current_stream()
+        for st in _sw_side.values():
+            cur.wait_stream(st)
+        _sw_used[0] = False
+    _sw_keep.clear()
 
 
 def _join_wgrad_side():
@@ -1144,16 +1184,21 @@ class AttnInnerFn(Function):
             dw = torch.empty(HD * 27, dtype=torch.float32, device=dev)
             defer = _can_defer(pw)
             dwp = None if defer else _p(dw)
-            if transposed:   # fine = dc (output side), coarse = qkv slot
+            side = _stencil_side(dc, qkv, wws) if (defer and STENCIL_WGRAD_SIDE) else None
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                sw = _stream()
+                if transposed:   # fine = dc (output side), coarse = qkv slot
+                    L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(dc), _dt(dc), _p(qkv, slot * Cc), _dt(qkv), dwp, _p(wws),
+                                                  wws.numel(), sw), "csts_dwconv_wgrad")
+                else:            # fine = qkv slot, coarse = dc
+                    L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(dc), _dt(dc), dwp, _p(wws),
+                                                  wws.numel(), sw), "csts_dwconv_wgrad")
+            if transposed:
                 L.check(lib.csts_dwconv_strided(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
                         "csts_dwconv_strided(bwd)")
-                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(dc), _dt(dc), _p(qkv, slot * Cc), _dt(qkv), dwp, _p(wws),
-                                              wws.numel(), s), "csts_dwconv_wgrad")
-            else:            # fine = qkv slot, coarse = dc
+            else:
                 L.check(lib.csts_dwconv_transposed(C.byref(g), _p(dc), _dt(dc), _p(w), _p(dqkv, slot * Cc), _dt(dqkv), s),
                         "csts_dwconv_transposed(bwd)")
-                L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(qkv, slot * Cc), _dt(qkv), _p(dc), _dt(dc), dwp, _p(wws),
-                                              wws.numel(), s), "csts_dwconv_wgrad")
             dwv = dw.view(HD, 1, 3, 3, 3)
             if defer:
                 _defer(wws, dw, wsz // (HD * 27 * 4), HD * 27)
@@ -1186,8 +1231,10 @@ class AttnInnerFn(Function):
             wws = _ws(2 * wsz, dev)
             dw = torch.empty(2, HD * 27, dtype=torch.float32, device=dev)
             dwp = vp2(None, None) if defer else vp2(_p(dw[0]), _p(dw[1]))
-            L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(kv_fine, kv_off[0]), _p(kv_fine, kv_off[1])), _dt(kv_fine),
-                                           vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), dwp, _p(wws), wws.numel(), s), "csts_dwconv_wgrad2")
+            side = _stencil_side(dc2, kv_fine, wws) if (defer and STENCIL_WGRAD_SIDE) else None
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(kv_fine, kv_off[0]), _p(kv_fine, kv_off[1])), _dt(kv_fine),
+                                               vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), dwp, _p(wws), wws.numel(), _stream()), "csts_dwconv_wgrad2")
             if defer:
                 nrow = wsz // (HD * 27 * 4)
                 _defer(wws[:wsz], dw[0], nrow, HD * 27)
