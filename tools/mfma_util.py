@@ -81,6 +81,42 @@ def main():
         fl, by = alg.get(k, (0.0, 0.0))
         print(f"{k} | {n1:.0f} | {ms:.3f} | {busy:.3f} | {busy_sq:.3f} | {w('SQ_WAIT_INST_ANY'):.3f} | {w('SQ_WAIT_INST_LDS'):.3f} | {w('SQ_WAIT_ANY'):.3f} | "
               f"{lds_conf:.3f} | {hbm:.3f} | {by / 1e9 if by else float('nan'):.3f} | {fl / ms / 1e9 if fl else float('nan'):.1f} | {hbm / ms * 1e3:.0f}")
+    # ---- kernel FAMILIES against the algorithmic work of the C-ABI entries that launch them (bench.json: roofline.per_entry,
+    # tools/work_model.py: every operand once): the roofline fraction of every family can be recomputed from these columns
+    bj = os.path.join(os.path.dirname(order_path), "bench.json")
+    per_entry = {}
+    if os.path.exists(bj):
+        try:
+            per_entry = json.load(open(bj)).get("roofline", {}).get("per_entry", {})
+        except Exception:
+            per_entry = {}
+    FAM = [("LayerNorm forward", r"^ln_fwd", ["layernorm_fwd", "layernorm_fwd_add"]),
+           ("LayerNorm backward", r"^ln_bwd", ["layernorm_bwd_ex", "layernorm_bwd", "layernorm_bwd2"]),
+           ("conv-pool + LN(hd) forward", r"^pool_ln_fwd", ["pool_ln_fwd"]),
+           ("stencil weight gradients", r"^dwconv_wgrad", ["dwconv_wgrad", "dwconv_wgrad2"]),
+           ("transposed / strided stencils", r"^dwconv_(transposed|strided)", ["dwconv_transposed", "dwconv_transposed2", "dwconv_strided"]),
+           ("attention forward", r"^attn_fwd", ["attn_fwd"]),
+           ("attention backward", r"^attn_(dq|dkv|bwd_fused)", ["attn_bwd"]),
+           ("grouped weight gradients 192x384", r"^wgrad8", ["wgrad_grouped8"]),
+           ("grouped weight gradients 128/256x128", r"^wgrad_grouped", ["wgrad_grouped"]),
+           ("clip + AdamW", r"^opt_", ["adamw_step"]),
+           ("max-pool skip", r"^maxpool", ["maxpool_fwd", "maxpool_bwd"]),
+           ("trilinear", r"^trilinear", ["trilinear_fwd", "trilinear_bwd"]),
+           ("all GEMM kernels", r"^(gemm|splitk_finish)", ["gemm"])]
+    if per_entry:
+        print("\nkernel families: time in the replayed step against the ALGORITHMIC bytes / flop of the entries that launch them")
+        print("family | launches/step | ms/step | algorithmic GB/step | GFLOP/step | hbm_frac (bytes / time / 8 TB/s) | mfma_frac (flop / time / 2.5 PF) | PMC GB/step | PMC / algorithmic")
+        for name, rx, entries in FAM:
+            ks = [k for k in t if re.search(rx, k)]
+            if not ks:
+                continue
+            n1 = sum(t[k][0] for k in ks) / len(use)
+            ms = sum(t[k][1] for k in ks) / len(use) / 1e3
+            by = sum(per_entry.get(e, {}).get("algorithmic_bytes", 0) for e in entries)
+            fl = sum(per_entry.get(e, {}).get("algorithmic_flop", 0) for e in entries)
+            hbm = sum((2 * pmc.get(k, {}).get("FETCH_SIZE", 0.0) + pmc.get(k, {}).get("WRITE_SIZE", 0.0)) * 1024 / 1e9 * t[k][0] / len(use) for k in ks)
+            print(f"{name} | {n1:.0f} | {ms:.3f} | {by / 1e9:.3f} | {fl / 1e9:.1f} | {by / (ms * 1e-3) / 8e12 if ms else 0:.3f} | {fl / (ms * 1e-3) / 2.5e15 if ms else 0:.3f} | "
+                  f"{hbm:.3f} | {hbm / (by / 1e9) if by else float('nan'):.2f}")
     print("\nraw counters (mean per launch over the eager launches of the --pmc passes):")
     for k, _ in top:
         print(k, {c: f"{v:.4g}" for c, v in sorted(pmc.get(k, {}).items())})

@@ -7,6 +7,7 @@ O="$R/gpurun_out/${1:-mfma_util}"
 mkdir -p $O
 cd "$R"
 B="python3 bench.py --one-stream --median-steps 0 --no-cpu-baseline --no-segments --no-loss-check"
+python tools/step_kernel_counts.py --help > /dev/null 2>&1 || true
 # graph replay: kernel durations + the ordered GEMM list (algorithmic bytes / flops per kernel name)
 timeout -k 10 600 $B --steps 5 --warmup 3 --dump-gemm-order $O/order.json > $O/bench.json 2> $O/bench.err
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o x -- $B --steps 4 --warmup 2 --no-roofline > $O/trace.txt 2>&1
@@ -20,6 +21,7 @@ done
 python tools/mfma_util.py $O/trace $O/order.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 > $O/mfma_util.txt
 python tools/pmc_traffic.py $O/p4 $O/p5 $O/pmc_traffic.json > $O/pmc_traffic_top.txt
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+python tools/step_kernel_counts.py $O/trace 200 > $O/step_inventory.txt
 python tools/sum_kernel_trace.py $O/trace _kernel > $O/kernel_by_grid.txt
 rm -rf $O/trace $O/p1 $O/p2 $O/p3 $O/p4 $O/p5
 cat $O/mfma_util.txt
