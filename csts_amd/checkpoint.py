@@ -104,15 +104,68 @@ def load_checkpoint(path_to_checkpoint, model, data_parallel=False, optimizer=No
     return epoch
 
 
+def load_video_and_audio_checkpoints(path_to_video_checkpoint, path_to_audio_checkpoint, model, data_parallel=False, optimizer=None,
+                                     scaler=None, epoch_reset=False, clear_name_pattern=(), report=None):
+    """checkpoint.py:357-470: initialise from a VIDEO pre-training checkpoint and an AUDIO one (TRAIN.CHECKPOINT_FILE_PATH +
+    TRAIN.AUDIO_CHECKPOINT_FILE_PATH).  Entries are taken by name + shape, the audio file winning where both provide a name;
+    the four position embeddings are resized bilinearly (first two dims as batch / channel) -- `pos_embed_spatial/temporal` from
+    the video file, the `*_audio` twins from the audio file, whenever either file holds the name (the reference indexes the
+    modality's own file there: a name held only by the other file raises KeyError, here too); epoch / optimizer / scaler state
+    come from the VIDEO file unless epoch_reset.  Returns the epoch (-1 when reset / absent)."""
+    for p_ in (path_to_video_checkpoint, path_to_audio_checkpoint):
+        assert os.path.exists(p_), "Checkpoint '{}' not found".format(p_)
+    ms = _core(model) if data_parallel or hasattr(model, "module") else model
+    states = []
+    for p_ in (path_to_video_checkpoint, path_to_audio_checkpoint):
+        with open(p_, "rb") as f:
+            states.append(torch.load(f, map_location="cpu", weights_only=False))
+    video_ck, audio_ck = states
+    pre = []
+    for ck in states:
+        sd = ck["model_state"]
+        for item in clear_name_pattern:
+            sd = OrderedDict((k.replace(item, "") if item in k else k, v) for k, v in sd.items())
+        pre.append(sd)
+    video_sd, audio_sd = pre
+    model_dict = ms.state_dict()
+    match = {k: v for k, v in video_sd.items() if k in model_dict and v.size() == model_dict[k].size()}
+    match.update({k: v for k, v in audio_sd.items() if k in model_dict and v.size() == model_dict[k].size()})
+    not_loaded = [k for k in model_dict if k not in match]
+    video_pos = ("pos_embed_spatial", "pos_embed_temporal")
+    for k in video_pos + ("pos_embed_spatial_audio", "pos_embed_temporal_audio"):
+        if k in model_dict and (k in video_sd or k in audio_sd):
+            v = video_sd[k] if k in video_pos else audio_sd[k]
+            t = model_dict[k].size()
+            match[k] = F.interpolate(v.float().unsqueeze(0), (t[1], t[2]), mode="bilinear").squeeze(0)
+            if k in not_loaded:
+                not_loaded.remove(k)
+    ms.load_state_dict(match, strict=False)
+    if hasattr(ms, "_refresh_w16") and next(ms.parameters()).is_cuda:
+        ms._refresh_w16()
+    epoch = -1
+    if "epoch" in video_ck and not epoch_reset:
+        epoch = video_ck["epoch"]
+        if optimizer is not None:
+            optimizer.load_state_dict(video_ck["optimizer_state"])
+        if scaler is not None and "scaler_state" in video_ck:
+            scaler.load_state_dict(video_ck["scaler_state"])
+    if report is not None:
+        report.extend(not_loaded)
+    return epoch
+
+
 def load_train_checkpoint(cfg, model, optimizer, scaler=None):
-    """checkpoint.py:617-659: auto-resume from OUTPUT_DIR, else TRAIN.CHECKPOINT_FILE_PATH (fine-tune init), else epoch 0.
-    (The separate video + audio pre-training pair of :645-656 is not provided.)"""
+    """checkpoint.py:617-659: auto-resume from OUTPUT_DIR, else TRAIN.CHECKPOINT_FILE_PATH (fine-tune init; with
+    TRAIN.AUDIO_CHECKPOINT_FILE_PATH the video + audio pre-training pair of :645-656), else epoch 0."""
     if cfg.TRAIN.AUTO_RESUME and has_checkpoint(cfg.OUTPUT_DIR):
         epoch = load_checkpoint(get_last_checkpoint(cfg.OUTPUT_DIR), model, cfg.NUM_GPUS > 1, optimizer, scaler=scaler)
         return epoch + 1
+    if cfg.TRAIN.CHECKPOINT_FILE_PATH != "" and getattr(cfg.TRAIN, "AUDIO_CHECKPOINT_FILE_PATH", "") != "":
+        epoch = load_video_and_audio_checkpoints(cfg.TRAIN.CHECKPOINT_FILE_PATH, cfg.TRAIN.AUDIO_CHECKPOINT_FILE_PATH, model,
+                                                 cfg.NUM_GPUS > 1, optimizer, scaler=scaler, epoch_reset=cfg.TRAIN.CHECKPOINT_EPOCH_RESET,
+                                                 clear_name_pattern=getattr(cfg.TRAIN, "CHECKPOINT_CLEAR_NAME_PATTERN", ()))
+        return epoch + 1
     if cfg.TRAIN.CHECKPOINT_FILE_PATH != "":
-        if getattr(cfg.TRAIN, "AUDIO_CHECKPOINT_FILE_PATH", "") != "":
-            raise NotImplementedError("separate video / audio pre-training checkpoints (checkpoint.py:357-470) are out of scope")
         epoch = load_checkpoint(cfg.TRAIN.CHECKPOINT_FILE_PATH, model, cfg.NUM_GPUS > 1, optimizer, scaler=scaler,
                                 epoch_reset=cfg.TRAIN.CHECKPOINT_EPOCH_RESET,
                                 clear_name_pattern=getattr(cfg.TRAIN, "CHECKPOINT_CLEAR_NAME_PATTERN", ()))

@@ -541,6 +541,65 @@ def gen_checkpoint():
     shutil.rmtree(tmp)
 
 
+def gen_checkpoint_pair():
+    """The video + audio pre-training pair (slowfast/utils/checkpoint.py:357-470; TRAIN.CHECKPOINT_FILE_PATH +
+    TRAIN.AUDIO_CHECKPOINT_FILE_PATH, :645-656): two .pyth files written by the reference's save_checkpoint for small stand-in
+    modules with CSTS-style names, and what the reference's load_video_and_audio_checkpoints makes of them in a model whose
+    position embeddings have other lengths (bilinear resize of both modalities) and whose head has another shape."""
+    import tempfile, shutil
+    from slowfast.utils import checkpoint as ref_ckpt
+
+    class PM:
+        def mkdirs(self, p): os.makedirs(p, exist_ok=True)
+        def open(self, *a, **k): return open(*a, **k)
+        def exists(self, p): return os.path.exists(p)
+        def ls(self, p): return os.listdir(p)
+    ref_ckpt.pathmgr = PM()
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, T, S, nout, audio=True, video=True):
+            super().__init__()
+            if video:
+                self.pos_embed_spatial = torch.nn.Parameter(torch.zeros(1, S, 8))
+                self.pos_embed_temporal = torch.nn.Parameter(torch.zeros(1, T, 8))
+                self.blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(2)])
+            if audio:
+                self.pos_embed_spatial_audio = torch.nn.Parameter(torch.zeros(1, S, 8))
+                self.pos_embed_temporal_audio = torch.nn.Parameter(torch.zeros(1, T, 8))
+                self.blocks_audio = torch.nn.ModuleList([torch.nn.Linear(8, 8)])
+            self.head = torch.nn.Linear(8, nout)
+
+    cfg = make_cfg(8)
+    tmp = tempfile.mkdtemp()
+    paths = {}
+    for name, seed, kw, ep in (("video", 21, dict(T=4, S=16, nout=3, audio=False), 4), ("audio", 22, dict(T=2, S=9, nout=3, video=False), 9)):
+        torch.manual_seed(seed)
+        src = Tiny(**kw)
+        for p_ in src.parameters():
+            torch.nn.init.normal_(p_, std=0.5)
+        opt = torch.optim.AdamW(src.parameters(), lr=1e-3)
+        d = os.path.join(tmp, name) + "/"
+        path = ref_ckpt.save_checkpoint(d, src, opt, ep, cfg)
+        paths[name] = os.path.join(OUT, f"ref_pretrain_{name}.pyth")
+        shutil.copy(path, paths[name])
+    dst = Tiny(T=8, S=16, nout=5)
+    torch.manual_seed(23)
+    for p_ in dst.parameters():
+        torch.nn.init.normal_(p_, std=0.1)
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    epoch = ref_ckpt.load_video_and_audio_checkpoints(paths["video"], paths["audio"], dst, data_parallel=False, optimizer=None,
+                                                      epoch_reset=True)
+    dst2 = Tiny(T=8, S=16, nout=3)
+    dst2.load_state_dict({k: v.clone() for k, v in before.items() if not k.startswith("head")}, strict=False)
+    epoch2 = ref_ckpt.load_video_and_audio_checkpoints(paths["video"], paths["audio"], dst2, data_parallel=False, optimizer=None,
+                                                       epoch_reset=False)
+    save("ref_pretrain_pair_loaded.npz", epoch=np.array(epoch), epoch_no_reset=np.array(epoch2),
+         **{k.replace(".", "__"): t2n(v) for k, v in dst.state_dict().items()},
+         **{"before__" + k.replace(".", "__"): t2n(v) for k, v in before.items()},
+         **{"noreset__" + k.replace(".", "__"): t2n(v) for k, v in dst2.state_dict().items()})
+    shutil.rmtree(tmp)
+
+
 def _autocast_fixture(m, batch, names, dtype, alpha=0.05):
     """The reference's OWN mixed-precision error on this path: the same model, weights and batch once in fp32 and once under
     ``torch.autocast(dtype)`` exactly as the training loop wraps forward + losses (tools/train_avgaze_net.py:70-88; CPU
@@ -632,6 +691,8 @@ if __name__ == "__main__":
         gen_metrics()
     if "checkpoint" in what or "blocks" in what:
         gen_checkpoint()
+    if "checkpoint_pair" in what or "blocks" in what:
+        gen_checkpoint_pair()
     if "model" in what:
         gen_model()
     if "model" in what or "t32" in what:

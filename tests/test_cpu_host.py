@@ -572,3 +572,44 @@ def test_act_checkpoint_key_is_logged_not_ignored(caplog):
     with caplog.at_level(logging.WARNING, logger="csts_amd"):
         MODEL_REGISTRY.get("CSTS")(cfg)
     assert any("ACT_CHECKPOINT" in r.message for r in caplog.records)
+
+
+def test_video_and_audio_pretraining_pair_matches_reference_loader():
+    """csts_amd.checkpoint.load_video_and_audio_checkpoints against what the REFERENCE's loader of the same name
+    (slowfast/utils/checkpoint.py:357-470) made of two .pyth files its own save_checkpoint wrote (fixtures from
+    oracle/gen_golden.py::gen_checkpoint_pair): audio entries win over video ones, all four position embeddings are resized from
+    their own modality's file, shape mismatches stay untouched, epoch comes from the video file unless reset; and the
+    TRAIN.CHECKPOINT_FILE_PATH + TRAIN.AUDIO_CHECKPOINT_FILE_PATH branch of load_train_checkpoint (:645-656) uses it."""
+    from csts_amd import checkpoint as ck
+    from csts_amd.config import load_yaml
+
+    class Tiny(torch.nn.Module):
+        def __init__(self, T, S, nout):
+            super().__init__()
+            self.pos_embed_spatial = torch.nn.Parameter(torch.zeros(1, S, 8))
+            self.pos_embed_temporal = torch.nn.Parameter(torch.zeros(1, T, 8))
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(2)])
+            self.pos_embed_spatial_audio = torch.nn.Parameter(torch.zeros(1, S, 8))
+            self.pos_embed_temporal_audio = torch.nn.Parameter(torch.zeros(1, T, 8))
+            self.blocks_audio = torch.nn.ModuleList([torch.nn.Linear(8, 8)])
+            self.head = torch.nn.Linear(8, nout)
+
+    g = np.load(os.path.join(GOLDEN, "ref_pretrain_pair_loaded.npz"))
+    vid, aud = os.path.join(GOLDEN, "ref_pretrain_video.pyth"), os.path.join(GOLDEN, "ref_pretrain_audio.pyth")
+    key = lambda k: k.replace(".", "__")
+    dst = Tiny(8, 16, 5)
+    dst.load_state_dict({k: torch.from_numpy(g["before__" + key(k)]) for k in dst.state_dict()})
+    missing = []
+    epoch = ck.load_video_and_audio_checkpoints(vid, aud, dst, epoch_reset=True, report=missing)
+    assert epoch == int(g["epoch"]) == -1 and sorted(missing) == ["head.bias", "head.weight"]
+    for k, v in dst.state_dict().items():
+        assert torch.allclose(v, torch.from_numpy(g[key(k)]), atol=1e-7), k
+    # epoch from the VIDEO file, head taken from the audio file (it comes second), through load_train_checkpoint's branch
+    dst2 = Tiny(8, 16, 3)
+    dst2.load_state_dict({k: torch.from_numpy(g["before__" + key(k)]) for k in dst2.state_dict() if not k.startswith("head")}, strict=False)
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "TRAIN.AUTO_RESUME", False, "TRAIN.CHECKPOINT_FILE_PATH", vid,
+                           "TRAIN.AUDIO_CHECKPOINT_FILE_PATH", aud, "TRAIN.CHECKPOINT_EPOCH_RESET", False])
+    start = ck.load_train_checkpoint(cfg, dst2, None)
+    assert start == int(g["epoch_no_reset"]) + 1 == 5
+    for k, v in dst2.state_dict().items():
+        assert torch.allclose(v, torch.from_numpy(g["noreset__" + key(k)]), atol=1e-7), k
