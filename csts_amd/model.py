@@ -48,14 +48,14 @@ def resolve_compute(cfg) -> str:
     (slowfast/config/defaults.py:79; tools/train_avgaze_net.py:70,99-109,277: torch.cuda.amp.autocast = fp16 + GradScaler).
     "fp16" IS that arithmetic: IEEE-half MFMA operands with fp32 accumulation, fp32 master weights / residual stream / LayerNorm
     statistics / softmax / losses (what autocast keeps in fp32), dynamic loss scaling with skipped steps (optim.FusedAdamW).
-    "bf16" is the throughput mode the benchmark is quoted in: bfloat16 operands, same fp32 set, no loss scaling (fp32's exponent
-    range).  "auto" follows the key: False -> fp32 (the reference's default arithmetic), True -> bf16 (north_star's dtype; set
-    COMPUTE fp16 for the reference's own).  The key is never ignored silently: the mapping is logged."""
+    "bf16" is the throughput mode the benchmark is quoted in (and what the shipped YAMLs name): bfloat16 operands, same fp32 set,
+    no loss scaling (fp32's exponent range).  "auto" follows the key with the REFERENCE's arithmetic: False -> fp32, True -> fp16.
+    The key is never ignored silently: the mapping is logged."""
     amd = getattr(cfg, "CSTS_AMD", None)
     compute = str(getattr(amd, "COMPUTE", "auto") if amd is not None else "auto").lower()
     mp = bool(getattr(getattr(cfg, "TRAIN", None), "MIXED_PRECISION", False))
     if compute == "auto":
-        compute = "bf16" if mp else "fp32"
+        compute = "fp16" if mp else "fp32"          # the reference's own arithmetic for either value of the key
     if mp:
         if compute == "fp16":
             _log.warning("TRAIN.MIXED_PRECISION True with CSTS_AMD.COMPUTE fp16: the reference's fp16 autocast + GradScaler arithmetic "

@@ -529,8 +529,9 @@ def test_checkpoint_wire_format_reads_reference_written_pyth(tmp_path):
 
 
 def test_mixed_precision_key_is_mapped_not_ignored(caplog):
-    """TRAIN.MIXED_PRECISION (reference: fp16 autocast + GradScaler) selects the bf16 mode and says so; with COMPUTE "auto"
-    the reference default (False) means fp32 arithmetic."""
+    """TRAIN.MIXED_PRECISION (reference: fp16 autocast + GradScaler): with COMPUTE "auto" it selects the fp16 mode (the
+    reference's own arithmetic, loss scaling included) and says so, the reference default (False) means fp32 arithmetic; an
+    explicit COMPUTE wins and says so; the shipped YAMLs name bf16."""
     import logging
     from csts_amd.config import load_yaml
     from csts_amd.model import resolve_compute
@@ -538,8 +539,13 @@ def test_mixed_precision_key_is_mapped_not_ignored(caplog):
     assert resolve_compute(cfg) == "fp32"
     cfg = load_yaml(YAML, ["NUM_GPUS", 0, "CSTS_AMD.COMPUTE", "auto", "TRAIN.MIXED_PRECISION", True])
     with caplog.at_level(logging.WARNING, logger="csts_amd"):
+        assert resolve_compute(cfg) == "fp16"
+    assert "MIXED_PRECISION" in caplog.text and "fp16" in caplog.text and "loss scaling" in caplog.text
+    caplog.clear()
+    cfg = load_yaml(YAML, ["NUM_GPUS", 0, "TRAIN.MIXED_PRECISION", True])          # the YAML's explicit bf16
+    with caplog.at_level(logging.WARNING, logger="csts_amd"):
         assert resolve_compute(cfg) == "bf16"
-    assert "MIXED_PRECISION" in caplog.text and "bf16" in caplog.text and "loss scaling" in caplog.text
+    assert "bf16 compute mode" in caplog.text and "no loss scaling" in caplog.text
     caplog.clear()
     cfg = load_yaml(YAML, ["NUM_GPUS", 0, "CSTS_AMD.COMPUTE", "fp32", "TRAIN.MIXED_PRECISION", True])
     with caplog.at_level(logging.WARNING, logger="csts_amd"):
