@@ -69,6 +69,8 @@ def parse():
                    help="data-parallel graph chain: second autograd cut in front of this video block (default CSTS_AMD.TRUNK_CUT = 3; 0 = off)")
     p.add_argument("--bucket-dtype", default=None, choices=["fp32", "bf16", "fp16"],
                    help="data-parallel gradient buckets: fp32 (default) or the 16-bit type of the compute mode (half the xGMI bytes)")
+    p.add_argument("--no-grad-factors", action="store_true",
+                   help="data-parallel chain: all-reduce the fusion-conv weight gradients (151 MB each) instead of all-gathering their rank-(B T') factors")
     p.add_argument("--eager-dist", action="store_true",
                    help="N>1: the eager step with hook-driven gradient buckets (GradAllReduce) instead of the graph chain")
     p.add_argument("--no-graph", action="store_true", help="do not capture anything into HIP graphs")
@@ -557,6 +559,8 @@ def main():
         args.bucket_dtype = args.compute
     if args.bucket_dtype is not None:
         opts += ["CSTS_AMD.GRAD_BUCKET_DTYPE", args.bucket_dtype]
+    if args.no_grad_factors:
+        opts += ["CSTS_AMD.FUSION_GRAD_FACTORS", False]
     if args.one_stream:
         opts += ["CSTS_AMD.TWO_STREAMS", False]
     if S != 256:
@@ -832,6 +836,10 @@ def main():
                        "step": step_kind, "hip_graph": step_kind != "eager", "rccl_ranks": rccl_ranks,
                        **({"trunk_cut": int(graphed.trunk_cut)} if hasattr(graphed, "trunk_cut") else {}),
                        **({"grad_bucket_dtype": ("16-bit" if graphed.bucket16 else "fp32")} if hasattr(graphed, "bucket16") else {}),
+                       **({"fusion_grad_factors": bool(graphed.factor_params),
+                           "allreduce_mb_per_step": round(sum((f[0].numel() - (sum((p.numel() + 3) // 4 * 4 for p in graphed.factor_params) if k == 0 else 0))
+                                                               * f[0].element_size() for k, f in enumerate(graphed.flat16 if graphed.bucket16 else graphed.flat)) / 1e6, 1)}
+                          if (hasattr(graphed, "factor_params") and getattr(graphed, "dist", False)) else {}),
                        "dist_backend": (torch.distributed.get_backend() if dist_path else None),
                        "note": ("256^2 not 224^2: the reference's (1,8,8) fusion convs reject 224^2 (SURVEY.md D1)" if S == 256 else
                                 "EXTENSION, parity unpinned: 224^2 with (1,7,7) fusion kernels (CSTS_AMD.FUSION_KERNEL_FROM_GRID); "

@@ -1604,6 +1604,20 @@ def patch_embed(x, W, b, pos_s, pos_t, kernel, stride, padding, act_dt, compute)
 
 
 # ----------------------------------------------------------------------------------------- fusion conv
+# Data-parallel factor exchange (csts_amd.train.SegmentedTrainStep, CSTS_AMD.FUSION_GRAD_FACTORS): the weight gradient of a fusion
+# conv is dW = dY^T A with only B*T' token rows (32 at b = 4, 16 frames) -- a rank-32 update of a 768 x 49152 matrix, 151 MB in
+# fp32, 60 % of all gradient bytes for the three of them.  Across W ranks the averaged gradient is (1/W) [dY_0; ..; dY_W-1]^T
+# [A_0; ..; A_W-1]: the ranks exchange the FACTORS (all-gather of 32 x 768 fp32 + 32 x 49152 16-bit rows: 3.2 MB per conv) and each
+# forms the product itself, instead of all-reducing the 151 MB.  While a sink is set, FusionConvFn.backward hands its factors over
+# and computes no dW (the parameter's gradient is written later by the step that owns the sink).
+_factor_sink = None          # None, or {"params": set of weight data_ptrs, "items": [(W, dy, A, compute)]}
+
+
+def set_factor_sink(sink=None):
+    global _factor_sink
+    _factor_sink = sink
+
+
 class FusionConvFn(Function):
     """Conv3d(C, C, kernel (1,8,8)) over the folded token grid -> (B, T, C)
     (custom_multimodal_builder.py:227-229,420-421,442-445): token fold (batched transpose) + skinny split-K GEMM
@@ -1635,8 +1649,13 @@ class FusionConvFn(Function):
         BT, K = B * T, Cc * HW
         dy = dy.contiguous()
         Wv = Wop.reshape(Cout, K)
-        dW = _grad_buffer(W, (Cout, K), dy.device)        # the data-parallel chain: straight into its all-reduce bucket
-        gemm(L.GEMM_TN, dy, 0, Cout, A, 0, K, dW, K, Cout, K, BT, compute=compute)
+        sink = _factor_sink
+        if sink is not None and W.data_ptr() in sink["params"] and ctx.needs_input_grad[1]:
+            sink["items"].append((W, dy, A, compute))      # factors only: the owner of the sink forms dW after the exchange
+            dW = None
+        else:
+            dW = _grad_buffer(W, (Cout, K), dy.device)        # the data-parallel chain: straight into its all-reduce bucket
+            gemm(L.GEMM_TN, dy, 0, Cout, A, 0, K, dW, K, Cout, K, BT, compute=compute)
         db = colsum(dy, 1, BT, Cout)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -1645,7 +1664,7 @@ class FusionConvFn(Function):
             dx = torch.empty(B, T * HW, Cc, dtype=xdtype, device=dy.device)
             L.check(_lib().csts_transpose_batched(_p(dA), _dt(dA), _p(dx), _dt(dx), BT, Cc, HW, _stream()),
                     "csts_transpose_batched(bwd)")
-        return dx, dW.view(W.shape), db, None, None, None, None, None
+        return dx, (dW.view(W.shape) if dW is not None else None), db, None, None, None, None, None
 
 
 def fusion_conv(x, W, b, T, HW, act_dt, compute, w16=None):

@@ -350,6 +350,15 @@ class SegmentedTrainStep:
         self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
         core = self.core
         self.head_params = [p for p in core.head_parameters() if p.requires_grad]
+        # Factor exchange for the three (1,8,8) fusion convs (ops.set_factor_sink): their weights go to the END of the head bucket,
+        # outside the all-reduced prefix; the ranks all-gather dY / A (3.2 MB per conv) and form the averaged dW themselves.
+        amd_ = getattr(cfg, "CSTS_AMD", None)
+        self.factor_params = []
+        if self.dist and use_graphs and bool(getattr(amd_, "FUSION_GRAD_FACTORS", True)):
+            self.factor_params = [m.weight for m in (getattr(core, n, None) for n in ("vision_pool", "audio_pool", "audio_pool2"))
+                                  if m is not None and m.weight.requires_grad]
+        fid = {id(p) for p in self.factor_params}
+        self.head_params = [p for p in self.head_params if id(p) not in fid] + self.factor_params
         hid = {id(p) for p in self.head_params}
         if trunk_cut is None:
             trunk_cut = int(getattr(getattr(cfg, "CSTS_AMD", None), "TRUNK_CUT", 0) or 0)
@@ -437,6 +446,9 @@ class SegmentedTrainStep:
     def _all_reduce(self, k):
         import torch.distributed as dist
         flat = (self.flat16 if self.bucket16 else self.flat)[k][0]
+        if k == 0 and self.factor_params:          # the fusion-conv weights sit behind the all-reduced prefix of the head bucket
+            n_tail = sum((p.numel() + 3) // 4 * 4 for p in self.factor_params)
+            flat = flat[:flat.numel() - n_tail]
         if self._avg is not None:
             return dist.all_reduce(flat, op=self._avg, async_op=True)
         flat /= dist.get_world_size()
@@ -543,12 +555,21 @@ class SegmentedTrainStep:
             self.result = res
 
         def bwd_head():
-            torch.autograd.backward(self.outs, self.douts, inputs=self.head_params + cut["in"])
+            from . import ops
+            sink = {"params": {p.data_ptr() for p in self.factor_params}, "items": []} if self.factor_params else None
+            ops.set_factor_sink(sink)
+            try:
+                torch.autograd.backward(self.outs, self.douts, inputs=self.head_params + cut["in"])
+            finally:
+                ops.set_factor_sink(None)
+            if sink is not None:
+                self._factors = sink["items"]          # static tensors of the captured graph (kept alive here)
             if self.dist:
                 self._copy_into_bucket(0)
 
         self._segment("bwd_head", bwd_head, capture)
         works = [self._all_reduce(0)] if coll else []
+        works += self._exchange_factors(coll)
 
         def bwd_trunk():
             # with a second cut, the tensors produced in front of it (encoder features of the early stages) wait for the
@@ -578,12 +599,58 @@ class SegmentedTrainStep:
                 w.wait()
             self._raw_grads = [p.grad for ps in self.buckets for p in ps]   # graph-owned: keep them alive
             self._bucket16_back()
+            self._finish_factors()
             for k, ps in enumerate(self.buckets):
                 for p, v in zip(ps, self.flat[k][1]):
                     p.grad = v
         self._segment("opt", lambda: _clip_and_step(cfg, self.model, self.opt), capture)
         del cut, cut2
         return res
+
+    # ------------------------------------------------------------------ factor exchange of the fusion-conv weight gradients
+    def _exchange_factors(self, coll):
+        """After the head backward: all-gather (dY / W, A) of every fusion conv over the ranks (async); without collectives (one
+        process, or the capture pass) the local factors stand in.  Returns the outstanding works."""
+        import torch.distributed as dist
+        from . import ops
+        works = []
+        self._gathered = []
+        if not self.factor_params:
+            return works
+        world = dist.get_world_size() if self.dist else 1
+        bufs = getattr(self, "_factor_bufs", None)
+        if bufs is None:
+            bufs = self._factor_bufs = {}
+        for i, (W, dy, A, compute) in enumerate(self._factors):
+            BT = dy.numel() // W.shape[0]
+            dy2, A2 = dy.reshape(BT, W.shape[0]), A.reshape(BT, -1)
+            if i not in bufs:
+                bufs[i] = (torch.empty(BT, W.shape[0], dtype=dy2.dtype, device=dy2.device),
+                           torch.empty(world * BT, W.shape[0], dtype=dy2.dtype, device=dy2.device),
+                           torch.empty(world * BT, A2.shape[1], dtype=A2.dtype, device=A2.device))
+            dys, gdy, gA = bufs[i]
+            ops.cast_into(dys, dy2.contiguous(), scale=1.0 / world)          # the mean over ranks, folded into the small factor
+            if coll and world > 1:
+                works.append(dist.all_gather(list(gdy.chunk(world)), dys, async_op=True))
+                works.append(dist.all_gather(list(gA.chunk(world)), A2.contiguous(), async_op=True))
+                self._gathered.append((W, gdy, gA, compute, world * BT))
+            else:       # no collective in this pass: every rank slot holds the local factors (the capture pass's results are discarded)
+                for r in range(world):
+                    gdy[r * BT:(r + 1) * BT].copy_(dys)
+                    gA[r * BT:(r + 1) * BT].copy_(A2)
+                self._gathered.append((W, gdy, gA, compute, world * BT))
+        return works
+
+    def _finish_factors(self):
+        """dW = [dY_0/W; ..]^T [A_0; ..] straight into the bucket slot the optimizer reads (fp32, or the 16-bit twin)."""
+        from . import ops, lib as L
+        if not self.factor_params:
+            return
+        tgt = self.averaged_grads()
+        for W, gdy, gA, compute, rows in self._gathered:
+            out = tgt[W].view(W.shape[0], -1)
+            K = out.shape[1]
+            ops.gemm(L.GEMM_TN, gdy, 0, W.shape[0], gA, 0, K, out, K, W.shape[0], K, rows, compute=compute)
 
     def _bucket16_back(self):
         """16-bit buckets with an optimizer that reads p.grad (stock torch optimizers; the gloo CPU tests): the averaged 16-bit
@@ -636,6 +703,7 @@ class SegmentedTrainStep:
         mark(2)
         self.graphs["bwd_head"].replay()
         works = [self._all_reduce(0)] if self.dist else []
+        works += self._exchange_factors(self.dist)
         mark(3)
         self.graphs["bwd_trunk"].replay()
         if self.dist:
@@ -647,6 +715,7 @@ class SegmentedTrainStep:
         for w in works:
             w.wait()
         self._bucket16_back()
+        self._finish_factors()
         mark(4)
         self.graphs["opt"].replay()
         mark(5)

@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port, trunk_cut, compute, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5], sys.argv[6]
     bucket_dtype = sys.argv[7] if len(sys.argv) > 7 else "fp32"
+    factors = (sys.argv[8] != "dense") if len(sys.argv) > 8 else True
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
@@ -35,7 +36,8 @@ def main():
 
     cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
                     ["NUM_GPUS", 1, "MODEL.LOSS_FUNC", "kldiv+egonce", "DATA.NUM_FRAMES", 8, "CSTS_AMD.COMPUTE", compute,
-                     "CSTS_AMD.TRUNK_CUT", trunk_cut, "CSTS_AMD.GRAD_BUCKET_DTYPE", bucket_dtype])
+                     "CSTS_AMD.TRUNK_CUT", trunk_cut, "CSTS_AMD.GRAD_BUCKET_DTYPE", bucket_dtype,
+                     "CSTS_AMD.FUSION_GRAD_FACTORS", factors])
     core = build_model(cfg)
     core.load_state_dict(O.seeded_params(8, 256), strict=True)
     core.eval()                                        # drop-path off: the fixture is an eval-mode forward + backward
@@ -51,7 +53,7 @@ def main():
     # ---- step A: gradients as the optimizer sees them
     loss, kld, nce = step.run(batch, lr=0.0)
     torch.cuda.synchronize()
-    res = {"loss": float(loss), "kld": float(kld), "nce": float(nce), "n_buckets": len(step.flat)}
+    res = {"loss": float(loss), "kld": float(kld), "nce": float(nce), "n_buckets": len(step.flat), "n_factor_params": len(step.factor_params)}
     ptrs = [(f.data_ptr(), f.data_ptr() + f.numel() * 4) for f, _ in step.flat]
     names, norms, total = [], [], 0.0
     avg = step.averaged_grads()        # what the optimizer graph reads: views of the fp32 buckets (= p.grad) or of the 16-bit ones

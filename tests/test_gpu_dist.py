@@ -30,11 +30,11 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run_ranks(tmp_path, trunk_cut, compute, world=2, timeout=900, bucket_dtype="fp32"):
+def _run_ranks(tmp_path, trunk_cut, compute, world=2, timeout=900, bucket_dtype="fp32", factors="factors"):
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, str(trunk_cut), compute, outs[r], bucket_dtype],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), str(r), str(world), port, str(trunk_cut), compute, outs[r], bucket_dtype, factors],
                               env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     try:
@@ -55,6 +55,7 @@ def test_two_process_graph_chain_equals_single_process_reference_fixture(tmp_pat
     g = np.load(os.path.join(GOLDEN, "model_T8_B2.npz"), allow_pickle=False)
     r0, r1 = _run_ranks(tmp_path, trunk_cut, "fp32")
     assert int(r0["n_buckets"]) == (3 if trunk_cut else 2)
+    assert int(r0["n_factor_params"]) == 3        # the fusion-conv weight gradients were exchanged as factors (all-gather), not all-reduced
     # EgoNCE runs over the GATHERED embeddings: the same global value on both ranks == the reference's B=2 value;
     # KLDiv is per rank, its mean over ranks is the reference's batch mean
     assert abs(float(r0["nce"]) - float(r1["nce"])) < 1e-6
@@ -101,6 +102,20 @@ def test_two_process_graph_chain_bf16_mode(tmp_path):
             assert abs(norm_of[n] - ref_norm) <= 4e-2 * ref_norm, (n, norm_of[n], ref_norm)
     tot, ref_tot = float(r0["grad_total_norm"]), float(g["grad_total_norm"])
     assert abs(tot - ref_tot) < 1e-2 * ref_tot
+    for k in ("param_sum", "param_abs_sum", "param_heads"):
+        assert np.array_equal(r0[k], r1[k]), k
+
+
+def test_two_process_graph_chain_dense_fusion_gradients(tmp_path):
+    """CSTS_AMD.FUSION_GRAD_FACTORS False: the three fusion-conv weight gradients travel inside the all-reduced head bucket (151 MB
+    each) instead of as all-gathered rank-(B T') factors -- the default the other tests of this file run.  Same bars."""
+    g = np.load(os.path.join(GOLDEN, "model_T8_B2.npz"), allow_pickle=False)
+    r0, r1 = _run_ranks(tmp_path, 3, "fp32", factors="dense")
+    assert int(r0["n_factor_params"]) == 0
+    norm_of = dict(zip([str(n) for n in r0["grad_names"]], r0["grad_norms"]))
+    for n, ref_norm in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        if n != "classifier.bias":
+            assert abs(norm_of[n] - ref_norm) <= 2e-3 * ref_norm, (n, norm_of[n], ref_norm)
     for k in ("param_sum", "param_abs_sum", "param_heads"):
         assert np.array_equal(r0[k], r1[k]), k
 

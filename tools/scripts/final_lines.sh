@@ -12,5 +12,9 @@ timeout -k 10 300 python bench.py --frames 32 --batch-per-gpu 2 --no-cpu-baselin
 timeout -k 10 300 python bench.py --crop 224 --no-cpu-baseline > $O/bench_crop224.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --rehearse-dist --no-cpu-baseline > $O/bench_rehearse_dist.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --rehearse-dist --trunk-cut 0 --no-cpu-baseline > $O/bench_rehearse_dist_cut0.json 2>> $O/bench.err
-for f in bench_fwd bench_T32_b2 bench_crop224 bench_rehearse_dist bench_rehearse_dist_cut0; do python -c "
+timeout -k 10 300 python bench.py --compute fp16 --no-cpu-baseline --no-roofline > $O/bench_fp16.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --compute fp16 --frames 32 --batch-per-gpu 2 --no-cpu-baseline --no-roofline > $O/bench_fp16_T32_b2.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --compute fp16 --mode fwd --no-cpu-baseline > $O/bench_fp16_fwd.json 2>> $O/bench.err
+timeout -k 10 400 python bench.py --compute fp32 --no-cpu-baseline --no-roofline > $O/bench_fp32.json 2>> $O/bench.err
+for f in bench_fwd bench_T32_b2 bench_crop224 bench_rehearse_dist bench_rehearse_dist_cut0 bench_fp16 bench_fp16_T32_b2 bench_fp16_fwd bench_fp32; do python -c "
 import json,sys; d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['unit'], d['ms_per_step'])"; done
