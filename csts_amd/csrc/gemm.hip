@@ -516,7 +516,11 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
   // ---------------- epilogue through LDS, 64 rows (one 32-row MFMA tile of each wave row) at a time
   float* Cs = reinterpret_cast<float*>(smem_raw);
   const bool first_split = (blockIdx.y == 0);
-  const bool RES_LINES = p.res_lines != 0;
+#ifdef CSTS_GEMM_RES_OLD
+  constexpr bool RES_LINES = false;
+#else
+  constexpr bool RES_LINES = true;      // compile-time: carrying both forms of the residual epilogue behind a run-time flag cost the kernel ~0.1 ms per step
+#endif
   const int col = (tid & 15) * 8;
   const int64_t n = n0 + col;
   float bias[8];
@@ -584,8 +588,8 @@ __global__ __launch_bounds__(128 * WM, (MT == 4) ? 2 : (MT == 2 ? 3 : 4)) void g
       continue;
     }
     if (n >= p.N) continue;
-    if (p.residual != nullptr && p.res_row_mod == 0 && p.ru_To == 0 && p.epilogue == CSTS_EPI_NONE && p.split_k == 1 &&
-        p.c_dt == CSTS_F32 && p.r_dt == CSTS_F32 && m0 + g * 64 + 64 <= p.M) {            // block-uniform
+    if (!RES_LINES && p.residual != nullptr && p.res_row_mod == 0 && p.ru_To == 0 && p.epilogue == CSTS_EPI_NONE && p.split_k == 1 &&
+        p.c_dt == CSTS_F32 && p.r_dt == CSTS_F32 && m0 + g * 64 + 64 <= p.M) {            // block-uniform (round-3 form, -DCSTS_GEMM_RES_OLD)
       constexpr int NI = 1024 / NTHR;
       const float* __restrict__ res = reinterpret_cast<const float*>(p.residual);
       float* __restrict__ Cf = reinterpret_cast<float*>(p.C);

@@ -61,7 +61,13 @@ template <int WM, int MT, int NT, int S, int FORM, int NP = 0>
 __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, NP>::WPS)) void gemm4_kernel(Params p) {
   typedef G4<WM, MT, NT, S, NP> G;
   constexpr bool KTAIL = false;        // K % 64 != 0 is not instantiated (the library never picks this kernel for it)
-  const bool STORE_AWARE = p.store_aware != 0;     // A/B switch (CSTS_GEMM4_STORE_AWARE=0): wave-uniform
+  // experiment of round 4 (profiles/r4_gemm4_store_aware_ab.txt): compiled in only with -DCSTS_GEMM4_STORE_AWARE_BUILD -- even
+  // switched off at run time, the extra wave-uniform branch in every k-step cost the whole family ~0.2 ms per step
+#ifdef CSTS_GEMM4_STORE_AWARE_BUILD
+  const bool STORE_AWARE = p.store_aware != 0;
+#else
+  constexpr bool STORE_AWARE = false;
+#endif
   constexpr int BM = G::BM, BN = G::BN, A_BYTES = G::A_BYTES, STAGE = G::STAGE, NA = G::NA, NB = G::NB, LPT = G::LPT;
   __shared__ __attribute__((aligned(1024))) char smem_raw[S * STAGE];
 
@@ -186,7 +192,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
       // vector memory retires in order on one counter, so a count without them drained every store of the previous tile
       // before the first MFMA of the next one (EPI_ST is exact for the straight-line forms; 0 = over-wait for the generic one)
       if constexpr (NP == 0) {
-        constexpr int EPI_ST = (FORM == 0) ? 0 : MT * NT * (FORM == 2 ? 4 : 2);
+        constexpr int EPI_ST = (FORM == 0) ? 0 : MT * NT * 2;      // a lower bound (FORM 2 stores twice as many when it keeps the pre-activation): under-counting only over-waits
         static_assert(2 * LPT + EPI_ST <= 63, "vmcnt immediate");
         const int ahead = min(S - 2, total_k - 1 - cidx);
         if (EPI_ST > 0 && STORE_AWARE && t != t_first && kt < S - 1) {
@@ -401,7 +407,7 @@ int gemm4_form(const Params& p, int BM, int BN) {
   if (p.M % BM != 0 || p.N % BN != 0 || p.c_dt != CSTS_BF16 || p.residual != nullptr || p.row_scale != nullptr) return 0;
   if (p.bias != nullptr) {
     if (p.epilogue == CSTS_EPI_NONE) return 1;
-    if (p.epilogue == CSTS_EPI_GELU && p.aux != nullptr && p.aux_dt == CSTS_BF16) return 2;
+    if (p.epilogue == CSTS_EPI_GELU && (p.aux == nullptr || p.aux_dt == CSTS_BF16)) return 2;     // aux == NULL: inference, the pre-activation is not kept
     return 0;
   }
   if (p.epilogue == CSTS_EPI_NONE) return 3;

@@ -286,6 +286,11 @@ __global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const v
 // A group of GL lanes owns one (batch, out-token, head, slot) item, 8 channels per lane (HD/8 lanes active), so the
 // LayerNorm statistics are a shuffle reduction inside the group and the pooled row never leaves registers before it is
 // normalised.  Writes the pre-LN row (saved for backward), the normalised row, mean and rstd.
+#ifdef CSTS_POOLLN_SPLIT8
+constexpr bool POOLLN_SPLIT8 = true;
+#else
+constexpr bool POOLLN_SPLIT8 = false;
+#endif
 #ifndef POOL_LN_WGS
 #define POOL_LN_WGS 4      // workgroups per CU the register budget is set for (128 VGPRs: the 1024-workgroup launches run in ONE round)
 #endif
@@ -305,7 +310,10 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   const Geom& g = rg.g;
   const int HD = g.HD, H = g.C / HD;
   {   // stage both slots' weights (tap-major, one zero row each)
-    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows<true>(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
+    // POOLLN_SPLIT8 (round 4, -DCSTS_POOLLN_SPLIT8): the conflict-free row layout took SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS from 3.56
+    // to 0.53 and made the kernel 8-10 % SLOWER (tools/pool_ln_bench.py: 17.4 -> 19.1 us at the 384-channel stage): the kernel is
+    // bound by its dependent global-load rounds, and the permuted staging costs every workgroup more than the conflicts did.  Off.
+    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows<POOLLN_SPLIT8>(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
     __syncthreads();
   }
   const int lane_in = threadIdx.x % GL;
@@ -329,12 +337,16 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
     bool hv[3], xv[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+#ifdef CSTS_POOLLN_SHIFT
+      const int h = (oh << rg.lh) - 1 + k, x = (ow << rg.lw) - 1 + k;
+#else
       const int h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
+#endif
       hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
       xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
     }
     const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
-    const float* wls = wl + slot * 28 * (HD + WPAD) + (c8 >> 1);      // SPLIT8 layout: first fours at 4 i, second fours at HD / 2 + 4 i
+    const float* wls = wl + slot * 28 * (HD + WPAD) + (POOLLN_SPLIT8 ? (c8 >> 1) : c8);      // SPLIT8 layout: first fours at 4 i, second fours at HD / 2 + 4 i
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // 9 taps (one temporal slice) in flight at a time: a 128-register budget, FOUR workgroups per CU, so the 1024-workgroup
     // launches of the 384-channel stages are resident at once.  (All 27 taps at once -- one memory round trip per item
@@ -342,7 +354,11 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
     // those launches, 10-30 % faster for the smaller ones; rocprofv3 kernel trace, profiles/r2_pool_ln_ab.txt.)
 #pragma unroll 1
     for (int kt = 0; kt < 3; ++kt) {           // a real loop: unrolled, the scheduler hoists all 27 loads again and spills
+#ifdef CSTS_POOLLN_SHIFT
+      const int t = (ot << rg.lt) - 1 + kt;
+#else
       const int t = ot * g.st - 1 + kt;
+#endif
       const bool tvk = (unsigned)t < (unsigned)g.Tf;
       const int tofk = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
       Raw8<F32> raw[9];
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
         for (int kw = 0; kw < 3; ++kw) {
           const int tap = (tvk && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
           const float4 w0 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD)]);
-          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD) + (HD >> 1)]);
+          const float4 w1 = *reinterpret_cast<const float4*>(&wls[tap * (HD + WPAD) + (POOLLN_SPLIT8 ? (HD >> 1) : 4)]);
           float v[8];
           raw8_cvt<F32>(raw[kh * 3 + kw], v);
           acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;

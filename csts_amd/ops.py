@@ -568,7 +568,9 @@ def gemm(layout, A, a_off, lda, B, b_off, ldb, Cm, ldc, M, N, K, *, compute, bia
     a.M, a.N, a.K = M, N, K
     a.bias = _p(bias)
     a.epilogue = epilogue
-    a.aux, a.aux_dt, a.ldaux = _p(aux), (_dt(aux) if aux is not None else 0), (N if aux is not None else 0)
+    # GELU without a kept pre-activation (inference): aux_dt still names the activation dtype -- it selects the GELU flavour
+    # (exact erf in fp32 mode, the 1.5e-7 polynomial in the 16-bit modes), which must not depend on whether h is kept
+    a.aux, a.aux_dt, a.ldaux = _p(aux), (_dt(aux) if aux is not None else (_dt(Cm) if epilogue == L.EPI_GELU else 0)), (N if aux is not None else 0)
     a.residual, a.r_dt, a.ldr = _p(residual), (_dt(residual) if residual is not None else 0), ldr
     a.res_row_mod = res_row_mod
     a.row_scale, a.rows_per_scale = _p(row_scale), rows_per_scale
@@ -934,15 +936,19 @@ class MlpFn(Function):
         Hd = W1.shape[0]
         N = W2.shape[0]
         M = x.numel() // K
-        h = torch.empty(M, Hd, dtype=torch_dtype(act_dt), device=x.device)   # pre-activation
-        g = torch.empty_like(h)
+        # the pre-activation h is kept for backward only: an inference forward (no input needs a gradient) does not write it
+        # (M x 4C x 2 bytes per block: 1.26 GB of a b = 4 forward at 16 x 256^2)
+        train = any(ctx.needs_input_grad)
+        g = torch.empty(M, Hd, dtype=torch_dtype(act_dt), device=x.device)
+        h = torch.empty_like(g) if train else None   # pre-activation
         gemm(L.GEMM_NT, x, 0, K, W1, 0, K, g, Hd, M, Hd, K, compute=compute, bias=b1, epilogue=L.EPI_GELU, aux=h)
         y = torch.empty(*x.shape[:-1], N, dtype=torch_dtype(out_dt), device=x.device)
         if residual is not None:
             residual = residual.contiguous()
         gemm(L.GEMM_NT, g, 0, Hd, W2, 0, Hd, y, N, M, N, Hd, compute=compute, bias=b2, residual=residual, ldr=N,
              row_scale=row_scale, rows_per_scale=rows_per_scale)
-        ctx.save_for_backward(x, W1, W2, h, g, row_scale)
+        if train:
+            ctx.save_for_backward(x, W1, W2, h, g, row_scale)
         ctx.meta = (M, K, Hd, N, rows_per_scale, compute, residual is not None)
         return y
 

@@ -1068,3 +1068,24 @@ def test_resampling_specialisations_match_generic(tmp_path):
     assert len(fast) == len(generic)
     for i, (a, b) in enumerate(zip(fast, generic)):
         assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("compute", [L.F32, L.BF16])
+@pytest.mark.parametrize("M,K,Hd,N", [(8192, 384, 1536, 384), (1000, 96, 384, 192)])
+def test_mlp_inference_forward_does_not_keep_the_preactivation_and_matches_training_forward(compute, M, K, Hd, N):
+    """An inference forward (no input requires a gradient) skips the M x 4C pre-activation write of fc1 (ops.MlpFn); the output
+    must equal the training-mode forward bit for bit (same GELU flavour, same kernels up to the epilogue's extra store)."""
+    dt = tdt(compute)
+    x = rnd(M, K, seed=1).to(dt)
+    W1, b1 = rnd(Hd, K, seed=2, scale=K ** -0.5), 0.1 * rnd(Hd, seed=3)
+    W2, b2 = rnd(N, Hd, seed=4, scale=Hd ** -0.5), 0.1 * rnd(N, seed=5)
+    res = rnd(M, N, seed=6)
+    w16 = (W1.to(torch.bfloat16), W2.to(torch.bfloat16)) if compute == L.BF16 else (None, None)
+    kw = dict(residual=res, act_dt=compute, out_dt=L.F32, compute=compute, w16_1=w16[0], w16_2=w16[1])
+    with torch.no_grad():
+        y_inf = ops.mlp(x, W1, b1, W2, b2, **kw)
+    xg = x.clone().requires_grad_(True)
+    y_tr = ops.mlp(xg, W1.clone().requires_grad_(True), b1, W2, b2, **kw)
+    assert torch.equal(y_inf, y_tr.detach())
+    ref = F.linear(F.gelu(F.linear(x.float(), W1 if compute == L.F32 else w16[0].float(), b1)), W2 if compute == L.F32 else w16[1].float(), b2) + res
+    assert rel_l2(y_inf, ref) < (2e-5 if compute == L.F32 else 1e-2)
