@@ -630,9 +630,14 @@ class SegmentedTrainStep:
                            torch.empty(world * BT, A2.shape[1], dtype=A2.dtype, device=A2.device))
             dys, gdy, gA = bufs[i]
             ops.cast_into(dys, dy2.contiguous(), scale=1.0 / world)          # the mean over ranks, folded into the small factor
-            if coll and world > 1:
-                works.append(dist.all_gather(list(gdy.chunk(world)), dys, async_op=True))
-                works.append(dist.all_gather(list(gA.chunk(world)), A2.contiguous(), async_op=True))
+            if coll:
+                # RCCL: the flat all-gather (rank r's rows land at [r * BT, (r + 1) * BT)); gloo (tests): the list form over views
+                if dist.get_backend() == "nccl":
+                    works.append(dist.all_gather_into_tensor(gdy, dys, async_op=True))
+                    works.append(dist.all_gather_into_tensor(gA, A2.contiguous(), async_op=True))
+                else:
+                    works.append(dist.all_gather(list(gdy.chunk(world)), dys, async_op=True))
+                    works.append(dist.all_gather(list(gA.chunk(world)), A2.contiguous(), async_op=True))
                 self._gathered.append((W, gdy, gA, compute, world * BT))
             else:       # no collective in this pass: every rank slot holds the local factors (the capture pass's results are discarded)
                 for r in range(world):
