@@ -8,6 +8,7 @@
 // straddle tensors) plus a per-tensor table; only the gradient pointers change between steps.  Step count, learning
 // rate and the clip coefficient live in device memory, so a captured HIP graph replays the schedule correctly.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -74,10 +75,15 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_sqnorm_kernel(OptTables t, in
 // 1 / loss scale), state[3] = 1 when this step is skipped (non-finite gradients under a loss scaler), else 0
 __global__ __launch_bounds__(1024) void opt_norm_finish_kernel(const float* __restrict__ partial, int nchunks, float max_norm,
                                                                float* __restrict__ state, float* __restrict__ scaler, float growth,
-                                                               float backoff, int growth_interval) {
+                                                               float backoff, int growth_interval, const float* __restrict__ extra_sq,
+                                                               int n_extra) {
   __shared__ float red[1024 / WAVE];
   float s = 0.f;
   for (int i = threadIdx.x; i < nchunks; i += 1024) s += partial[i];
+  if (extra_sq != nullptr && (int)threadIdx.x < n_extra) {      // never-materialised (factored) gradients: same units as g, so 1 / scale applies
+    const float inv = scaler != nullptr ? 1.f / scaler[0] : 1.f;
+    s += extra_sq[threadIdx.x] * inv * inv;
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -174,7 +180,189 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_adamw_kernel(OptTables t, int
   }
 }
 
+
+// ---------------------------------------------------------------- factored AdamW (csts_opt_factored, include/csts_hip.h)
+constexpr int FK = 256;       // k-columns per workgroup tile / Gram slab
+constexpr int FT = 64;        // max token rows
+constexpr int FMAX = 8;       // items per call (the list travels by value in the kernel arguments: graph-capturable, no staging)
+
+struct FactoredList { csts_opt_factored it[FMAX]; int64_t ws_off[FMAX]; };
+
+__device__ __forceinline__ float ld_a(const void* a, int a_dt, int64_t i) {
+  return a_dt == CSTS_F32 ? reinterpret_cast<const float*>(a)[i] : (float)reinterpret_cast<const bf16*>(a)[i];
+}
+
+// partial Gram slab: ws[item][slab][t * T + t'] = sum_{k in slab} A[t][k] A[t'][k]
+__global__ __launch_bounds__(256) void factored_gram_kernel(FactoredList l, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];                     // [T][FK + 1]
+  float (*As)[FK + 1] = reinterpret_cast<float (*)[FK + 1]>(fsm);
+  const csts_opt_factored& it = l.it[blockIdx.z];
+  const int nslab = it.K / FK;
+  if ((int)blockIdx.x >= nslab) return;
+  const int k0 = blockIdx.x * FK, T = it.T;
+  for (int i = threadIdx.x; i < T * (FK / 8); i += 256) {
+    const int t = i / (FK / 8), k = (i - t * (FK / 8)) * 8;
+    float v[8];
+    ld8_as_f32(it.a, it.a_dt, (int64_t)t * it.K + k0 + k, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) As[t][k + j] = v[j];
+  }
+  __syncthreads();
+  float* out = ws + l.ws_off[blockIdx.z] + (int64_t)blockIdx.x * T * T;
+  for (int pr = threadIdx.x; pr < T * T; pr += 256) {
+    const int t = pr / T, u = pr - t * T;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < FK; ++k) s += As[t][k] * As[u][k];
+    out[pr] = s;
+  }
+}
+// out_sq[item] = sum_{t,t'} G1[t,t'] G2[t,t'],  G2 = sum of the slabs, G1 = dY dY^T   (fixed order: reproducible)
+__global__ __launch_bounds__(1024) void factored_sq_finish_kernel(FactoredList l, const float* __restrict__ ws, float* __restrict__ out_sq) {
+  __shared__ float red[1024 / WAVE];
+  const csts_opt_factored& it = l.it[blockIdx.x];
+  const int T = it.T, nslab = it.K / FK;
+  const float* w = ws + l.ws_off[blockIdx.x];
+  float acc = 0.f;
+  for (int pr = threadIdx.x; pr < T * T; pr += 1024) {
+    const int t = pr / T, u = pr - t * T;
+    float g2 = 0.f;
+    for (int s = 0; s < nslab; ++s) g2 += w[(int64_t)s * T * T + pr];
+    float g1 = 0.f;
+    for (int n = 0; n < it.N; ++n) g1 += it.dy[(int64_t)t * it.N + n] * it.dy[(int64_t)u * it.N + n];
+    acc += g1 * g2;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 1024 / WAVE; ++i) tot += red[i];
+    out_sq[blockIdx.x] = (tot == tot) ? fmaxf(tot, 0.f) : __builtin_inff();      // a non-finite factor must reach the loss scaler's check (fmaxf drops NaN)
+  }
+}
+// tile: FR rows n x FK columns k; g[n][k] = sum_t dy[t][n] A[t][k] in fp32, then the AdamW update of csts_adamw_step.  A thread owns
+// 4 consecutive columns of FR / 4 rows: one float4 of the operand tile per token row feeds all of them from registers.
+constexpr int FR = 32;
+__global__ __launch_bounds__(256) void opt_adamw_factored_kernel(FactoredList l, const float* __restrict__ lr_ptr,
+                                                                 const float* __restrict__ state, float b1, float b2, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];                     // [T][FK] operand tile, then [T][FR] dY tile
+  if (state[3] != 0.f) return;                                  // step skipped by the loss scaler
+  const csts_opt_factored& it = l.it[blockIdx.z];
+  float (*As)[FK] = reinterpret_cast<float (*)[FK]>(fsm);
+  float (*Ds)[FR] = reinterpret_cast<float (*)[FR]>(fsm + it.T * FK);
+  const int k0 = blockIdx.x * FK, n0 = blockIdx.y * FR, T = it.T;
+  if (k0 >= it.K || n0 >= it.N) return;
+  // operand tile: 8 elements (16 bytes of the 16-bit type, 32 of fp32) per thread and pass
+  for (int i = threadIdx.x; i < T * (FK / 8); i += 256) {
+    const int t = i / (FK / 8), k = (i - t * (FK / 8)) * 8;
+    float v[8];
+    ld8_as_f32(it.a, it.a_dt, (int64_t)t * it.K + k0 + k, v);
+    *reinterpret_cast<float4*>(&As[t][k]) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(&As[t][k + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  for (int i = threadIdx.x; i < T * FR; i += 256) {
+    const int t = i / FR, n = i - t * FR;
+    Ds[t][n] = (n0 + n < it.N) ? it.dy[(int64_t)t * it.N + n0 + n] : 0.f;
+  }
+  __syncthreads();
+  const float lr = *lr_ptr, step = state[0], clip = state[2];
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1, rsqrt_bc2 = 1.f / sqrtf(bc2);
+  const int kq = (threadIdx.x & 63) * 4;                        // 4 consecutive columns
+  const int nr = threadIdx.x >> 6;                              // rows nr, nr + 4, ..., nr + FR - 4
+  constexpr int RPT = FR / 4;
+  float g[RPT][4];
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) { g[rr][0] = 0.f; g[rr][1] = 0.f; g[rr][2] = 0.f; g[rr][3] = 0.f; }
+  for (int t = 0; t < T; ++t) {
+    const float4 av = *reinterpret_cast<const float4*>(&As[t][kq]);
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+      const float d = Ds[t][nr + 4 * rr];
+      g[rr][0] += d * av.x; g[rr][1] += d * av.y; g[rr][2] += d * av.z; g[rr][3] += d * av.w;
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    const int n = n0 + nr + 4 * rr;
+    if (n >= it.N) continue;
+    const int64_t at = (int64_t)n * it.K + k0 + kq;
+    float4 pp = *reinterpret_cast<float4*>(it.p + at), mm = *reinterpret_cast<float4*>(it.m + at), vv = *reinterpret_cast<float4*>(it.v + at);
+    adamw_one(pp.x, g[rr][0], mm.x, vv.x, clip, lr, it.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
+    adamw_one(pp.y, g[rr][1], mm.y, vv.y, clip, lr, it.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
+    adamw_one(pp.z, g[rr][2], mm.z, vv.z, clip, lr, it.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
+    adamw_one(pp.w, g[rr][3], mm.w, vv.w, clip, lr, it.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
+    *reinterpret_cast<float4*>(it.p + at) = pp;
+    *reinterpret_cast<float4*>(it.m + at) = mm;
+    *reinterpret_cast<float4*>(it.v + at) = vv;
+    if (it.w16 != nullptr) {
+      bf16x4 w;
+      w[0] = (bf16)pp.x; w[1] = (bf16)pp.y; w[2] = (bf16)pp.z; w[3] = (bf16)pp.w;
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(it.w16) + at) = w;
+    }
+  }
+}
+
 }  // namespace
+
+static int factored_fill(const csts_opt_factored* items, int nitems, FactoredList& l, int* max_k, int* max_n) {
+  CSTS_REQUIRE(items != nullptr && nitems > 0 && nitems <= FMAX, "1 .. 8 items per call");
+  *max_k = 0; *max_n = 0;
+  int64_t off = 0;
+  for (int i = 0; i < nitems; ++i) {
+    const csts_opt_factored& it = items[i];
+    CSTS_REQUIRE(it.p && it.m && it.v && it.dy && it.a, "null pointer");
+    CSTS_REQUIRE(it.T > 0 && it.T <= FT && it.K > 0 && it.K % FK == 0 && it.N > 0 && it.N % 16 == 0, "T <= 64, K % 256 == 0, N % 16 == 0");
+    CSTS_REQUIRE(it.a_dt == CSTS_F32 || it.a_dt == CSTS_HALF, "bad a dtype");
+    CSTS_REQUIRE(aligned16(it.p) && aligned16(it.m) && aligned16(it.v) && (it.w16 == nullptr || ((uintptr_t)it.w16 & 7) == 0), "alignment");
+    l.it[i] = it;
+    l.ws_off[i] = off;
+    off += (int64_t)(it.K / FK) * it.T * it.T;
+    *max_k = std::max(*max_k, it.K); *max_n = std::max(*max_n, it.N);
+  }
+  return 0;
+}
+
+extern "C" size_t csts_factored_sqnorm_workspace(const csts_opt_factored* items, int nitems) {
+  if (items == nullptr || nitems <= 0 || nitems > FMAX) return 0;
+  size_t b = 0;
+  for (int i = 0; i < nitems; ++i) b += (size_t)(items[i].K / FK) * items[i].T * items[i].T * sizeof(float);
+  return b;
+}
+extern "C" int csts_factored_sqnorm(const csts_opt_factored* items, int nitems, float* out_sq, void* workspace, size_t ws_bytes,
+                                    hipStream_t stream) {
+  FactoredList l;
+  int mk, mn;
+  if (int rc = factored_fill(items, nitems, l, &mk, &mn)) return rc;
+  CSTS_REQUIRE(out_sq != nullptr && workspace != nullptr && aligned16(workspace) && ws_bytes >= csts_factored_sqnorm_workspace(items, nitems), "workspace too small");
+  float* slabs = reinterpret_cast<float*>(workspace);
+  int mt = 0;
+  for (int i = 0; i < nitems; ++i) mt = std::max(mt, items[i].T);
+  const size_t sm = (size_t)mt * (FK + 1) * sizeof(float);
+  CSTS_REQUIRE(sm <= 64 * 1024 || csts_dyn_lds_optin(reinterpret_cast<const void*>(&factored_gram_kernel), (int)sm), "LDS opt-in failed");
+  hipLaunchKernelGGL(factored_gram_kernel, dim3((unsigned)(mk / FK), 1, (unsigned)nitems), dim3(256), sm, stream, l, slabs);
+  CSTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(factored_sq_finish_kernel, dim3((unsigned)nitems), dim3(1024), 0, stream, l, (const float*)slabs, out_sq);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int csts_adamw_factored(const csts_opt_factored* items, int nitems, const float* state, const float* lr, float beta1,
+                                   float beta2, float eps, hipStream_t stream) {
+  FactoredList l;
+  int mk, mn;
+  if (int rc = factored_fill(items, nitems, l, &mk, &mn)) return rc;
+  CSTS_REQUIRE(state != nullptr && lr != nullptr, "null state");
+  int mt = 0;
+  for (int i = 0; i < nitems; ++i) mt = std::max(mt, items[i].T);
+  const size_t sm = (size_t)mt * (FK + FR) * sizeof(float);
+  CSTS_REQUIRE(sm <= 64 * 1024 || csts_dyn_lds_optin(reinterpret_cast<const void*>(&opt_adamw_factored_kernel), (int)sm), "LDS opt-in failed");
+  hipLaunchKernelGGL(opt_adamw_factored_kernel, dim3((unsigned)(mk / FK), (unsigned)cdiv(mn, FR), (unsigned)nitems), dim3(256), sm, stream, l, lr,
+                     state, beta1, beta2, eps);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int csts_adamw_step(const csts_opt_args* a, hipStream_t stream) {
   CSTS_REQUIRE(a != nullptr, "null args");
@@ -183,6 +371,7 @@ extern "C" int csts_adamw_step(const csts_opt_args* a, hipStream_t stream) {
   CSTS_REQUIRE(a->partial && a->state && a->lr, "null state");
   CSTS_REQUIRE(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps > 0.f, "bad hyper-parameters");
   CSTS_REQUIRE(a->grad_dt == CSTS_F32 || a->grad_dt == CSTS_HALF, "bad gradient dtype");
+  CSTS_REQUIRE(a->n_extra_sq >= 0 && a->n_extra_sq <= 1024 && (a->n_extra_sq == 0 || a->extra_sq != nullptr), "bad extra_sq");
   CSTS_REQUIRE(a->scaler == nullptr || (a->growth > 1.f && a->backoff > 0.f && a->backoff < 1.f && a->growth_interval > 0), "bad loss-scaler parameters");
   OptTables t{a->chunk_tensor, a->chunk_off, a->tensors, a->grads};
   const bool g16 = a->grad_dt != CSTS_F32;
@@ -191,7 +380,7 @@ extern "C" int csts_adamw_step(const csts_opt_args* a, hipStream_t stream) {
   else hipLaunchKernelGGL(opt_sqnorm_kernel<false>, grid, block, 0, stream, t, a->chunk_elems, a->partial, (const float*)a->scaler);
   CSTS_LAUNCH_CHECK();
   hipLaunchKernelGGL(opt_norm_finish_kernel, dim3(1), dim3(1024), 0, stream, a->partial, a->nchunks, a->max_grad_norm, a->state,
-                     a->scaler, a->growth, a->backoff, a->growth_interval);
+                     a->scaler, a->growth, a->backoff, a->growth_interval, a->extra_sq, a->n_extra_sq);
   CSTS_LAUNCH_CHECK();
   if (g16) hipLaunchKernelGGL(opt_adamw_kernel<true>, grid, block, 0, stream, t, a->chunk_elems, a->lr, a->state, a->beta1, a->beta2, a->eps);
   else hipLaunchKernelGGL(opt_adamw_kernel<false>, grid, block, 0, stream, t, a->chunk_elems, a->lr, a->state, a->beta1, a->beta2, a->eps);

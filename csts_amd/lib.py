@@ -42,7 +42,7 @@ def half_dtype():
     return torch.float16 if HALF == "fp16" else torch.bfloat16
 
 
-ABI_VERSION = 3   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
+ABI_VERSION = 4   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
@@ -131,7 +131,13 @@ class OptArgs(C.Structure):
                 ("tensors", vp), ("grads", vp), ("ntensors", C.c_int),
                 ("partial", vp), ("state", vp), ("lr", vp),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("max_grad_norm", C.c_float),
-                ("grad_dt", C.c_int), ("scaler", vp), ("growth", C.c_float), ("backoff", C.c_float), ("growth_interval", C.c_int)]
+                ("grad_dt", C.c_int), ("scaler", vp), ("growth", C.c_float), ("backoff", C.c_float), ("growth_interval", C.c_int),
+                ("extra_sq", vp), ("n_extra_sq", C.c_int)]
+
+
+class OptFactored(C.Structure):
+    _fields_ = [("p", vp), ("m", vp), ("v", vp), ("w16", vp), ("dy", vp), ("a", vp), ("a_dt", C.c_int),
+                ("N", C.c_int), ("K", C.c_int), ("T", C.c_int), ("weight_decay", C.c_float), ("pad_", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/csts_hip.h declares
@@ -205,6 +211,9 @@ SYMBOLS = {
     "csts_egonce_fwd": (_I, [vp, vp, vp, vp, _I, _F, vp]),
     "csts_egonce_bwd": (_I, [vp, vp, vp, vp, vp, _I, _F, vp]),
     "csts_adamw_step": (_I, [C.POINTER(OptArgs), vp]),
+    "csts_factored_sqnorm_workspace": (sz, [C.POINTER(OptFactored), _I]),
+    "csts_factored_sqnorm": (_I, [C.POINTER(OptFactored), _I, vp, vp, sz, vp]),
+    "csts_adamw_factored": (_I, [C.POINTER(OptFactored), _I, vp, vp, _F, _F, _F, vp]),
     "csts_frames_normalize": (_I, [vp, vp, _I, i64, _I, C.c_float * 3, C.c_float * 3, vp]),
     "csts_stft_frames": (_I, [_I, _I, _I]),
     "csts_stft_logpower": (_I, [vp, vp, _I, _I, _I, _I, _I, _F, vp]),

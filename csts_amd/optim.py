@@ -54,6 +54,8 @@ class FusedAdamW:
         self.scaler_t = torch.tensor([float(init_scale), 0.0], dtype=torch.float32, device=self.device) if loss_scaling else None
         self.scaler_cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
         self.grad_dt = L.F32          # L.BF16: every gradient handed to step() is in the library's 16-bit type (16-bit buckets)
+        self._factored = None         # [(param index, dy [T, N] fp32, a [T, K])]: gradients formed on the fly (set_factored)
+        self._extra_sq = torch.zeros(8, dtype=torch.float32, device=self.device)
         self._ext_grads = None        # index -> tensor: gradients read from there instead of p.grad (torch refuses a .grad whose
                                       # dtype differs from the parameter's, so 16-bit bucket views cannot be p.grad)
         # tables
@@ -66,6 +68,7 @@ class FusedAdamW:
             if sh is not None:
                 assert sh.dtype == L.half_dtype() and sh.numel() == p.numel() and sh.is_contiguous() and sh.device == p.device
                 self._shadow_refs.append(sh)
+                self.__dict__.setdefault("_shadow_by_index", {})[i] = sh
             tt[i].p, tt[i].m, tt[i].v = p.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr()
             tt[i].w16 = sh.data_ptr() if sh is not None else None
             tt[i].n, tt[i].weight_decay = p.numel(), wd_of[id(p)]
@@ -107,6 +110,51 @@ class FusedAdamW:
         """Total L2 gradient norm of the last step (device scalar; what clip_grad_norm_ returns)."""
         return self.state_t[1]
 
+    # ------------------------------------------------------------------ factored gradients (fusion convs)
+    FACTORED_MAX_T = 64
+
+    def set_factored(self, items=None):
+        """items: [(param, dy [T, N] fp32, a [T, K] fp32 / 16-bit)] with param.view(N, K) -- the weight gradient dY^T A of these
+        parameters is never materialised: step() adds its squared norm to the clip norm from T x T Gram matrices
+        (csts_factored_sqnorm) and forms g on the fly inside their AdamW update (csts_adamw_factored).  Their p.grad is ignored.
+        None / [] switches back.  Tensors must stay alive and in place while step() may run (a captured graph: for its lifetime)."""
+        if not items:
+            self._factored = None
+            return
+        idx = {id(p): i for i, p in enumerate(self.params)}
+        fac = []
+        for p, dy, a in items:
+            i = idx[id(p)]
+            N = p.shape[0]
+            K = p.numel() // N
+            T = dy.shape[0]
+            if not (dy.dtype == torch.float32 and dy.is_contiguous() and a.is_contiguous() and tuple(dy.shape) == (T, N) and tuple(a.shape) == (T, K)
+                    and T <= self.FACTORED_MAX_T and K % 256 == 0 and N % 16 == 0):
+                raise L.CstsError("factored gradient: dy [T, N] fp32 and a [T, K] contiguous, T <= 64, K % 256 == 0, N % 16 == 0")
+            fac.append((i, dy, a))
+        if len(fac) > 8:
+            raise L.CstsError("at most 8 factored parameters")
+        self._factored = fac
+
+    @staticmethod
+    def factored_ok(p, T):
+        N = p.shape[0]
+        return T <= FusedAdamW.FACTORED_MAX_T and (p.numel() // N) % 256 == 0 and N % 16 == 0
+
+    def _factored_items(self):
+        arr = (L.OptFactored * len(self._factored))()
+        wd_of = {id(p): float(g["weight_decay"]) for g in self.param_groups for p in g["params"]}
+        sh = {i: s for i, s in getattr(self, "_shadow_by_index", {}).items()}
+        for j, (i, dy, a) in enumerate(self._factored):
+            p = self.params[i]
+            arr[j].p, arr[j].m, arr[j].v = p.data_ptr(), self._m[i].data_ptr(), self._v[i].data_ptr()
+            arr[j].w16 = sh[i].data_ptr() if i in sh else None
+            arr[j].dy, arr[j].a = dy.data_ptr(), a.data_ptr()
+            arr[j].a_dt = L.F32 if a.dtype == torch.float32 else L.BF16
+            arr[j].N, arr[j].K, arr[j].T = p.shape[0], p.numel() // p.shape[0], dy.shape[0]
+            arr[j].weight_decay = wd_of[id(p)]
+        return arr
+
     def set_external_grads(self, grads_by_param=None, grad_dt=None):
         """grads_by_param: {id(param): tensor} -- step() reads these instead of p.grad (data-parallel buckets in 16 bits);
         None restores p.grad.  grad_dt: L.F32 | L.BF16 (the library's 16-bit type) of EVERY gradient."""
@@ -120,9 +168,10 @@ class FusedAdamW:
     @torch.no_grad()
     def step(self):
         ptrs = []
+        fac_idx = {i for i, _, _ in self._factored} if self._factored else ()
         for i, p in enumerate(self.params):
             g = p.grad if self._ext_grads is None else self._ext_grads.get(i)
-            if g is None:
+            if g is None or i in fac_idx:          # factored parameters: updated by csts_adamw_factored below, skipped here
                 ptrs.append(0)
                 continue
             if g.dtype != (torch.float32 if self.grad_dt == L.F32 else L.half_dtype()) or not g.is_contiguous():
@@ -157,7 +206,20 @@ class FusedAdamW:
         if self.scaler_t is not None:
             a.scaler = self.scaler_t.data_ptr()
             a.growth, a.backoff, a.growth_interval = self.scaler_cfg
-        L.check(L.load().csts_adamw_step(C.byref(a), torch.cuda.current_stream().cuda_stream), "csts_adamw_step")
+        lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream
+        items = None
+        if self._factored:
+            items = self._factored_items()
+            n = len(self._factored)
+            nb = int(lib.csts_factored_sqnorm_workspace(items, n))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.device)
+            L.check(lib.csts_factored_sqnorm(items, n, self._extra_sq.data_ptr(), ws.data_ptr(), ws.numel(), st), "csts_factored_sqnorm")
+            a.extra_sq, a.n_extra_sq = self._extra_sq.data_ptr(), n
+        L.check(lib.csts_adamw_step(C.byref(a), st), "csts_adamw_step")
+        if items is not None:
+            L.check(lib.csts_adamw_factored(items, len(self._factored), self.state_t.data_ptr(), self._lr.data_ptr(), self.betas[0],
+                                            self.betas[1], self.eps, st), "csts_adamw_factored")
 
     @property
     def loss_scale(self):

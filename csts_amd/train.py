@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 import time
 from typing import Dict, Optional
 
@@ -119,6 +120,42 @@ def backward_scaled(loss, optimizer):
     (loss if sc is None else loss * sc).backward()
 
 
+def _factored_params(cfg, core, optimizer):
+    """The fusion-conv weights whose gradient the optimizer can form on the fly from its rank-(B T') factors
+    (FusedAdamW.set_factored; CSTS_AMD.FACTORED_ADAMW): never written to memory, never read back."""
+    if not bool(getattr(getattr(cfg, "CSTS_AMD", None), "FACTORED_ADAMW", False) or os.environ.get("CSTS_FACTORED_ADAMW", "0") == "1") \
+            or not hasattr(optimizer, "set_factored"):          # environment switch for same-box A/B runs
+        return []
+    ws = [m.weight for m in (getattr(core, n, None) for n in ("vision_pool", "audio_pool", "audio_pool2")) if m is not None]
+    return [w for w in ws if w.requires_grad and w.grad is None and w.is_cuda]
+
+
+def backward_with_factors(cfg, model, loss, optimizer):
+    """scaler.scale(loss).backward() with the fusion-conv weight gradients left as factors for the optimizer (see
+    _factored_params): FusionConvFn.backward hands (dY, A) to the sink instead of running its TN GEMM."""
+    from . import ops
+    core = model.module if isinstance(model, GradAllReduce) else model
+    fac = [] if isinstance(model, GradAllReduce) else _factored_params(cfg, core, optimizer)
+    if not fac:
+        if hasattr(optimizer, "set_factored"):
+            optimizer.set_factored(None)
+        backward_scaled(loss, optimizer)
+        return
+    sink = {"params": {p.data_ptr() for p in fac}, "items": []}
+    ops.set_factor_sink(sink)
+    try:
+        backward_scaled(loss, optimizer)
+    finally:
+        ops.set_factor_sink(None)
+    items = []
+    for W, dy, A, _ in sink["items"]:
+        bt = dy.numel() // W.shape[0]
+        if not optimizer.factored_ok(W, bt):
+            raise RuntimeError("factored AdamW: unsupported fusion-conv geometry (set CSTS_AMD.FACTORED_ADAMW False)")
+        items.append((W, dy.reshape(bt, W.shape[0]), A.reshape(bt, -1)))
+    optimizer.set_factored(items)
+
+
 def compute_loss(cfg, model, video, audio, labels_hm, keep_masks=None):
     """train_avgaze_net.py:70-93."""
     if cfg.MODEL.LOSS_FUNC == "kldiv+egonce":
@@ -147,7 +184,10 @@ def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: O
         for p in model.parameters():
             p.grad = None
     loss, kld, nce, _ = compute_loss(cfg, model, batch["video"], batch["audio"], batch["labels_hm"], keep_masks)
-    backward_scaled(loss, optimizer)
+    if optimizer is not None:
+        backward_with_factors(cfg, model, loss, optimizer)
+    else:
+        backward_scaled(loss, optimizer)
     if isinstance(model, GradAllReduce):
         model.finish()
     if optimizer is not None:
@@ -294,7 +334,7 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss, kld, nce, _ = compute_loss(self.cfg, self.model, self.static["video"], self.static["audio"],
                                          self.static["labels_hm"])
-        backward_scaled(loss, self.opt)
+        backward_with_factors(self.cfg, self.model, loss, self.opt)
         if isinstance(self.model, GradAllReduce):
             self.model.finish()
         _clip_and_step(self.cfg, self.model, self.opt)
@@ -354,9 +394,11 @@ class SegmentedTrainStep:
         # outside the all-reduced prefix; the ranks all-gather dY / A (3.2 MB per conv) and form the averaged dW themselves.
         amd_ = getattr(cfg, "CSTS_AMD", None)
         self.factor_params = []
-        if self.dist and use_graphs and bool(getattr(amd_, "FUSION_GRAD_FACTORS", True)):
+        opt_factored = hasattr(optimizer, "set_factored") and bool(getattr(amd_, "FACTORED_ADAMW", False) or os.environ.get("CSTS_FACTORED_ADAMW", "0") == "1")
+        if use_graphs and ((self.dist and bool(getattr(amd_, "FUSION_GRAD_FACTORS", True))) or (not self.dist and opt_factored)):
             self.factor_params = [m.weight for m in (getattr(core, n, None) for n in ("vision_pool", "audio_pool", "audio_pool2"))
                                   if m is not None and m.weight.requires_grad]
+        self.opt_factored = opt_factored
         fid = {id(p) for p in self.factor_params}
         self.head_params = [p for p in self.head_params if id(p) not in fid] + self.factor_params
         hid = {id(p) for p in self.head_params}
@@ -599,10 +641,10 @@ class SegmentedTrainStep:
                 w.wait()
             self._raw_grads = [p.grad for ps in self.buckets for p in ps]   # graph-owned: keep them alive
             self._bucket16_back()
-            self._finish_factors()
             for k, ps in enumerate(self.buckets):
                 for p, v in zip(ps, self.flat[k][1]):
                     p.grad = v
+        self._finish_factors()
         self._segment("opt", lambda: _clip_and_step(cfg, self.model, self.opt), capture)
         del cut, cut2
         return res
@@ -651,6 +693,12 @@ class SegmentedTrainStep:
         from . import ops, lib as L
         if not self.factor_params:
             return
+        if self.opt_factored and all(self.opt.factored_ok(W, rows) for W, _, _, _, rows in self._gathered):
+            # few enough token rows (W * B * T' <= 64): the optimizer forms dW on the fly from the gathered factors
+            self.opt.set_factored([(W, gdy, gA) for W, gdy, gA, _, _ in self._gathered])
+            return
+        if hasattr(self.opt, "set_factored"):
+            self.opt.set_factored(None)
         tgt = self.averaged_grads()
         for W, gdy, gA, compute, rows in self._gathered:
             out = tgt[W].view(W.shape[0], -1)

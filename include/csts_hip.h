@@ -32,10 +32,10 @@ enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 
 /* Version of this header's struct layouts and call semantics.  Bumped whenever a struct grows or a field changes meaning
- * (2: csts_gemm_args.res_up; 3: fused-MLP entry points, compact K|V pooling).  csts_abi_version() returns the value the
+ * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW).  csts_abi_version() returns the value the
  * LIBRARY was built with: a caller must compare it with the CSTS_ABI_VERSION it was compiled against and refuse a mismatch
  * (the Python binding does, csts_amd/lib.py::load). */
-#define CSTS_ABI_VERSION 3
+#define CSTS_ABI_VERSION 4
 const char* csts_last_error(void);
 int csts_abi_version(void);
 int csts_half_kind(void);   /* the 16-bit type behind CSTS_BF16 in THIS library: 0 bfloat16 (libcsts_hip.so), 1 IEEE half (libcsts_hip_f16.so) */
@@ -318,8 +318,30 @@ typedef struct {
    * (scaler.unscale_); a non-finite norm SKIPS the step (no parameter, moment or step-count change; state[3] = 1) and multiplies
    * the scale by backoff; growth_interval consecutive good steps multiply it by growth (scaler.update()). */
   float* scaler; float growth, backoff; int growth_interval;
+  /* optional: extra_sq[0 .. n_extra_sq) device floats added to the sum of squared gradients before the norm is taken -- the
+   * squared norms of gradients that are never materialised (csts_adamw_factored); they are in the same (loss-scaled) units as
+   * the gradients */
+  const float* extra_sq; int n_extra_sq;
 } csts_opt_args;
 int csts_adamw_step(const csts_opt_args* args, hipStream_t stream);
+
+/* Factored AdamW: the weight gradient of a fusion conv (custom_multimodal_builder.py:227-229) is dW[N][K] = dY[T][N]^T A[T][K]
+ * with T = B * T' token rows (32 at b = 4, 16 frames) for N x K = 768 x 49152 -- a rank-T update.  Instead of writing dW to
+ * memory (151 MB, read twice by the clip norm and the update) the optimizer forms g = dY^T A ON THE FLY, in fp32, inside the
+ * update of p / m / v (same AdamW arithmetic, same clip coefficient and loss-scale handling as csts_adamw_step, whose `state`
+ * it reads -- call it after csts_adamw_step of the same iteration).  csts_factored_sqnorm gives the squared Frobenius norm of
+ * every item's never-materialised gradient for that step's clip norm (csts_opt_args.extra_sq) as
+ * sum_{t,t'} (dY dY^T)[t,t'] (A A^T)[t,t'], from T x T Gram matrices.  dy fp32 [T][N]; a [T][K] in a_dt; T <= 64, K % 256 == 0,
+ * N % 16 == 0.  workspace: csts_factored_sqnorm_workspace(items) bytes. */
+typedef struct {
+  float* p; float* m; float* v; void* w16;
+  const float* dy; const void* a; int a_dt;
+  int N, K, T; float weight_decay; int pad_;
+} csts_opt_factored;
+size_t csts_factored_sqnorm_workspace(const csts_opt_factored* items, int nitems);
+int csts_factored_sqnorm(const csts_opt_factored* items, int nitems, float* out_sq, void* workspace, size_t ws_bytes, hipStream_t stream);
+int csts_adamw_factored(const csts_opt_factored* items, int nitems, const float* state, const float* lr, float beta1, float beta2,
+                        float eps, hipStream_t stream);
 
 /* ---- evaluation metric ("next" row): metrics.adaptive_f1 (slowfast/utils/metrics.py:9-74) with the
  *      per-frame min-max rescale of its callers (tools/test_avgaze_net.py:66-68, tools/train_avgaze_net.py:125-127) folded

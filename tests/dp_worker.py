@@ -37,7 +37,8 @@ def main():
     cfg = load_yaml(os.path.join(ROOT, "configs/Ego4D/CSTS_Ego4D_Gaze_Forecast.yaml"),
                     ["NUM_GPUS", 1, "MODEL.LOSS_FUNC", "kldiv+egonce", "DATA.NUM_FRAMES", 8, "CSTS_AMD.COMPUTE", compute,
                      "CSTS_AMD.TRUNK_CUT", trunk_cut, "CSTS_AMD.GRAD_BUCKET_DTYPE", bucket_dtype,
-                     "CSTS_AMD.FUSION_GRAD_FACTORS", factors])
+                     "CSTS_AMD.FUSION_GRAD_FACTORS", factors,
+                     "CSTS_AMD.FACTORED_ADAMW", (len(sys.argv) > 9 and sys.argv[9] == "factored_adamw")])
     core = build_model(cfg)
     core.load_state_dict(O.seeded_params(8, 256), strict=True)
     core.eval()                                        # drop-path off: the fixture is an eval-mode forward + backward

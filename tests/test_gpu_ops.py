@@ -626,6 +626,66 @@ def test_fused_adamw_matches_torch_clip_plus_adamw():
     assert rel_l2(fused._m[[id(p) for p in fused.params].index(id(pa[3]))].view_as(m_ref), m_ref) < 1e-6
 
 
+@pytest.mark.parametrize("a_dtype", [torch.bfloat16, torch.float32])
+def test_factored_adamw_matches_dense_gradient(a_dtype):
+    """csts_factored_sqnorm + csts_adamw_factored (FusedAdamW.set_factored): a weight whose gradient is dW = dY^T A with few token
+    rows (the (1,8,8) fusion convs, custom_multimodal_builder.py:227-229) is updated from the FACTORS -- the clip norm from T x T
+    Gram matrices, g formed on the fly in fp32 -- and must equal clip_grad_norm_ + torch AdamW on the materialised dW; other
+    parameters of the same optimizer take the ordinary path in the same step.  Also: loss-scaled factors and a skipped step."""
+    from csts_amd.optim import FusedAdamW
+    N, K, T2 = 48, 1024, 32
+    shapes = [(N, 4, 16, 16), (64, 2, 8, 32), (300,), (96, 32)]          # two "fusion convs" (N x K = 48 x 1024, 64 x 512) + ordinary ones
+    pa = [rnd(*s, seed=10 + i, scale=0.5).requires_grad_() for i, s in enumerate(shapes)]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    ga = [{"params": [pa[0], pa[1], pa[3]], "weight_decay": 0.05}, {"params": [pa[2]], "weight_decay": 0.0}]
+    gb = [{"params": [pb[0], pb[1], pb[3]], "weight_decay": 0.05}, {"params": [pb[2]], "weight_decay": 0.0}]
+    shadow = torch.empty(shapes[0], dtype=torch.bfloat16, device=DEV)
+    fused = FusedAdamW(ga, lr=1e-3, eps=1e-8, max_grad_norm=1.0, shadows={id(pa[0]): shadow})
+    ref = torch.optim.AdamW(gb, lr=1e-3, eps=1e-8, weight_decay=0.05)
+    for step, gscale in enumerate([1.0, 1e-3, 2.0]):                      # clipped, un-clipped, clipped
+        facs = []
+        for i, Tn in ((0, T2), (1, 8)):
+            n, k = shapes[i][0], pa[i].numel() // shapes[i][0]
+            dy = rnd(Tn, n, seed=50 * step + i, scale=gscale)
+            a = rnd(Tn, k, seed=70 * step + i).to(a_dtype)
+            facs.append((pa[i], dy, a))
+            pb[i].grad = (dy.t() @ a.float()).view(shapes[i])
+            pa[i].grad = None
+        for i in (2, 3):
+            g = rnd(*shapes[i], seed=100 * step + i, scale=gscale)
+            pa[i].grad, pb[i].grad = g.clone(), g.clone()
+        fused.set_factored(facs)
+        norm_ref = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ref.step()
+        fused.step()
+        assert abs(float(fused.grad_norm) - float(norm_ref)) < 2e-5 * float(norm_ref), (step, float(fused.grad_norm), float(norm_ref))
+        for i, (a_, b_) in enumerate(zip(pa, pb)):
+            assert rel_l2(a_.detach(), b_.detach()) < 3e-6, (step, i)
+    assert torch.equal(shadow, pa[0].detach().bfloat16())
+    fused.set_factored(None)
+    # loss scaling: factors of the SCALED loss; an inf in a factor skips the whole step
+    fs = FusedAdamW([{"params": [pa[0], pa[2]], "weight_decay": 0.0}], lr=1e-3, max_grad_norm=1.0, loss_scaling=True, init_scale=1024.0)
+    before = [p.detach().clone() for p in (pa[0], pa[2])]
+    dy, a = rnd(T2, N, seed=1), rnd(T2, K, seed=2).to(a_dtype)
+    ref2 = torch.optim.AdamW([pb[0], pb[2]], lr=1e-3, eps=1e-8, weight_decay=0.0)
+    pb[0].data.copy_(pa[0].data); pb[2].data.copy_(pa[2].data)
+    g2 = rnd(300, seed=3)
+    pb[0].grad, pb[2].grad = (dy.t() @ a.float()).view(shapes[0]), g2.clone()
+    pa[0].grad, pa[2].grad = None, g2 * 1024.0
+    fs.set_factored([(pa[0], dy * 1024.0, a)])
+    nr = torch.nn.utils.clip_grad_norm_([pb[0], pb[2]], 1.0)
+    ref2.step(); fs.step()
+    assert abs(float(fs.grad_norm) - float(nr)) < 2e-5 * float(nr)
+    assert rel_l2(pa[0].detach(), pb[0].detach()) < 3e-6 and rel_l2(pa[2].detach(), pb[2].detach()) < 3e-6
+    keep = [pa[0].detach().clone(), pa[2].detach().clone()]
+    bad = dy * 1024.0
+    bad[3, 5] = float("inf")
+    fs.set_factored([(pa[0], bad, a)])
+    fs.step()
+    assert float(fs.state_t[3]) == 1.0 and float(fs.loss_scale) == 512.0
+    assert torch.equal(pa[0].detach(), keep[0]) and torch.equal(pa[2].detach(), keep[1])
+
+
 # ------------------------------------------------------------------------------------------------ evaluation metric
 def test_adaptive_f1_on_device():
     """csts_adaptive_f1 (min-max rescale folded in) == the reference's adaptive_f1 (fixture generated by importing
