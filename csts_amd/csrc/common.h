@@ -33,6 +33,57 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
 
+// Streaming cache policy for tensors that are far larger than the caches and touched once per kernel (tools/launch_floor.hip,
+// profiles/r4_stream_policy.txt: c = f(a, b) over 3 x 200 MB: plain loads + stores 5.5 TB/s, nontemporal loads 6.7 TB/s; below
+// ~50 MB per tensor the plain forms win -- the producer's lines are still in the memory-side cache).  Used by the optimizer
+// (6.4 GB per step, nothing re-read): clip + AdamW 1.20 -> 1.03 ms.
+// -DCSTS_NO_STREAM_POLICY gives the plain forms back (same-box A/B builds).
+__device__ __forceinline__ f32x4 ld_stream(const f32x4* p) {
+#ifdef CSTS_NO_STREAM_POLICY
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ bf16x4 ld_stream(const bf16x4* p) {
+#ifdef CSTS_NO_STREAM_POLICY
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ bf16x8 ld_stream(const bf16x8* p) {
+#ifdef CSTS_NO_STREAM_POLICY
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+// Write-through ("sc0 sc1") stores through a buffer descriptor (the compiler schedules and pads them itself; an inline-asm
+// global_store_dwordx4 needs a manual wait state after it -- without one the data registers were overwritten too early: NaNs in a
+// GEMM epilogue that tried it).  Only for tensors no kernel reads soon: a consumer that would have found the lines in the
+// memory-side cache gets slower (profiles/r4_stream_policy.txt).  base: wave-uniform; off: bytes, < 2^31.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+struct StreamOut {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ StreamOut(void* base, int64_t bytes) : rsrc(__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000)) {}
+  __device__ __forceinline__ void st16(int off, f32x4 v) const {
+#ifdef CSTS_NO_STREAM_POLICY
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, off, 0, 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, off, 0, 17);
+#endif
+  }
+  __device__ __forceinline__ void st8(int off, bf16x4 v) const {
+#ifdef CSTS_NO_STREAM_POLICY
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rsrc, off, 0, 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), rsrc, off, 0, 17);
+#endif
+  }
+};
+
 // 16-bit element(s) held as raw bits -> float: element 0 / 1 of a 32-bit pair, or one 16-bit value
 __device__ __forceinline__ float h16_lo(unsigned v) {
 #ifdef CSTS_HALF_F16

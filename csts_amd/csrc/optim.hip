@@ -28,9 +28,16 @@ template <bool G16> __device__ __forceinline__ float ldg(const void* g, int64_t 
 }
 template <bool G16> __device__ __forceinline__ float4 ldg4(const void* g, int64_t i4) {
   if constexpr (G16) {
-    const bf16x4 v = reinterpret_cast<const bf16x4*>(g)[i4];
+    const bf16x4 v = ld_stream(reinterpret_cast<const bf16x4*>(g) + i4);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-  } else return reinterpret_cast<const float4*>(g)[i4];
+  } else {
+    const f32x4 v = ld_stream(reinterpret_cast<const f32x4*>(g) + i4);
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+__device__ __forceinline__ float4 ld4s(const float* p, int64_t i4) {
+  const f32x4 v = ld_stream(reinterpret_cast<const f32x4*>(p) + i4);
+  return make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // partial[chunk] = sum g^2 over the chunk (fixed summation order: reproducible)
@@ -153,21 +160,23 @@ __global__ __launch_bounds__(OPT_THREADS) void opt_adamw_kernel(OptTables t, int
   int64_t done = 0;
   if (vec) {
     const int64_t n4 = n / OPT_VEC;
+    const StreamOut sp(p, n * 4), sm(m, n * 4), sv(v, n * 4), sw(w16 ? (void*)w16 : (void*)p, n * 2);     // chunk_elems * 4 < 2^31 (csts_adamw_step)
+    auto f4 = [](const float4& x) { f32x4 o; o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; return o; };
     for (int64_t i = threadIdx.x; i < n4; i += OPT_THREADS) {
-      float4 pp = reinterpret_cast<float4*>(p)[i];
+      float4 pp = ld4s(p, i);
       const float4 gg = ldg4<G16>(g, i);
-      float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+      float4 mm = ld4s(m, i), vv = ld4s(v, i);
       adamw_one(pp.x, gg.x, mm.x, vv.x, clip, lr, tt.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
       adamw_one(pp.y, gg.y, mm.y, vv.y, clip, lr, tt.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
       adamw_one(pp.z, gg.z, mm.z, vv.z, clip, lr, tt.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
       adamw_one(pp.w, gg.w, mm.w, vv.w, clip, lr, tt.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
-      reinterpret_cast<float4*>(p)[i] = pp;
-      reinterpret_cast<float4*>(m)[i] = mm;
-      reinterpret_cast<float4*>(v)[i] = vv;
+      sp.st16((int)i * 16, f4(pp));
+      sm.st16((int)i * 16, f4(mm));
+      sv.st16((int)i * 16, f4(vv));
       if (w16) {
         bf16x4 w;
         w[0] = (bf16)pp.x; w[1] = (bf16)pp.y; w[2] = (bf16)pp.z; w[3] = (bf16)pp.w;
-        reinterpret_cast<bf16x4*>(w16)[i] = w;
+        sw.st8((int)i * 8, w);
       }
     }
     done = n4 * OPT_VEC;
@@ -366,7 +375,7 @@ extern "C" int csts_adamw_factored(const csts_opt_factored* items, int nitems, c
 
 extern "C" int csts_adamw_step(const csts_opt_args* a, hipStream_t stream) {
   CSTS_REQUIRE(a != nullptr, "null args");
-  CSTS_REQUIRE(a->nchunks > 0 && a->ntensors > 0 && a->chunk_elems > 0 && a->chunk_elems % 4 == 0, "bad chunking");
+  CSTS_REQUIRE(a->nchunks > 0 && a->ntensors > 0 && a->chunk_elems > 0 && a->chunk_elems % 4 == 0 && a->chunk_elems <= (1 << 28), "bad chunking");
   CSTS_REQUIRE(a->chunk_tensor && a->chunk_off && a->tensors && a->grads, "null table");
   CSTS_REQUIRE(a->partial && a->state && a->lr, "null state");
   CSTS_REQUIRE(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f && a->eps > 0.f, "bad hyper-parameters");

@@ -11,6 +11,9 @@
 //                      custom_multimodal_builder.py:479)
 // HBM-bound kernels: channels are the fastest index, consecutive lanes -> consecutive channels.
 #include "common.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace {
 
@@ -579,19 +582,17 @@ struct WgSlots2 {
   const void* coarse[2];
   float* ws[2];
 };
+// One workgroup's share: channel slab bx of nbx, coarse-token chunk by; thread (tx, ty) = (channel pair, token lane) of
+// (slab / 2) x lanes.  Threads with ty >= lanes (the grouped launch's fixed-size workgroups) only take part in the barriers.
 template <bool FF32, bool CF32>
-__global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [slab][27]
-  const void* __restrict__ fine = sl.fine[blockIdx.z];
-  const void* __restrict__ coarse = sl.coarse[blockIdx.z];
-  float* __restrict__ ws = sl.ws[blockIdx.z];
-  const Geom& g = rg.g;
-  const int tx = threadIdx.x, ty = threadIdx.y;
+__device__ __forceinline__ void dwconv_wgrad_body(const Geom& g, const void* __restrict__ fine, const void* __restrict__ coarse,
+                                                  float* __restrict__ ws, int slab, int chunk, int bx, int by, int nbx, int tx, int ty,
+                                                  int lanes, int nthr, float* __restrict__ red) {
   const int cl = 2 * tx;
-  const int c = blockIdx.x * slab + cl;
+  const int c = bx * slab + cl;
   const int ntok = g.Tc * g.Hc * g.Wc;
   const int total = g.B * ntok;
-  const int beg = blockIdx.y * chunk, end = min(total, beg + chunk);
+  const int beg = by * chunk, end = ty < lanes ? min(total, beg + chunk) : 0;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   float a0[27], a1[27];
 #pragma unroll
@@ -600,7 +601,7 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
   // token were a quarter of this loop's vector instructions)
   int b = 0, ot = 0, oh = 0, ow = 0;
   if (beg + ty < end) decomp(beg + ty, ntok, g.Hc, g.Wc, b, ot, oh, ow);
-  const int tstep = blockDim.y;
+  const int tstep = lanes;
   for (int bt = beg + ty; bt < end; bt += tstep) {
     int tof[3], hof[3], xof[3];
     bool tv[3], hv[3], xv[3];
@@ -678,7 +679,7 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
     for (int k = 0; k < 27; ++k) { red[cl * 27 + k] = a0[k]; red[(cl + 1) * 27 + k] = a1[k]; }
   }
   __syncthreads();
-  for (int l = 1; l < (int)blockDim.y; ++l) {
+  for (int l = 1; l < lanes; ++l) {
     if (ty == l) {
       float t0[27], t1[27];
 #pragma unroll
@@ -689,14 +690,45 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
     __syncthreads();
   }
   const int heads_in_slab = slab / g.HD;
-  float* out = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * g.HD * 27;
-  const int tid = ty * blockDim.x + tx, nthr = blockDim.x * blockDim.y;
+  float* out = ws + ((int64_t)by * nbx + bx) * g.HD * 27;
+  const int tid = ty * (slab / 2) + tx;
   for (int i = tid; i < g.HD * 27; i += nthr) {
     const int cc = i / 27, k = i - cc * 27;
     float s2 = 0.f;
     for (int hh = 0; hh < heads_in_slab; ++hh) s2 += red[(cc + hh * g.HD) * 27 + k];
     out[i] = s2;
   }
+}
+
+template <bool FF32, bool CF32>
+__global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [slab][27]
+  dwconv_wgrad_body<FF32, CF32>(rg.g, sl.fine[blockIdx.z], sl.coarse[blockIdx.z], sl.ws[blockIdx.z], slab, chunk, blockIdx.x, blockIdx.y,
+                                gridDim.x, threadIdx.x, threadIdx.y, blockDim.y, blockDim.x * blockDim.y, red);
+}
+
+// Grouped form (csts_dwconv_wgrad_grouped): every stencil weight gradient of a backward pass in ONE launch.  The item table
+// lives in device memory (written by csts_dwconv_wgrad_grouped_plan on the host, uploaded by the caller); workgroup -> item by
+// the items' first-block numbers (items sorted longest workgroups first), fixed 512-thread workgroups cut into
+// (slab / 2) x lanes like the single launch's.
+struct WgItem {
+  Geom g;
+  const void* fine; const void* coarse; float* ws;
+  int slab, chunk, nslab, lanes;
+  int block_begin, nblocks;
+};
+constexpr int WG_GROUP_THREADS = 512;
+template <bool F32>
+__global__ __launch_bounds__(WG_GROUP_THREADS) void dwconv_wgrad_grouped_kernel(const WgItem* __restrict__ items, int nitems) {
+  __shared__ __attribute__((aligned(16))) float red[192 * 27];
+  int it = 0;
+  while (it + 1 < nitems && (int)blockIdx.x >= items[it + 1].block_begin) ++it;
+  const WgItem& w = items[it];
+  const int local = blockIdx.x - w.block_begin;
+  const int half = w.slab / 2;
+  const int ty = threadIdx.x / half, tx = threadIdx.x - ty * half;
+  dwconv_wgrad_body<F32, F32>(w.g, w.fine, w.coarse, w.ws, w.slab, w.chunk, local % w.nslab, local / w.nslab, w.nslab, tx, ty, w.lanes,
+                              WG_GROUP_THREADS, red);
 }
 
 // ------------------------------------------------------------------ max-pool skip
@@ -1211,6 +1243,49 @@ extern "C" int csts_dwconv_wgrad2(const csts_dwconv_geom* a, const void* const f
                                   int coarse_dt, float* const dweight[2], void* workspace, size_t ws_bytes, hipStream_t stream) {
   CSTS_REQUIRE(fine && coarse, "null pointer");
   return wgrad_launch(a, 2, fine, fine_dt, coarse, coarse_dt, dweight, workspace, ws_bytes, stream);
+}
+
+static_assert(sizeof(WgItem) == CSTS_DWCONV_WGRAD_TABLE_ENTRY, "device table entry size is part of the C-ABI");
+
+extern "C" int csts_dwconv_wgrad_grouped_plan(const csts_dwconv_wgrad_item* items, int nitems, void* table_host, size_t table_bytes,
+                                              int* nblocks) {
+  CSTS_REQUIRE(items != nullptr && table_host != nullptr && nblocks != nullptr && nitems > 0, "null argument");
+  CSTS_REQUIRE(table_bytes >= (size_t)nitems * sizeof(WgItem), "table too small");
+  std::vector<WgItem> tab((size_t)nitems);
+  for (int i = 0; i < nitems; ++i) {
+    const csts_dwconv_geom* a = &items[i].geom;
+    CHECK_GEOM(a);
+    CSTS_REQUIRE(items[i].fine && items[i].coarse && items[i].workspace, "null pointer");
+    int slab, nslab; int64_t chunk, nchunk;
+    wgrad_plan(a, slab, nslab, chunk, nchunk);
+    CSTS_REQUIRE(a->C % slab == 0 && slab % a->HD == 0 && slab % 2 == 0 && slab <= 192, "channel slab must hold whole heads");
+    RowGeom rg; fill_geom(a, rg);
+    WgItem& w = tab[(size_t)i];
+    w.g = rg.g;
+    w.fine = items[i].fine; w.coarse = items[i].coarse; w.ws = reinterpret_cast<float*>(items[i].workspace);
+    w.slab = slab; w.chunk = (int)chunk; w.nslab = nslab;
+    w.lanes = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, WG_GROUP_THREADS / (slab / 2)), chunk / 2));
+    w.nblocks = (int)(nchunk * nslab);
+    w.block_begin = 0;
+  }
+  // longest workgroups first (tokens per lane): the short ones fill the tail of the launch
+  std::stable_sort(tab.begin(), tab.end(), [](const WgItem& x, const WgItem& y) { return cdiv(x.chunk, x.lanes) > cdiv(y.chunk, y.lanes); });
+  int64_t at = 0;
+  for (auto& w : tab) { w.block_begin = (int)at; at += w.nblocks; }
+  CSTS_REQUIRE(at < ((int64_t)1 << 31), "too many workgroups");
+  std::memcpy(table_host, tab.data(), (size_t)nitems * sizeof(WgItem));
+  *nblocks = (int)at;
+  return 0;
+}
+
+extern "C" int csts_dwconv_wgrad_grouped(const void* table_dev, int nitems, int nblocks, int dt, hipStream_t stream) {
+  CSTS_REQUIRE(table_dev != nullptr && nitems > 0 && nblocks > 0, "null / empty table");
+  CSTS_REQUIRE(dt == CSTS_F32 || dt == CSTS_BF16, "bad dtype");
+  const WgItem* items = reinterpret_cast<const WgItem*>(table_dev);
+  if (dt == CSTS_F32) hipLaunchKernelGGL(dwconv_wgrad_grouped_kernel<true>, dim3((unsigned)nblocks), dim3(WG_GROUP_THREADS), 0, stream, items, nitems);
+  else hipLaunchKernelGGL(dwconv_wgrad_grouped_kernel<false>, dim3((unsigned)nblocks), dim3(WG_GROUP_THREADS), 0, stream, items, nitems);
+  CSTS_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int csts_pool_ln_fwd(const csts_pool_ln_args* a, hipStream_t stream) {

@@ -42,7 +42,7 @@ def half_dtype():
     return torch.float16 if HALF == "fp16" else torch.bfloat16
 
 
-ABI_VERSION = 4   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
+ABI_VERSION = 5   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
@@ -75,6 +75,13 @@ class DwconvGeom(C.Structure):
                 ("st", C.c_int), ("sh", C.c_int), ("sw", C.c_int),
                 ("fine_batch_stride", i64), ("fine_token_stride", i64),
                 ("coarse_batch_stride", i64), ("coarse_token_stride", i64)]
+
+
+class DwconvWgradItem(C.Structure):
+    _fields_ = [("geom", DwconvGeom), ("fine", vp), ("coarse", vp), ("workspace", vp)]
+
+
+DWCONV_WGRAD_TABLE_ENTRY = 128
 
 
 class PoolLnArgs(C.Structure):
@@ -172,6 +179,8 @@ SYMBOLS = {
     "csts_dwconv_wgrad": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, _I, vp, vp, sz, vp]),
     "csts_dwconv_transposed2": (_I, [C.POINTER(DwconvGeom), vp * 2, _I, vp * 2, vp * 2, _I, vp]),
     "csts_dwconv_wgrad2": (_I, [C.POINTER(DwconvGeom), vp * 2, _I, vp * 2, _I, vp * 2, vp, sz, vp]),
+    "csts_dwconv_wgrad_grouped_plan": (_I, [C.POINTER(DwconvWgradItem), _I, vp, sz, C.POINTER(C.c_int)]),
+    "csts_dwconv_wgrad_grouped": (_I, [vp, _I, _I, _I, vp]),
     "csts_pool_ln_fwd": (_I, [C.POINTER(PoolLnArgs), vp]),
     "csts_maxpool_fwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, vp, vp]),
     "csts_maxpool_bwd": (_I, [C.POINTER(PoolGeom), vp, _I, vp, vp, vp]),

@@ -160,6 +160,7 @@ def reset_deferred():
             st.synchronize()
         _sw_used[0] = False
     _sw_keep.clear()
+    _swq.clear()
     _deferred.clear()
     _assign.clear()
     _wgq.clear()
@@ -243,6 +244,7 @@ def flush_deferred():
     their parameters (idempotent)."""
     _deferred_task[0] = -1
     flush_wgrads()
+    flush_stencil_wgrads()
     _join_wgrad_side()
     _join_stencil_side()
     if not _deferred:
@@ -486,6 +488,51 @@ def flush_wgrads(side: bool = False):
     if side:
         _wg_pending.append((q, keep))      # alive until the final callback has joined the side stream
     del q, keep
+
+
+# Stencil weight gradients, grouped (csts_dwconv_wgrad_grouped): 34 first-stage launches of ~24 us per step -- each a single round
+# of <= 1024 latency-bound workgroups -- become ONE launch at the end of backward (their second stages were deferred already).
+# Same policy as the grouped Linear weight gradients: while the step is captured (GROUP_WGRADS), and only when the gradient may be
+# deferred; the operands (the saved q / k / v tensors and the conv-output gradients) stay alive until the flush.
+STENCIL_WGRAD_GROUPED = os.environ.get("CSTS_STENCIL_WGRAD_GROUPED", "1") != "0"
+_swq = []               # (DwconvGeom copy, fine ptr, coarse ptr, workspace ptr, dt, (tensors kept alive))
+_swq_tables = {}        # device index -> HostTable
+
+
+def _stencil_group_now() -> bool:
+    return STENCIL_WGRAD_GROUPED and GROUP_WGRADS != "never" and (GROUP_WGRADS == "always" or torch.cuda.is_current_stream_capturing())
+
+
+def _queue_stencil_wgrad(g, fine, fine_off, coarse, coarse_off, ws):
+    """One csts_dwconv_wgrad problem for the grouped launch of flush_stencil_wgrads (first stage only: the caller defers the row sums
+    of `ws` itself)."""
+    gg = L.DwconvGeom()
+    C.memmove(C.byref(gg), C.byref(g), C.sizeof(L.DwconvGeom))
+    _swq.append((gg, _p(fine, fine_off), _p(coarse, coarse_off), _p(ws), _dt(fine), (fine, coarse, ws)))
+
+
+def flush_stencil_wgrads():
+    if not _swq:
+        return
+    q = list(_swq)
+    _swq.clear()
+    dev = q[0][5][0].device
+    tab = _swq_tables.get(dev.index)
+    if tab is None:
+        tab = _swq_tables[dev.index] = HostTable(L.DWCONV_WGRAD_TABLE_ENTRY * 256, dev, ring=4, captures=16)
+    for dt in sorted({e[4] for e in q}):
+        sel = [e for e in q if e[4] == dt]
+        if len(sel) > 256:
+            raise L.CstsError("too many grouped stencil weight gradients")
+        items = (L.DwconvWgradItem * len(sel))()
+        for i, (gg, fp, cp, wp, _, _) in enumerate(sel):
+            items[i].geom, items[i].fine, items[i].coarse, items[i].workspace = gg, fp, cp, wp
+        image = (C.c_uint8 * (L.DWCONV_WGRAD_TABLE_ENTRY * len(sel)))()
+        nblocks = C.c_int(0)
+        L.check(_lib().csts_dwconv_wgrad_grouped_plan(items, len(sel), image, len(image), C.byref(nblocks)), "csts_dwconv_wgrad_grouped_plan")
+        ptr = tab.upload(bytes(image))
+        L.check(_lib().csts_dwconv_wgrad_grouped(ptr, len(sel), nblocks.value, dt, _stream()), "csts_dwconv_wgrad_grouped")
+    del q
 
 
 # Stencil weight gradients (csts_dwconv_wgrad / _wgrad2: 34 launches of ~24 us per step, latency-bound, 0.16 of the HBM roofline)
@@ -1190,10 +1237,18 @@ class AttnInnerFn(Function):
             dw = torch.empty(HD * 27, dtype=torch.float32, device=dev)
             defer = _can_defer(pw)
             dwp = None if defer else _p(dw)
-            side = _stencil_side(dc, qkv, wws) if (defer and STENCIL_WGRAD_SIDE) else None
+            grouped = defer and _stencil_group_now()
+            if grouped:
+                if transposed:
+                    _queue_stencil_wgrad(g, dc, 0, qkv, slot * Cc, wws)
+                else:
+                    _queue_stencil_wgrad(g, qkv, slot * Cc, dc, 0, wws)
+            side = _stencil_side(dc, qkv, wws) if (defer and not grouped and STENCIL_WGRAD_SIDE) else None
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 sw = _stream()
-                if transposed:   # fine = dc (output side), coarse = qkv slot
+                if grouped:
+                    pass
+                elif transposed:   # fine = dc (output side), coarse = qkv slot
                     L.check(lib.csts_dwconv_wgrad(C.byref(g), _p(dc), _dt(dc), _p(qkv, slot * Cc), _dt(qkv), dwp, _p(wws),
                                                   wws.numel(), sw), "csts_dwconv_wgrad")
                 else:            # fine = qkv slot, coarse = dc
@@ -1237,9 +1292,14 @@ class AttnInnerFn(Function):
             wws = _ws(2 * wsz, dev)
             dw = torch.empty(2, HD * 27, dtype=torch.float32, device=dev)
             dwp = vp2(None, None) if defer else vp2(_p(dw[0]), _p(dw[1]))
-            side = _stencil_side(dc2, kv_fine, wws) if (defer and STENCIL_WGRAD_SIDE) else None
+            grouped = defer and _stencil_group_now()
+            if grouped:
+                for i in (0, 1):
+                    _queue_stencil_wgrad(g, kv_fine, kv_off[i], dc2[i], 0, wws[i * wsz:(i + 1) * wsz])
+            side = _stencil_side(dc2, kv_fine, wws) if (defer and not grouped and STENCIL_WGRAD_SIDE) else None
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(kv_fine, kv_off[0]), _p(kv_fine, kv_off[1])), _dt(kv_fine),
+                if not grouped:
+                    L.check(lib.csts_dwconv_wgrad2(C.byref(g), vp2(_p(kv_fine, kv_off[0]), _p(kv_fine, kv_off[1])), _dt(kv_fine),
                                                vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), dwp, _p(wws), wws.numel(), _stream()), "csts_dwconv_wgrad2")
             if defer:
                 nrow = wsz // (HD * 27 * 4)

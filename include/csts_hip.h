@@ -32,10 +32,10 @@ enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 
 /* Version of this header's struct layouts and call semantics.  Bumped whenever a struct grows or a field changes meaning
- * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW).  csts_abi_version() returns the value the
+ * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients).  csts_abi_version() returns the value the
  * LIBRARY was built with: a caller must compare it with the CSTS_ABI_VERSION it was compiled against and refuse a mismatch
  * (the Python binding does, csts_amd/lib.py::load). */
-#define CSTS_ABI_VERSION 4
+#define CSTS_ABI_VERSION 5
 const char* csts_last_error(void);
 int csts_abi_version(void);
 int csts_half_kind(void);   /* the 16-bit type behind CSTS_BF16 in THIS library: 0 bfloat16 (libcsts_hip.so), 1 IEEE half (libcsts_hip_f16.so) */
@@ -158,6 +158,22 @@ int csts_dwconv_transposed2(const csts_dwconv_geom* g, const void* const coarse[
                             void* const fine[2], int fine_dt, hipStream_t stream);
 int csts_dwconv_wgrad2(const csts_dwconv_geom* g, const void* const fine[2], int fine_dt, const void* const coarse[2],
                        int coarse_dt, float* const dweight[2], void* workspace, size_t ws_bytes, hipStream_t stream);
+/* Grouped first stage: every stencil weight gradient of a backward pass (the q / k / v pools of all blocks, attention.py:104-116,
+ * and the decoder's transposed convs, :344-348) in ONE launch instead of one ~24 us latency-bound launch each.  Item i is one
+ * csts_dwconv_wgrad problem whose partial rows go to its own workspace (csts_dwconv_wgrad_workspace(&geom) bytes; rows =
+ * bytes / (HD*27*4)); the second stage (the row sums) is the caller's, exactly as with dweight NULL above.  _plan runs on the
+ * host: it validates the items and writes the DEVICE TABLE IMAGE (nitems * CSTS_DWCONV_WGRAD_TABLE_ENTRY bytes, items
+ * re-ordered longest workgroups first) into table_host and the grid size into *nblocks; the caller copies the image to device
+ * memory in stream order and passes that address to csts_dwconv_wgrad_grouped.  All items of a call share dtype dt. */
+typedef struct {
+  csts_dwconv_geom geom;
+  const void* fine; const void* coarse;
+  void* workspace;
+} csts_dwconv_wgrad_item;
+#define CSTS_DWCONV_WGRAD_TABLE_ENTRY 128
+int csts_dwconv_wgrad_grouped_plan(const csts_dwconv_wgrad_item* items, int nitems, void* table_host, size_t table_bytes, int* nblocks);
+int csts_dwconv_wgrad_grouped(const void* table_dev, int nitems, int nblocks, int dt, hipStream_t stream);
+
 /* attention_pool fused (attention.py:11-49): depthwise Conv3d k=3 p=1 stride s of the head-split q/k/v slot + LayerNorm(hd)
  * of the pooled rows, for nslots (1 or 2) tensors sharing the geometry.  conv_out = pre-LN pooled tensor (needed by
  * backward), y = normalised tensor, mean/rstd fp32 [B * N_coarse * heads]; all tensors of dtype dt. */

@@ -452,8 +452,18 @@ def test_gradient_accumulation_and_failed_backward():
     batch = T.synthetic_batch(2, 8, 256, 31, DEV)
     old_mode, ops.GROUP_WGRADS = ops.GROUP_WGRADS, "always"
     try:
-        _train_pass(m, cfg, batch)
+        assert ops.STENCIL_WGRAD_GROUPED
+        ops.STENCIL_WGRAD_GROUPED = False     # (c) the pools' stencil weight gradients: one launch each ...
+        try:
+            _train_pass(m, cfg, batch)
+            one_by_one = {n: p.grad.clone() for n, p in m.named_parameters() if "pool" in n and p.dim() == 5 and p.shape[1] == 1}
+        finally:
+            ops.STENCIL_WGRAD_GROUPED = True
+        assert len(one_by_one) >= 40
+        _train_pass(m, cfg, batch)            # ... == all of them in ONE grouped launch, bit for bit
         ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+        for n, g1 in one_by_one.items():
+            assert torch.equal(ref[n], g1), n
         loss, *_ = T.compute_loss(cfg, m, batch["video"], batch["audio"], batch["labels_hm"])
         loss.backward()                       # no zero_grad in between: accumulate
         torch.cuda.synchronize()

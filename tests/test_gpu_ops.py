@@ -585,6 +585,63 @@ def test_grouped_weight_gradients_match_inline():
         assert rel_l2(a, r.grad) < 2e-2
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_grouped_stencil_weight_gradients_are_bit_identical(dt):
+    """csts_dwconv_wgrad_grouped (every pool's first stage in ONE launch; raw C-ABI calls) leaves exactly the partial rows that
+    csts_dwconv_wgrad with dweight NULL leaves per problem -- mixed geometries in one call: stride 1 / 2 / 8 / compact (1,3,3),
+    head dims 96 / 192 / 32, ragged grids, operands read in place inside 3C-wide buffers; the row sums then equal the gradient of
+    torch's grouped conv3d (attention.py:104-116)."""
+    import ctypes as C
+    lib = L.load()
+    cdt = L.F32 if dt == torch.float32 else L.BF16
+    st_ = torch.cuda.current_stream().cuda_stream
+    cases = [  # B, C, HD, fine thw, stride
+        (2, 384, 96, (4, 8, 8), (1, 1, 1)), (2, 192, 96, (4, 9, 7), (1, 2, 2)), (1, 96, 96, (2, 16, 16), (1, 8, 8)),
+        (2, 768, 96, (4, 4, 4), (1, 1, 1)), (1, 192, 192, (2, 6, 10), (1, 2, 2)), (2, 64, 32, (3, 11, 8), (1, 3, 3)),
+        (3, 96, 96, (1, 5, 5), (1, 1, 1)),
+    ]
+    probs = []
+    for i, (B, Cc, HD, fthw, st) in enumerate(cases):
+        cthw = [(f - 1) // s_ + 1 for f, s_ in zip(fthw, st)]
+        Nf, Nc = fthw[0] * fthw[1] * fthw[2], cthw[0] * cthw[1] * cthw[2]
+        fine = rnd(B, Nf, 3 * Cc, seed=10 + i).to(dt)            # the conv reads slot 1 of a qkv-shaped buffer
+        coarse = rnd(B, Nc, Cc, seed=40 + i).to(dt)
+        g = L.DwconvGeom()
+        g.B, g.C, g.HD = B, Cc, HD
+        g.Tf, g.Hf, g.Wf = fthw; g.Tc, g.Hc, g.Wc = cthw; g.st, g.sh, g.sw = st
+        g.fine_batch_stride, g.fine_token_stride = Nf * 3 * Cc, 3 * Cc
+        g.coarse_batch_stride, g.coarse_token_stride = Nc * Cc, Cc
+        wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
+        ws_one = torch.zeros(wsz // 4, dtype=torch.float32, device=DEV)
+        ws_grp = torch.full((wsz // 4,), float("nan"), dtype=torch.float32, device=DEV)
+        fptr = fine.data_ptr() + Cc * fine.element_size()
+        L.check(lib.csts_dwconv_wgrad(C.byref(g), fptr, cdt, coarse.data_ptr(), cdt, None, ws_one.data_ptr(), wsz, st_), "single")
+        probs.append((g, fine, fptr, coarse, ws_one, ws_grp, (B, Cc, HD, fthw, cthw, st, Nf, Nc)))
+    items = (L.DwconvWgradItem * len(probs))()
+    for i, (g, fine, fptr, coarse, ws_one, ws_grp, _) in enumerate(probs):
+        items[i].geom, items[i].fine, items[i].coarse, items[i].workspace = g, fptr, coarse.data_ptr(), ws_grp.data_ptr()
+    image = (C.c_uint8 * (L.DWCONV_WGRAD_TABLE_ENTRY * len(probs)))()
+    nblocks = C.c_int(0)
+    L.check(lib.csts_dwconv_wgrad_grouped_plan(items, len(probs), image, len(image), C.byref(nblocks)), "plan")
+    assert nblocks.value > 0
+    table = torch.frombuffer(bytearray(bytes(image)), dtype=torch.uint8).to(DEV)
+    L.check(lib.csts_dwconv_wgrad_grouped(table.data_ptr(), len(probs), nblocks.value, cdt, st_), "grouped")
+    torch.cuda.synchronize()
+    for g, fine, fptr, coarse, ws_one, ws_grp, (B, Cc, HD, fthw, cthw, st, Nf, Nc) in probs:
+        assert torch.equal(ws_one, ws_grp), (Cc, HD, fthw, st)
+        dw = ws_grp.view(-1, HD * 27).sum(0).view(HD, 27)
+        x = fine[:, :, Cc:2 * Cc].float().reshape(B, *fthw, Cc).permute(0, 4, 1, 2, 3).requires_grad_(False)
+        w = torch.zeros(Cc, 1, 3, 3, 3, device=DEV, requires_grad=True)
+        y = F.conv3d(x, w, stride=st, padding=1, groups=Cc)
+        assert tuple(y.shape[2:]) == tuple(cthw)
+        y.backward(coarse.float().reshape(B, *cthw, Cc).permute(0, 4, 1, 2, 3))
+        ref = w.grad.view(Cc // HD, HD, 27).sum(0)               # the pools share one (hd, 27) weight over the heads
+        assert rel_l2(dw, ref) < (2e-5 if dt == torch.float32 else 2e-5), (Cc, HD, fthw, st)
+    # a table that is too small, and an empty call, are refused
+    assert lib.csts_dwconv_wgrad_grouped_plan(items, len(probs), image, 16, C.byref(nblocks)) != 0
+    assert lib.csts_dwconv_wgrad_grouped(table.data_ptr(), 0, 1, cdt, st_) != 0
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def test_fused_adamw_matches_torch_clip_plus_adamw():
     """csts_adamw_step == clip_grad_norm_(1.0) + torch.optim.AdamW(eps 1e-8) (train_avgaze_net.py:101-109,
