@@ -112,7 +112,7 @@ def get_cfg() -> CfgNode:
                        EPOCHS_THIS_RUN=0,            # > 0: stop this invocation after that many epochs (pre-emption; the next one auto-resumes)
                        EVAL_STEPS=2,                 # synthetic validation iterations of the periodic eval pass (TRAIN.EVAL_PERIOD)
                        GRAD_BUCKET_MB=64,
-                       FACTORED_ADAMW=False,         # (measured +0.1 .. +0.3 ms per step at b = 4, profiles/r4_factored_adamw_ab.txt: off) FusedAdamW forms the fusion convs' weight gradient dY^T A on the fly from its rank-(B T') factors (never written / re-read: 453 MB per step)
+                       FACTORED_ADAMW=True,          # 16-bit compute modes: FusedAdamW forms the fusion convs' weight gradient dY^T A on the matrix cores inside their update, from the rank-(B T') factors (never written / re-read: 453 MB per step; -0.3 ms at b = 4)
                        FUSION_GRAD_FACTORS=True,     # data-parallel chain: the ranks all-gather the rank-(B*T') factors of the three fusion-conv weight gradients (3.2 MB each) instead of all-reducing 151 MB each
                        GRAD_BUCKET_DTYPE="fp32",     # "bf16" / "fp16": data-parallel gradient buckets travel in the library's 16-bit type (half the xGMI bytes), fp32 accumulation in the optimizer
                        TRUNK_CUT=3,                  # data-parallel graph chain: second autograd cut in front of this video block (0 = trunks in one piece)

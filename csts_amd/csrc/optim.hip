@@ -226,19 +226,39 @@ __global__ __launch_bounds__(256) void factored_gram_kernel(FactoredList l, floa
     out[pr] = s;
   }
 }
-// out_sq[item] = sum_{t,t'} G1[t,t'] G2[t,t'],  G2 = sum of the slabs, G1 = dY dY^T   (fixed order: reproducible)
-__global__ __launch_bounds__(1024) void factored_sq_finish_kernel(FactoredList l, const float* __restrict__ ws, float* __restrict__ out_sq) {
-  __shared__ float red[1024 / WAVE];
-  const csts_opt_factored& it = l.it[blockIdx.x];
-  const int T = it.T, nslab = it.K / FK;
-  const float* w = ws + l.ws_off[blockIdx.x];
-  float acc = 0.f;
+// out_sq[item] = sum_{t,t'} G1[t,t'] G2[t,t'],  G2 = sum of the slabs, G1 = dY dY^T   (fixed order: reproducible).  Two stages: one
+// workgroup per item doing everything was a 430 us serial chain (192 slabs + 2 x 768 dY values per pair and thread); part b of
+// FPARTS sums the slabs s = b mod FPARTS and the dY columns of its N / FPARTS range, the finish multiplies the two sums per pair.
+constexpr int FPARTS = 32;
+__global__ __launch_bounds__(1024) void factored_sq_part_kernel(FactoredList l, const float* __restrict__ ws, float* __restrict__ parts) {
+  const csts_opt_factored& it = l.it[blockIdx.y];
+  const int T = it.T, nslab = it.K / FK, b = blockIdx.x;
+  const float* w = ws + l.ws_off[blockIdx.y];
+  float* out = parts + ((int64_t)blockIdx.y * FPARTS + b) * 2 * FT * FT;
+  const int nb = (it.N + FPARTS - 1) / FPARTS, n_beg = b * nb, n_end = min(it.N, n_beg + nb);
   for (int pr = threadIdx.x; pr < T * T; pr += 1024) {
     const int t = pr / T, u = pr - t * T;
     float g2 = 0.f;
-    for (int s = 0; s < nslab; ++s) g2 += w[(int64_t)s * T * T + pr];
+    for (int s = b; s < nslab; s += FPARTS) g2 += w[(int64_t)s * T * T + pr];
     float g1 = 0.f;
-    for (int n = 0; n < it.N; ++n) g1 += it.dy[(int64_t)t * it.N + n] * it.dy[(int64_t)u * it.N + n];
+    if (it.a_dt == CSTS_F32) {
+      for (int n = n_beg; n < n_end; ++n) g1 += it.dy[(int64_t)t * it.N + n] * it.dy[(int64_t)u * it.N + n];
+    } else {             // the MFMA form of the update multiplies dY rounded to the 16-bit type: the norm is that gradient's
+      for (int n = n_beg; n < n_end; ++n) g1 += (float)(bf16)it.dy[(int64_t)t * it.N + n] * (float)(bf16)it.dy[(int64_t)u * it.N + n];
+    }
+    out[pr] = g2;
+    out[FT * FT + pr] = g1;
+  }
+}
+__global__ __launch_bounds__(1024) void factored_sq_finish_kernel(FactoredList l, const float* __restrict__ parts, float* __restrict__ out_sq) {
+  __shared__ float red[1024 / WAVE];
+  const csts_opt_factored& it = l.it[blockIdx.x];
+  const int T = it.T;
+  const float* w = parts + (int64_t)blockIdx.x * FPARTS * 2 * FT * FT;
+  float acc = 0.f;
+  for (int pr = threadIdx.x; pr < T * T; pr += 1024) {
+    float g2 = 0.f, g1 = 0.f;
+    for (int b = 0; b < FPARTS; ++b) { g2 += w[(int64_t)b * 2 * FT * FT + pr]; g1 += w[(int64_t)b * 2 * FT * FT + FT * FT + pr]; }
     acc += g1 * g2;
   }
   acc = wave_sum(acc);
@@ -314,6 +334,76 @@ __global__ __launch_bounds__(256) void opt_adamw_factored_kernel(FactoredList l,
   }
 }
 
+// 16-bit operand form: g = dY^T A on the matrix cores (dY rounded to the 16-bit type, fp32 accumulation -- the arithmetic of the TN
+// GEMM that materialises dW otherwise), no LDS: a wave owns 32 rows x 64 columns, T <= 64 is <= 4 MFMA k-steps, the operands come
+// straight from memory in MFMA layout (dY 98 KB and the k-columns of A: L2-resident), and p / m / v stream through once with the
+// optimizer's cache policy.  Accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31: a half-wave
+// touches 128 contiguous bytes of a row per access.
+__global__ __launch_bounds__(256) void opt_adamw_factored_mfma_kernel(FactoredList l, const float* __restrict__ lr_ptr,
+                                                                      const float* __restrict__ state, float b1, float b2, float eps) {
+  if (state[3] != 0.f) return;                                  // step skipped by the loss scaler
+  const csts_opt_factored& it = l.it[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * FK + wave * 64;
+  if (k0 >= it.K || n0 >= it.N) return;
+  const int T = it.T, N = it.N, K = it.K;
+  const bf16* __restrict__ a16 = reinterpret_cast<const bf16*>(it.a);
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int nl = n0 + (lane & 31), kl = k0 + (lane & 31);
+  for (int t0 = 0; t0 < T; t0 += 16) {
+    bf16x8 dv, a0, a1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = t0 + 8 * (lane >> 5) + e;
+      const bool ok = t < T;
+      dv[e] = (bf16)((ok && nl < N) ? it.dy[(int64_t)t * N + nl] : 0.f);
+      a0[e] = ok ? a16[(int64_t)t * K + kl] : (bf16)0.f;
+      a1[e] = ok ? a16[(int64_t)t * K + kl + 32] : (bf16)0.f;
+    }
+    acc[0] = CSTS_MFMA16(dv, a0, acc[0], 0, 0, 0);
+    acc[1] = CSTS_MFMA16(dv, a1, acc[1], 0, 0, 0);
+  }
+  const float lr = *lr_ptr, step = state[0], clip = state[2];
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  const float step_size = lr / bc1, rsqrt_bc2 = 1.f / sqrtf(bc2);
+#ifdef CSTS_NO_STREAM_POLICY
+  constexpr int LD_AUX = 0, ST_AUX = 0;
+#else
+  constexpr int LD_AUX = 2, ST_AUX = 17;                        // nontemporal loads, write-through stores (common.h)
+#endif
+  const int bytes = (int)((int64_t)N * K * 4);
+  const auto rp = __builtin_amdgcn_make_buffer_rsrc(it.p, 0, bytes, 0x00020000), rm = __builtin_amdgcn_make_buffer_rsrc(it.m, 0, bytes, 0x00020000),
+             rv = __builtin_amdgcn_make_buffer_rsrc(it.v, 0, bytes, 0x00020000),
+             rw = __builtin_amdgcn_make_buffer_rsrc(it.w16 != nullptr ? it.w16 : (void*)it.p, 0, bytes / 2, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float pp[16], mm[16], vv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int off = (n < N) ? (n * K + kl + 32 * j) * 4 : 0;
+      pp[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, off, 0, LD_AUX));
+      mm[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, off, 0, LD_AUX));
+      vv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, off, 0, LD_AUX));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n >= N) continue;
+      const int off = (n * K + kl + 32 * j) * 4;
+      adamw_one(pp[r], acc[j][r], mm[r], vv[r], clip, lr, it.weight_decay, b1, b2, eps, step_size, rsqrt_bc2);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pp[r]), rp, off, 0, ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mm[r]), rm, off, 0, ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[r]), rv, off, 0, ST_AUX);
+      if (it.w16 != nullptr) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)pp[r]), rw, off / 2, 0, ST_AUX);
+    }
+  }
+}
+
 }  // namespace
 
 static int factored_fill(const csts_opt_factored* items, int nitems, FactoredList& l, int* max_k, int* max_n) {
@@ -338,7 +428,7 @@ extern "C" size_t csts_factored_sqnorm_workspace(const csts_opt_factored* items,
   if (items == nullptr || nitems <= 0 || nitems > FMAX) return 0;
   size_t b = 0;
   for (int i = 0; i < nitems; ++i) b += (size_t)(items[i].K / FK) * items[i].T * items[i].T * sizeof(float);
-  return b;
+  return b + (size_t)nitems * FPARTS * 2 * FT * FT * sizeof(float);          // Gram slabs + the two-stage finish's partial sums
 }
 extern "C" int csts_factored_sqnorm(const csts_opt_factored* items, int nitems, float* out_sq, void* workspace, size_t ws_bytes,
                                     hipStream_t stream) {
@@ -353,7 +443,12 @@ extern "C" int csts_factored_sqnorm(const csts_opt_factored* items, int nitems, 
   CSTS_REQUIRE(sm <= 64 * 1024 || csts_dyn_lds_optin(reinterpret_cast<const void*>(&factored_gram_kernel), (int)sm), "LDS opt-in failed");
   hipLaunchKernelGGL(factored_gram_kernel, dim3((unsigned)(mk / FK), 1, (unsigned)nitems), dim3(256), sm, stream, l, slabs);
   CSTS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(factored_sq_finish_kernel, dim3((unsigned)nitems), dim3(1024), 0, stream, l, (const float*)slabs, out_sq);
+  size_t slab_floats = 0;
+  for (int i = 0; i < nitems; ++i) slab_floats += (size_t)(items[i].K / FK) * items[i].T * items[i].T;
+  float* parts = slabs + slab_floats;
+  hipLaunchKernelGGL(factored_sq_part_kernel, dim3(FPARTS, (unsigned)nitems), dim3(1024), 0, stream, l, (const float*)slabs, parts);
+  CSTS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(factored_sq_finish_kernel, dim3((unsigned)nitems), dim3(1024), 0, stream, l, (const float*)parts, out_sq);
   CSTS_LAUNCH_CHECK();
   return 0;
 }
@@ -365,6 +460,14 @@ extern "C" int csts_adamw_factored(const csts_opt_factored* items, int nitems, c
   CSTS_REQUIRE(state != nullptr && lr != nullptr, "null state");
   int mt = 0;
   for (int i = 0; i < nitems; ++i) mt = std::max(mt, items[i].T);
+  bool all16 = true;
+  for (int i = 0; i < nitems; ++i) all16 = all16 && items[i].a_dt == CSTS_HALF && (int64_t)items[i].N * items[i].K * 4 < ((int64_t)1 << 31) && items[i].K % 64 == 0;
+  if (all16) {
+    hipLaunchKernelGGL(opt_adamw_factored_mfma_kernel, dim3((unsigned)(mk / FK), (unsigned)cdiv(mn, 32), (unsigned)nitems), dim3(256), 0, stream, l, lr,
+                       state, beta1, beta2, eps);
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t sm = (size_t)mt * (FK + FR) * sizeof(float);
   CSTS_REQUIRE(sm <= 64 * 1024 || csts_dyn_lds_optin(reinterpret_cast<const void*>(&opt_adamw_factored_kernel), (int)sm), "LDS opt-in failed");
   hipLaunchKernelGGL(opt_adamw_factored_kernel, dim3((unsigned)(mk / FK), (unsigned)cdiv(mn, FR), (unsigned)nitems), dim3(256), sm, stream, l, lr,

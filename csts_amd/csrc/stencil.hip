@@ -12,6 +12,7 @@
 // HBM-bound kernels: channels are the fastest index, consecutive lanes -> consecutive channels.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1247,6 +1248,28 @@ extern "C" int csts_dwconv_wgrad2(const csts_dwconv_geom* a, const void* const f
 
 static_assert(sizeof(WgItem) == CSTS_DWCONV_WGRAD_TABLE_ENTRY, "device table entry size is part of the C-ABI");
 
+// Chunking of the GROUPED launch: the single launches above cut a tensor into up to 512 workgroups of >= 16 coarse tokens because
+// each of them has the chip to itself for one latency-bound round; grouped, the problems fill the chip together, and longer
+// chunks amortise the fixed part of a workgroup (LDS fold over the token lanes, partial row, launch) and leave fewer partial rows
+// to the second stage.  CSTS_SWG_TOKENS (environment, read once) sets the minimum tokens per workgroup for sweeps.
+static int grouped_min_tokens() {
+  static const int v = [] { const char* e = getenv("CSTS_SWG_TOKENS"); const int x = e ? atoi(e) : 0; return x >= 8 ? x : 64; }();
+  return v;
+}
+static void wgrad_plan_grouped(const csts_dwconv_geom* a, int& slab, int& nslab, int64_t& chunk, int64_t& nchunk) {
+  wgrad_plan(a, slab, nslab, chunk, nchunk);
+  const int64_t total = (int64_t)a->B * a->Tc * a->Hc * a->Wc;
+  nchunk = std::max<int64_t>(1, std::min<int64_t>(nchunk, cdiv(total, grouped_min_tokens())));
+  chunk = cdiv(total, nchunk);
+  nchunk = cdiv(total, chunk);
+}
+extern "C" size_t csts_dwconv_wgrad_grouped_workspace(const csts_dwconv_geom* a) {
+  if (!a || a->C <= 0 || a->HD <= 0) return 0;
+  int slab, nslab; int64_t chunk, nchunk;
+  wgrad_plan_grouped(a, slab, nslab, chunk, nchunk);
+  return (size_t)nchunk * nslab * a->HD * 27 * sizeof(float);
+}
+
 extern "C" int csts_dwconv_wgrad_grouped_plan(const csts_dwconv_wgrad_item* items, int nitems, void* table_host, size_t table_bytes,
                                               int* nblocks) {
   CSTS_REQUIRE(items != nullptr && table_host != nullptr && nblocks != nullptr && nitems > 0, "null argument");
@@ -1257,7 +1280,7 @@ extern "C" int csts_dwconv_wgrad_grouped_plan(const csts_dwconv_wgrad_item* item
     CHECK_GEOM(a);
     CSTS_REQUIRE(items[i].fine && items[i].coarse && items[i].workspace, "null pointer");
     int slab, nslab; int64_t chunk, nchunk;
-    wgrad_plan(a, slab, nslab, chunk, nchunk);
+    wgrad_plan_grouped(a, slab, nslab, chunk, nchunk);
     CSTS_REQUIRE(a->C % slab == 0 && slab % a->HD == 0 && slab % 2 == 0 && slab <= 192, "channel slab must hold whole heads");
     RowGeom rg; fill_geom(a, rg);
     WgItem& w = tab[(size_t)i];

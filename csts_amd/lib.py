@@ -179,6 +179,7 @@ SYMBOLS = {
     "csts_dwconv_wgrad": (_I, [C.POINTER(DwconvGeom), vp, _I, vp, _I, vp, vp, sz, vp]),
     "csts_dwconv_transposed2": (_I, [C.POINTER(DwconvGeom), vp * 2, _I, vp * 2, vp * 2, _I, vp]),
     "csts_dwconv_wgrad2": (_I, [C.POINTER(DwconvGeom), vp * 2, _I, vp * 2, _I, vp * 2, vp, sz, vp]),
+    "csts_dwconv_wgrad_grouped_workspace": (sz, [C.POINTER(DwconvGeom)]),
     "csts_dwconv_wgrad_grouped_plan": (_I, [C.POINTER(DwconvWgradItem), _I, vp, sz, C.POINTER(C.c_int)]),
     "csts_dwconv_wgrad_grouped": (_I, [vp, _I, _I, _I, vp]),
     "csts_pool_ln_fwd": (_I, [C.POINTER(PoolLnArgs), vp]),

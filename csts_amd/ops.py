@@ -1232,12 +1232,12 @@ class AttnInnerFn(Function):
             c, mean, rstd, g = saved[slot]
             pw, pg, pb = P[3 * slot], P[3 * slot + 1], P[3 * slot + 2]
             dc, dg, db = _ln_rows_bwd(dy, c, gamma, mean, rstd, HD, params=(pg, pb))
-            wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
+            defer = _can_defer(pw)
+            grouped = defer and _stencil_group_now()
+            wsz = (lib.csts_dwconv_wgrad_grouped_workspace if grouped else lib.csts_dwconv_wgrad_workspace)(C.byref(g))
             wws = _ws(wsz, dev)
             dw = torch.empty(HD * 27, dtype=torch.float32, device=dev)
-            defer = _can_defer(pw)
             dwp = None if defer else _p(dw)
-            grouped = defer and _stencil_group_now()
             if grouped:
                 if transposed:
                     _queue_stencil_wgrad(g, dc, 0, qkv, slot * Cc, wws)
@@ -1288,11 +1288,11 @@ class AttnInnerFn(Function):
             L.check(lib.csts_dwconv_transposed2(C.byref(g), vp2(_p(dc2[0]), _p(dc2[1])), _dt(dc2), vp2(_p(wk), _p(wv)),
                                                 vp2(_p(kv_dfine, kv_off[0]), _p(kv_dfine, kv_off[1])), _dt(kv_dfine), s),
                     "csts_dwconv_transposed2")
-            wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
+            grouped = defer and _stencil_group_now()
+            wsz = (lib.csts_dwconv_wgrad_grouped_workspace if grouped else lib.csts_dwconv_wgrad_workspace)(C.byref(g))
             wws = _ws(2 * wsz, dev)
             dw = torch.empty(2, HD * 27, dtype=torch.float32, device=dev)
             dwp = vp2(None, None) if defer else vp2(_p(dw[0]), _p(dw[1]))
-            grouped = defer and _stencil_group_now()
             if grouped:
                 for i in (0, 1):
                     _queue_stencil_wgrad(g, kv_fine, kv_off[i], dc2[i], 0, wws[i * wsz:(i + 1) * wsz])

@@ -120,11 +120,21 @@ def backward_scaled(loss, optimizer):
     (loss if sc is None else loss * sc).backward()
 
 
+def _factored_on(cfg, core) -> bool:
+    """CSTS_AMD.FACTORED_ADAMW (default on) in the 16-bit compute modes: there the update forms dY^T A on the matrix cores
+    (profiles/r4_factored_adamw_ab.txt: -0.3 ms per step at b = 4); the fp32 mode's scalar form measured slower and stays off.
+    CSTS_FACTORED_ADAMW=0 / 1 (environment) overrides both for same-box A/B runs."""
+    env = os.environ.get("CSTS_FACTORED_ADAMW", "")
+    if env in ("0", "1"):
+        return env == "1"
+    from . import lib as L
+    return bool(getattr(getattr(cfg, "CSTS_AMD", None), "FACTORED_ADAMW", True)) and getattr(getattr(core, "rt", None), "compute", L.F32) != L.F32
+
+
 def _factored_params(cfg, core, optimizer):
     """The fusion-conv weights whose gradient the optimizer can form on the fly from its rank-(B T') factors
     (FusedAdamW.set_factored; CSTS_AMD.FACTORED_ADAMW): never written to memory, never read back."""
-    if not bool(getattr(getattr(cfg, "CSTS_AMD", None), "FACTORED_ADAMW", False) or os.environ.get("CSTS_FACTORED_ADAMW", "0") == "1") \
-            or not hasattr(optimizer, "set_factored"):          # environment switch for same-box A/B runs
+    if not _factored_on(cfg, core) or not hasattr(optimizer, "set_factored"):
         return []
     ws = [m.weight for m in (getattr(core, n, None) for n in ("vision_pool", "audio_pool", "audio_pool2")) if m is not None]
     return [w for w in ws if w.requires_grad and w.grad is None and w.is_cuda]
@@ -394,7 +404,7 @@ class SegmentedTrainStep:
         # outside the all-reduced prefix; the ranks all-gather dY / A (3.2 MB per conv) and form the averaged dW themselves.
         amd_ = getattr(cfg, "CSTS_AMD", None)
         self.factor_params = []
-        opt_factored = hasattr(optimizer, "set_factored") and bool(getattr(amd_, "FACTORED_ADAMW", False) or os.environ.get("CSTS_FACTORED_ADAMW", "0") == "1")
+        opt_factored = hasattr(optimizer, "set_factored") and _factored_on(cfg, core)
         if use_graphs and ((self.dist and bool(getattr(amd_, "FUSION_GRAD_FACTORS", True))) or (not self.dist and opt_factored)):
             self.factor_params = [m.weight for m in (getattr(core, n, None) for n in ("vision_pool", "audio_pool", "audio_pool2"))
                                   if m is not None and m.weight.requires_grad]

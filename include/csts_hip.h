@@ -160,8 +160,9 @@ int csts_dwconv_wgrad2(const csts_dwconv_geom* g, const void* const fine[2], int
                        int coarse_dt, float* const dweight[2], void* workspace, size_t ws_bytes, hipStream_t stream);
 /* Grouped first stage: every stencil weight gradient of a backward pass (the q / k / v pools of all blocks, attention.py:104-116,
  * and the decoder's transposed convs, :344-348) in ONE launch instead of one ~24 us latency-bound launch each.  Item i is one
- * csts_dwconv_wgrad problem whose partial rows go to its own workspace (csts_dwconv_wgrad_workspace(&geom) bytes; rows =
- * bytes / (HD*27*4)); the second stage (the row sums) is the caller's, exactly as with dweight NULL above.  _plan runs on the
+ * csts_dwconv_wgrad problem whose partial rows go to its own workspace (csts_dwconv_wgrad_grouped_workspace(&geom) bytes -- the
+ * grouped launch cuts a tensor into fewer, longer token chunks than the single one; rows = bytes / (HD*27*4)); the second stage
+ * (the row sums) is the caller's, exactly as with dweight NULL above.  _plan runs on the
  * host: it validates the items and writes the DEVICE TABLE IMAGE (nitems * CSTS_DWCONV_WGRAD_TABLE_ENTRY bytes, items
  * re-ordered longest workgroups first) into table_host and the grid size into *nblocks; the caller copies the image to device
  * memory in stream order and passes that address to csts_dwconv_wgrad_grouped.  All items of a call share dtype dt. */
@@ -171,6 +172,7 @@ typedef struct {
   void* workspace;
 } csts_dwconv_wgrad_item;
 #define CSTS_DWCONV_WGRAD_TABLE_ENTRY 128
+size_t csts_dwconv_wgrad_grouped_workspace(const csts_dwconv_geom* g);
 int csts_dwconv_wgrad_grouped_plan(const csts_dwconv_wgrad_item* items, int nitems, void* table_host, size_t table_bytes, int* nblocks);
 int csts_dwconv_wgrad_grouped(const void* table_dev, int nitems, int nblocks, int dt, hipStream_t stream);
 

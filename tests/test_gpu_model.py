@@ -460,10 +460,10 @@ def test_gradient_accumulation_and_failed_backward():
         finally:
             ops.STENCIL_WGRAD_GROUPED = True
         assert len(one_by_one) >= 40
-        _train_pass(m, cfg, batch)            # ... == all of them in ONE grouped launch, bit for bit
+        _train_pass(m, cfg, batch)            # ... == all of them in ONE grouped launch (longer token chunks: fp32 summation order)
         ref = {n: p.grad.clone() for n, p in m.named_parameters()}
         for n, g1 in one_by_one.items():
-            assert torch.equal(ref[n], g1), n
+            assert rel_l2(ref[n], g1) < 1e-5, n
         loss, *_ = T.compute_loss(cfg, m, batch["video"], batch["audio"], batch["labels_hm"])
         loss.backward()                       # no zero_grad in between: accumulate
         torch.cuda.synchronize()
@@ -501,7 +501,7 @@ def test_gradient_accumulation_and_failed_backward():
 def test_train_step_runs_bf16_b4():
     """BASELINE config 3 shape: bs=4 train step (fwd + KLDiv + 0.05 EgoNCE + bwd + clip + AdamW), bf16 mode."""
     m, cfg = make_model("bf16")
-    cfg.CSTS_AMD.FACTORED_ADAMW = True                   # off by default (measured slower at b = 4): exercised here
+    cfg.CSTS_AMD.FACTORED_ADAMW = True                   # the default in the 16-bit modes
     m.train()
     opt = T.construct_optimizer(m, cfg)
     batch = T.synthetic_batch(4, 8, 256, 1234, DEV)

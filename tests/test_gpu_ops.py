@@ -586,9 +586,9 @@ def test_grouped_weight_gradients_match_inline():
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-def test_grouped_stencil_weight_gradients_are_bit_identical(dt):
-    """csts_dwconv_wgrad_grouped (every pool's first stage in ONE launch; raw C-ABI calls) leaves exactly the partial rows that
-    csts_dwconv_wgrad with dweight NULL leaves per problem -- mixed geometries in one call: stride 1 / 2 / 8 / compact (1,3,3),
+def test_grouped_stencil_weight_gradients(dt):
+    """csts_dwconv_wgrad_grouped (every pool's first stage in ONE launch; raw C-ABI calls) against csts_dwconv_wgrad with dweight
+    NULL per problem (same products, longer token chunks: equal to fp32 summation order) -- mixed geometries in one call: stride 1 / 2 / 8 / compact (1,3,3),
     head dims 96 / 192 / 32, ragged grids, operands read in place inside 3C-wide buffers; the row sums then equal the gradient of
     torch's grouped conv3d (attention.py:104-116)."""
     import ctypes as C
@@ -612,8 +612,10 @@ def test_grouped_stencil_weight_gradients_are_bit_identical(dt):
         g.fine_batch_stride, g.fine_token_stride = Nf * 3 * Cc, 3 * Cc
         g.coarse_batch_stride, g.coarse_token_stride = Nc * Cc, Cc
         wsz = lib.csts_dwconv_wgrad_workspace(C.byref(g))
+        gsz = lib.csts_dwconv_wgrad_grouped_workspace(C.byref(g))       # fewer, longer token chunks than the single launch
+        assert 0 < gsz <= wsz and gsz % (HD * 27 * 4) == 0
         ws_one = torch.zeros(wsz // 4, dtype=torch.float32, device=DEV)
-        ws_grp = torch.full((wsz // 4,), float("nan"), dtype=torch.float32, device=DEV)
+        ws_grp = torch.full((gsz // 4,), float("nan"), dtype=torch.float32, device=DEV)
         fptr = fine.data_ptr() + Cc * fine.element_size()
         L.check(lib.csts_dwconv_wgrad(C.byref(g), fptr, cdt, coarse.data_ptr(), cdt, None, ws_one.data_ptr(), wsz, st_), "single")
         probs.append((g, fine, fptr, coarse, ws_one, ws_grp, (B, Cc, HD, fthw, cthw, st, Nf, Nc)))
@@ -628,8 +630,9 @@ def test_grouped_stencil_weight_gradients_are_bit_identical(dt):
     L.check(lib.csts_dwconv_wgrad_grouped(table.data_ptr(), len(probs), nblocks.value, cdt, st_), "grouped")
     torch.cuda.synchronize()
     for g, fine, fptr, coarse, ws_one, ws_grp, (B, Cc, HD, fthw, cthw, st, Nf, Nc) in probs:
-        assert torch.equal(ws_one, ws_grp), (Cc, HD, fthw, st)
         dw = ws_grp.view(-1, HD * 27).sum(0).view(HD, 27)
+        assert bool(torch.isfinite(ws_grp).all())                       # every partial row of the plan was written
+        assert rel_l2(dw, ws_one.view(-1, HD * 27).sum(0).view(HD, 27)) < 1e-6, (Cc, HD, fthw, st)
         x = fine[:, :, Cc:2 * Cc].float().reshape(B, *fthw, Cc).permute(0, 4, 1, 2, 3).requires_grad_(False)
         w = torch.zeros(Cc, 1, 3, 3, 3, device=DEV, requires_grad=True)
         y = F.conv3d(x, w, stride=st, padding=1, groups=Cc)
@@ -692,6 +695,8 @@ def test_factored_adamw_matches_dense_gradient(a_dtype):
     from csts_amd.optim import FusedAdamW
     N, K, T2 = 48, 1024, 32
     shapes = [(N, 4, 16, 16), (64, 2, 8, 32), (300,), (96, 32)]          # two "fusion convs" (N x K = 48 x 1024, 64 x 512) + ordinary ones
+    # 16-bit operands take the MFMA form: dY is rounded to the 16-bit type like in the TN GEMM that materialises dW otherwise
+    dy16 = (lambda t: t.to(a_dtype).float()) if a_dtype != torch.float32 else (lambda t: t)
     pa = [rnd(*s, seed=10 + i, scale=0.5).requires_grad_() for i, s in enumerate(shapes)]
     pb = [p.detach().clone().requires_grad_() for p in pa]
     ga = [{"params": [pa[0], pa[1], pa[3]], "weight_decay": 0.05}, {"params": [pa[2]], "weight_decay": 0.0}]
@@ -706,7 +711,7 @@ def test_factored_adamw_matches_dense_gradient(a_dtype):
             dy = rnd(Tn, n, seed=50 * step + i, scale=gscale)
             a = rnd(Tn, k, seed=70 * step + i).to(a_dtype)
             facs.append((pa[i], dy, a))
-            pb[i].grad = (dy.t() @ a.float()).view(shapes[i])
+            pb[i].grad = (dy16(dy).t() @ a.float()).view(shapes[i])
             pa[i].grad = None
         for i in (2, 3):
             g = rnd(*shapes[i], seed=100 * step + i, scale=gscale)
@@ -727,7 +732,7 @@ def test_factored_adamw_matches_dense_gradient(a_dtype):
     ref2 = torch.optim.AdamW([pb[0], pb[2]], lr=1e-3, eps=1e-8, weight_decay=0.0)
     pb[0].data.copy_(pa[0].data); pb[2].data.copy_(pa[2].data)
     g2 = rnd(300, seed=3)
-    pb[0].grad, pb[2].grad = (dy.t() @ a.float()).view(shapes[0]), g2.clone()
+    pb[0].grad, pb[2].grad = (dy16(dy).t() @ a.float()).view(shapes[0]), g2.clone()
     pa[0].grad, pa[2].grad = None, g2 * 1024.0
     fs.set_factored([(pa[0], dy * 1024.0, a)])
     nr = torch.nn.utils.clip_grad_norm_([pb[0], pb[2]], 1.0)
