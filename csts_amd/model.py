@@ -16,6 +16,7 @@ import weakref
 from functools import partial
 from typing import Dict, List, Optional
 
+import os
 import torch
 import torch.nn as nn
 from torch.nn.init import trunc_normal_
@@ -67,6 +68,9 @@ def resolve_compute(cfg) -> str:
         else:
             _log.warning("TRAIN.MIXED_PRECISION True but CSTS_AMD.COMPUTE is %r: the explicit compute mode wins, no mixed precision", compute)
     return compute
+
+
+HEAD_STREAMS = os.environ.get("CSTS_HEAD_STREAMS", "1") != "0"      # temporal fusion beside the spatial fusion on the side stream (A/B switch)
 
 
 class Runtime:
@@ -522,6 +526,24 @@ class CSTS(nn.Module):
         Tn, HW = thw[0], thw[1] * thw[2]
         HWa = thw_a[1] * thw_a[2]
         c16 = lambda m: getattr(m, "_w16", None) if rt.compute == L.BF16 else None     # bf16 shadow (CSTS._refresh_w16)
+        def temporal_branch(x_t):                               # :435-451
+            x_tmp = ops.fusion_conv(x_t, self.vision_pool.weight, self.vision_pool.bias, Tn, HW, rt.act_dt, rt.compute,
+                                    w16=c16(self.vision_pool))
+            y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
+                                    w16=c16(self.audio_pool2))
+            return self.temporal_fusion(torch.cat([x_tmp, y_tmp], dim=1), (2, 2, 2), want_attn=return_temporal_attn)
+
+        # The temporal fusion (16 tokens per clip: every kernel of it is one latency-bound round trip) does not depend on the spatial
+        # one unless SPATIAL_AUDIO_ATTN re-weights its input (:438-440): it runs on the side stream beside the spatial fusion, and
+        # autograd replays its backward there too.
+        main = torch.cuda.current_stream()
+        side = self._audio_stream() if (self.two_streams and HEAD_STREAMS and not self.spatial_audio_attn) else None
+        if side is not None:
+            side.wait_stream(main)
+            xt.record_stream(side)
+            yt.record_stream(side)
+            with torch.cuda.stream(side):
+                av_t, _, t_extra = temporal_branch(xt)
         y_sp = ops.fusion_conv(yt, self.audio_pool.weight, self.audio_pool.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
                                w16=c16(self.audio_pool))
         av_sp = torch.cat([xt, y_sp], dim=1)
@@ -529,15 +551,16 @@ class CSTS(nn.Module):
                                                  spatial_audio_attn=self.spatial_audio_attn)
         x_spatial = av_sp[:, :Nv, :]
         # ---- temporal fusion (:435-451)
-        x_t = xt
-        if self.spatial_audio_attn:                             # :438-440
-            x_t = ops.row_weight(xt, sp_extra[1])
-        x_tmp = ops.fusion_conv(x_t, self.vision_pool.weight, self.vision_pool.bias, Tn, HW, rt.act_dt, rt.compute,
-                                w16=c16(self.vision_pool))
-        y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
-                                w16=c16(self.audio_pool2))
-        av_t = torch.cat([x_tmp, y_tmp], dim=1)
-        av_t, _, t_extra = self.temporal_fusion(av_t, (2, 2, 2), want_attn=return_temporal_attn)
+        if side is not None:
+            main.wait_stream(side)
+            av_t.record_stream(main)
+            if torch.is_tensor(t_extra):
+                t_extra.record_stream(main)
+        else:
+            x_t = xt
+            if self.spatial_audio_attn:                         # :438-440
+                x_t = ops.row_weight(xt, sp_extra[1])
+            av_t, _, t_extra = temporal_branch(x_t)
         # ---- re-weight (:454-461)
         x_w, y_w = av_t[:, :Tn, :], av_t[:, Tn:, :]
         x_rw = ops.reweight(x_spatial, x_w, Tn, HW)

@@ -243,8 +243,23 @@ def flush_deferred():
     """Finish the queued weight gradients and every deferred reduction on the current stream, then hand the results to
     their parameters (idempotent)."""
     _deferred_task[0] = -1
+    # the grouped stencil weight gradients (0.8 ms of load-latency-bound work, no matrix math) run on a side stream BESIDE the
+    # grouped Linear weight gradients (MFMA-bound, one persistent workgroup per CU whose last items leave most CUs idle)
+    tail = None
+    if _swq and _wgq and STENCIL_TAIL_SIDE and _swq[0][5][0].is_cuda:
+        cur = torch.cuda.current_stream()
+        tail = _tail_side.get(cur.device.index)
+        if tail is None:
+            tail = _tail_side[cur.device.index] = torch.cuda.Stream(device=cur.device)
+        tail.wait_stream(cur)
+        with torch.cuda.stream(tail):
+            keep = flush_stencil_wgrads()
     flush_wgrads()
-    flush_stencil_wgrads()
+    if tail is not None:
+        torch.cuda.current_stream().wait_stream(tail)
+        del keep        # allocated on this stream, read on `tail`: alive until the join above
+    else:
+        flush_stencil_wgrads()
     _join_wgrad_side()
     _join_stencil_side()
     if not _deferred:
@@ -495,6 +510,8 @@ def flush_wgrads(side: bool = False):
 # Same policy as the grouped Linear weight gradients: while the step is captured (GROUP_WGRADS), and only when the gradient may be
 # deferred; the operands (the saved q / k / v tensors and the conv-output gradients) stay alive until the flush.
 STENCIL_WGRAD_GROUPED = os.environ.get("CSTS_STENCIL_WGRAD_GROUPED", "1") != "0"
+STENCIL_TAIL_SIDE = os.environ.get("CSTS_STENCIL_TAIL_SIDE", "0") == "1"     # MEASURED NEUTRAL (20.85-21.05 vs 20.95-21.06 ms, profiles/r4_branch_streams_ab.txt): wgrad8's 144 KB of LDS leave no room for a second workgroup on its CUs; off
+_tail_side = {}         # device index -> stream
 _swq = []               # (DwconvGeom copy, fine ptr, coarse ptr, workspace ptr, dt, (tensors kept alive))
 _swq_tables = {}        # device index -> HostTable
 
@@ -513,7 +530,7 @@ def _queue_stencil_wgrad(g, fine, fine_off, coarse, coarse_off, ws):
 
 def flush_stencil_wgrads():
     if not _swq:
-        return
+        return None
     q = list(_swq)
     _swq.clear()
     dev = q[0][5][0].device
@@ -532,7 +549,7 @@ def flush_stencil_wgrads():
         L.check(_lib().csts_dwconv_wgrad_grouped_plan(items, len(sel), image, len(image), C.byref(nblocks)), "csts_dwconv_wgrad_grouped_plan")
         ptr = tab.upload(bytes(image))
         L.check(_lib().csts_dwconv_wgrad_grouped(ptr, len(sel), nblocks.value, dt, _stream()), "csts_dwconv_wgrad_grouped")
-    del q
+    return q            # the operands: the caller keeps them alive until the launch stream has been joined
 
 
 # Stencil weight gradients (csts_dwconv_wgrad / _wgrad2: 34 launches of ~24 us per step, latency-bound, 0.16 of the HBM roofline)
