@@ -357,11 +357,13 @@ class CSTS(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
-    def _refresh_w16(self):
+    def _refresh_w16(self, defer_twins=False):
         """bf16 shadows of every block Linear weight (fp32 masters stay the nn.Parameters): one multi-tensor cast per
-        forward in training mode (weights change every step; also what a captured HIP graph replays), on demand in eval."""
+        forward in training mode (weights change every step; also what a captured HIP graph replays), on demand in eval.
+        defer_twins: the [in][out] twins (read by backward only) are NOT refreshed here; the transpose set is returned and the
+        caller refreshes it where it costs nothing (forward_trunk: on the side stream, beside the forward pass)."""
         if self.rt.compute != L.BF16:
-            return
+            return None
         lins = getattr(self, "_w16_lins", None)
         if lins is None:
             lins = [m for blk in self.modules() if isinstance(blk, Block)
@@ -392,7 +394,10 @@ class CSTS(nn.Module):
                 for l in lins:
                     l._w16t = torch.empty(l.weight.shape[1], l.weight.shape[0], dtype=L.half_dtype(), device=l.weight.device)
                 ts = self._w16t_set = ops._TransposeSet([(l._w16, l._w16t) for l in lins])
+            if defer_twins:
+                return ts
             ts.refresh()
+        return None
 
     def _draw_drop_paths(self, B, device):
         """All stochastic-depth scales of one forward in ONE draw (4 small kernels instead of 4 per block branch):
@@ -458,20 +463,25 @@ class CSTS(nn.Module):
         km = keep_masks or {}
         if self.training and keep_masks is None:
             km = self._draw_drop_paths(inpt.shape[0], inpt.device)
-        self._refresh_w16()
-        feats, geo = self.forward_trunk(inpt, y, km, boundary)
+        twins = self._refresh_w16(defer_twins=self.two_streams and HEAD_STREAMS)
+        feats, geo = self.forward_trunk(inpt, y, km, boundary, twins=twins)
         if boundary is not None:
             feats = boundary(feats)
         return self.forward_head(feats, geo, km, return_embed, return_spatial_attn, return_temporal_attn)
 
-    def forward_trunk(self, inpt, y, km, boundary=None):
-        """Patch embeddings + the video and audio encoders (custom_multimodal_builder.py:346-411)."""
+    def forward_trunk(self, inpt, y, km, boundary=None, twins=None):
+        """Patch embeddings + the video and audio encoders (custom_multimodal_builder.py:346-411).  twins: the weight-twin
+        transpose set whose refresh _refresh_w16 left to this function."""
         rt = self.rt
         pe, pa = self.patch_embed, self.patch_embed_audio
+        audio_embed = lambda: ops.patch_embed(y.float(), pa.proj.weight, pa.proj.bias, self.pos_embed_spatial_audio,
+                                              self.pos_embed_temporal_audio, pa.kernel, pa.stride, pa.padding, rt.act_dt, rt.compute)
+        early_side = self.two_streams and HEAD_STREAMS          # the audio patch embedding and the twin refresh start the side stream
+        if twins is not None and not early_side:
+            twins.refresh()
+        yt = None if early_side else audio_embed()
         xt = ops.patch_embed(inpt.float(), pe.proj.weight, pe.proj.bias, self.pos_embed_spatial, self.pos_embed_temporal,
                              pe.kernel, pe.stride, pe.padding, rt.act_dt, rt.compute)
-        yt = ops.patch_embed(y.float(), pa.proj.weight, pa.proj.bias, self.pos_embed_spatial_audio,
-                             self.pos_embed_temporal_audio, pa.kernel, pa.stride, pa.padding, rt.act_dt, rt.compute)
         T, H, W = self.patch_dims
         thw, thw_a = [T, H, W], [T, H, W]
         # encoder features the decoder re-uses (:384,389,396,403): each goes through ops.tap, so that its two gradients
@@ -495,9 +505,14 @@ class CSTS(nn.Module):
         side = self._audio_stream() if self.two_streams else None
         if side is not None:
             side.wait_stream(main)
-            yt.record_stream(side)      # allocated on `main`, read on `side`: keep the allocator from recycling it early
+            if yt is not None:
+                yt.record_stream(side)  # allocated on `main`, read on `side`: keep the allocator from recycling it early
             with torch.cuda.stream(side):
+                if yt is None:
+                    yt = audio_embed()
                 yt, thw_a = run(yt, thw_a, ab, an)
+                if twins is not None and early_side:
+                    twins.refresh()     # read by backward only: after the audio trunk, beside the rest of the video trunk
         cut_at = int(getattr(boundary, "trunk_cut", 0) or 0)
         for i, (blk, nm) in enumerate(zip(vb, vn)):
             if cut_at and i == cut_at:
@@ -565,6 +580,20 @@ class CSTS(nn.Module):
         x_w, y_w = av_t[:, :Tn, :], av_t[:, Tn:, :]
         x_rw = ops.reweight(x_spatial, x_w, Tn, HW)
         y_rw = ops.reweight(yt, y_w, thw_a[0], HWa)
+        # ---- embeddings (:493-497) early, on the side stream beside the decoder (their EgoNCE backward runs there too)
+        emb = None
+        if return_embed:
+            embed = lambda: (ops.linear(ops.token_mean(x_rw), self.vision_proj.weight, self.vision_proj.bias, out_dt=L.F32, compute=L.F32),
+                             ops.linear(ops.token_mean(y_rw), self.audio_proj.weight, self.audio_proj.bias, out_dt=L.F32, compute=L.F32))
+            eside = self._audio_stream() if (self.two_streams and HEAD_STREAMS) else None
+            if eside is not None:
+                eside.wait_stream(main)
+                x_rw.record_stream(eside)
+                y_rw.record_stream(eside)
+                with torch.cuda.stream(eside):
+                    emb = embed()
+            else:
+                emb = embed()
         # ---- decoder (:466-475)
         feat, dthw = x_rw, list(thw)
         skip = None                              # feat = feat + inter[...] (:469-475) happens inside the next block's norm1
@@ -585,6 +614,9 @@ class CSTS(nn.Module):
             if return_temporal_attn:
                 out.append(t_extra)
             return out
-        v_emb = ops.linear(ops.token_mean(x_rw), self.vision_proj.weight, self.vision_proj.bias, out_dt=L.F32, compute=L.F32)
-        a_emb = ops.linear(ops.token_mean(y_rw), self.audio_proj.weight, self.audio_proj.bias, out_dt=L.F32, compute=L.F32)
+        v_emb, a_emb = emb
+        if self.two_streams and HEAD_STREAMS:
+            main.wait_stream(self._audio_stream())
+            v_emb.record_stream(main)
+            a_emb.record_stream(main)
         return [logits, v_emb, a_emb]
