@@ -70,6 +70,8 @@ def resolve_compute(cfg) -> str:
     return compute
 
 
+SPLIT_STAGE3 = os.environ.get("CSTS_SPLIT_STAGE3", "0") == "1"
+_HALF_STREAMS = weakref.WeakKeyDictionary()
 HEAD_STREAMS = os.environ.get("CSTS_HEAD_STREAMS", "1") != "0"      # temporal fusion beside the spatial fusion on the side stream (A/B switch)
 
 
@@ -469,6 +471,34 @@ class CSTS(nn.Module):
             feats = boundary(feats)
         return self.forward_head(feats, geo, km, return_embed, return_spatial_attn, return_temporal_attn)
 
+    def _run_halves(self, xt, thw, km, blocks, names, main):
+        """blocks over the two halves of the batch, the second half on its own stream (autograd replays its backward there)."""
+        B = xt.shape[0]
+        h = B // 2
+        st2 = _HALF_STREAMS.get(self)
+        if st2 is None:
+            st2 = _HALF_STREAMS[self] = torch.cuda.Stream()
+
+        def km_half(v, lo, hi):
+            if v is None:
+                return None
+            return tuple(e if isinstance(e, str) else e[lo:hi] for e in v)
+
+        def chain(t, lo, hi):
+            shape = list(thw)
+            for blk, nm in zip(blocks, names):
+                t, shape, _ = blk(t, shape, km_half(km.get(nm), lo, hi))
+            return t, shape
+
+        st2.wait_stream(main)
+        xt.record_stream(st2)
+        with torch.cuda.stream(st2):
+            xb, _ = chain(xt[h:], h, B)
+        xa, shape = chain(xt[:h], 0, h)
+        main.wait_stream(st2)
+        xb.record_stream(main)
+        return torch.cat([xa, xb], dim=0), shape
+
     def forward_trunk(self, inpt, y, km, boundary=None, twins=None):
         """Patch embeddings + the video and audio encoders (custom_multimodal_builder.py:346-411).  twins: the weight-twin
         transpose set whose refresh _refresh_w16 left to this function."""
@@ -514,7 +544,20 @@ class CSTS(nn.Module):
                 if twins is not None and early_side:
                     twins.refresh()     # read by backward only: after the audio trunk, beside the rest of the video trunk
         cut_at = int(getattr(boundary, "trunk_cut", 0) or 0)
-        for i, (blk, nm) in enumerate(zip(vb, vn)):
+        B = xt.shape[0]
+        split = SPLIT_STAGE3 and side is not None and B >= 2 and B % 2 == 0 and len(vb) == 16
+        i = 0
+        while i < len(vb):
+            blk, nm = vb[i], vn[i]
+            if split and i == 4:
+                # EXPERIMENT (CSTS_SPLIT_STAGE3=1): blocks 4..13 (384 channels, 2048 tokens per clip: every kernel one latency-bound
+                # round) as two half-batch chains on two streams
+                xt, thw = self._run_halves(xt, thw, km, vb[4:14], vn[4:14], main)
+                i = 14
+                xt, keep = ops.tap(xt, rt.compute)
+                inter.append(keep)
+                inter_thw.append(list(thw))
+                continue
             if cut_at and i == cut_at:
                 xt = boundary.inner([xt])[0]
             xt, thw, _ = blk(xt, thw, km.get(nm))
@@ -522,6 +565,7 @@ class CSTS(nn.Module):
                 xt, keep = ops.tap(xt, rt.compute)
                 inter.append(keep)
                 inter_thw.append(list(thw))
+            i += 1
         if side is not None:
             main.wait_stream(side)
             yt.record_stream(main)
