@@ -743,7 +743,14 @@ def main():
             import work_model
             n_par = sum(p.numel() for p in core.parameters())
             n_sh = sum(l.weight.numel() for l in (getattr(core, "_w16_all", None) or []))
-            extra["adamw_step"] = work_model.work_adamw(n_par, n_sh)
+            fac = getattr(opt, "_factored", None) or []       # fusion convs updated from their gradient factors (csts_adamw_factored)
+            n_fac = sum(opt.params[i].numel() for i, _, _ in fac)
+            n_fac_sh = sum(opt.params[i].numel() for i, _, _ in fac if i in getattr(opt, "_shadow_by_index", {}))
+            extra["adamw_step"] = work_model.work_adamw(n_par - n_fac, n_sh - n_fac_sh)
+            if fac:
+                fbytes = sum(dy.numel() * dy.element_size() + a_.numel() * a_.element_size() for _, dy, a_ in fac)
+                extra["adamw_factored"] = (n_fac * 24 + n_fac_sh * 2 + fbytes, sum(2.0 * dy.shape[0] * opt.params[i].numel() for i, dy, _ in fac))
+                extra["factored_sqnorm"] = (fbytes, sum(2.0 * dy.shape[0] * dy.shape[0] * (dy.shape[1] + a_.shape[1]) for _, dy, a_ in fac))
             ops_ms = per_entry = ot.summary(1, extra)
             tot = t_ev0.elapsed_time(t_ev1)
             if args.op_breakdown:

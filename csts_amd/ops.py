@@ -548,6 +548,11 @@ def flush_stencil_wgrads():
         nblocks = C.c_int(0)
         L.check(_lib().csts_dwconv_wgrad_grouped_plan(items, len(sel), image, len(image), C.byref(nblocks)), "csts_dwconv_wgrad_grouped_plan")
         ptr = tab.upload(bytes(image))
+        if WG_STATS is not None:          # fine + coarse read once; 2 x 27 flop per coarse cell and channel
+            esz = 4 if dt == F32 else 2
+            cells = lambda gg: (gg.B * gg.Tf * gg.Hf * gg.Wf, gg.B * gg.Tc * gg.Hc * gg.Wc)
+            WG_STATS.append(("csts_dwconv_wgrad_grouped", sum(sum(cells(e[0])) * e[0].C * esz for e in sel),
+                             sum(54.0 * cells(e[0])[1] * e[0].C for e in sel)))
         L.check(_lib().csts_dwconv_wgrad_grouped(ptr, len(sel), nblocks.value, dt, _stream()), "csts_dwconv_wgrad_grouped")
     return q            # the operands: the caller keeps them alive until the launch stream has been joined
 
