@@ -93,13 +93,13 @@ def main():
     FAM = [("LayerNorm forward", r"^ln_fwd", ["layernorm_fwd", "layernorm_fwd_add"]),
            ("LayerNorm backward", r"^ln_bwd", ["layernorm_bwd_ex", "layernorm_bwd", "layernorm_bwd2"]),
            ("conv-pool + LN(hd) forward", r"^pool_ln_fwd", ["pool_ln_fwd"]),
-           ("stencil weight gradients", r"^dwconv_wgrad", ["dwconv_wgrad", "dwconv_wgrad2"]),
+           ("stencil weight gradients", r"^dwconv_wgrad", ["dwconv_wgrad", "dwconv_wgrad2", "dwconv_wgrad_grouped"]),
            ("transposed / strided stencils", r"^dwconv_(transposed|strided)", ["dwconv_transposed", "dwconv_transposed2", "dwconv_strided"]),
            ("attention forward", r"^attn_fwd", ["attn_fwd"]),
            ("attention backward", r"^attn_(dq|dkv|bwd_fused)", ["attn_bwd"]),
            ("grouped weight gradients 192x384", r"^wgrad8", ["wgrad_grouped8"]),
            ("grouped weight gradients 128/256x128", r"^wgrad_grouped", ["wgrad_grouped"]),
-           ("clip + AdamW", r"^opt_", ["adamw_step"]),
+           ("clip + AdamW", r"^(opt_|factored_)", ["adamw_step", "adamw_factored", "factored_sqnorm"]),
            ("max-pool skip", r"^maxpool", ["maxpool_fwd", "maxpool_bwd"]),
            ("trilinear", r"^trilinear", ["trilinear_fwd", "trilinear_bwd"]),
            ("all GEMM kernels", r"^(gemm|splitk_finish)", ["gemm"])]
