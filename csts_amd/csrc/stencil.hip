@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -712,9 +713,13 @@ __global__ void dwconv_wgrad_kernel(RowGeom rg, WgSlots2 sl, int slab, int chunk
 // lives in device memory (written by csts_dwconv_wgrad_grouped_plan on the host, uploaded by the caller); workgroup -> item by
 // the items' first-block numbers (items sorted longest workgroups first), fixed 512-thread workgroups cut into
 // (slab / 2) x lanes like the single launch's.
+// (pointers that are LOADED from memory are generic to the compiler and become flat_load / flat_store; declared in the global
+// address space here, the casts at the call site let it prove the accesses global again)
+typedef __attribute__((address_space(1))) const void* gcvoid_p;
+typedef __attribute__((address_space(1))) float* gfloat_p;
 struct WgItem {
   Geom g;
-  const void* fine; const void* coarse; float* ws;
+  gcvoid_p fine; gcvoid_p coarse; gfloat_p ws;
   int slab, chunk, nslab, lanes;
   int block_begin, nblocks;
 };
@@ -728,8 +733,8 @@ __global__ __launch_bounds__(WG_GROUP_THREADS) void dwconv_wgrad_grouped_kernel(
   const int local = blockIdx.x - w.block_begin;
   const int half = w.slab / 2;
   const int ty = threadIdx.x / half, tx = threadIdx.x - ty * half;
-  dwconv_wgrad_body<F32, F32>(w.g, w.fine, w.coarse, w.ws, w.slab, w.chunk, local % w.nslab, local / w.nslab, w.nslab, tx, ty, w.lanes,
-                              WG_GROUP_THREADS, red);
+  dwconv_wgrad_body<F32, F32>(w.g, (const void*)w.fine, (const void*)w.coarse, (float*)w.ws, w.slab, w.chunk, local % w.nslab, local / w.nslab,
+                              w.nslab, tx, ty, w.lanes, WG_GROUP_THREADS, red);
 }
 
 // ------------------------------------------------------------------ max-pool skip
@@ -1285,7 +1290,7 @@ extern "C" int csts_dwconv_wgrad_grouped_plan(const csts_dwconv_wgrad_item* item
     RowGeom rg; fill_geom(a, rg);
     WgItem& w = tab[(size_t)i];
     w.g = rg.g;
-    w.fine = items[i].fine; w.coarse = items[i].coarse; w.ws = reinterpret_cast<float*>(items[i].workspace);
+    w.fine = (gcvoid_p)items[i].fine; w.coarse = (gcvoid_p)items[i].coarse; w.ws = (gfloat_p)reinterpret_cast<float*>(items[i].workspace);
     w.slab = slab; w.chunk = (int)chunk; w.nslab = nslab;
     w.lanes = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, WG_GROUP_THREADS / (slab / 2)), chunk / 2));
     w.nblocks = (int)(nchunk * nslab);
