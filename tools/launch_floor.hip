@@ -13,6 +13,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 __global__ void empty_kernel(int* p) { if (p != nullptr && threadIdx.x == 9999) p[0] = 1; }
+__global__ void spin_kernel(int* p, int ticks) {      // busy for `ticks` counts of the 100 MHz realtime counter
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) { }
+  if (threadIdx.x == 9999) p[0] = 1;
+}
 
 template <int SM>
 __global__ __launch_bounds__(256) void writer_kernel(v4i* __restrict__ out, int64_t n16, int seed) {
@@ -76,6 +81,27 @@ int main() {
   for (int grid : {1, 256, 2048}) {
     hipGraphExec_t g = capture(s, [&] { for (int i = 0; i < NODES; ++i) hipLaunchKernelGGL(empty_kernel, dim3(grid), dim3(256), 0, s, sink); });
     printf("empty kernel chain, grid %5d: %.2f us per node\n", grid, time_graph(g, s, 20) * 1e3 / NODES);
+  }
+  // fork / join inside a captured graph: [A -> (B on a second stream || C) -> D] against A -> B -> C -> D, kernels that spin ~DUR us
+  {
+    hipStream_t s2; CK(hipStreamCreate(&s2));
+    hipEvent_t ef, ej; CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    for (int dur : {0, 5, 20}) {
+      const int G = 64;
+      auto K = [&](hipStream_t st) { hipLaunchKernelGGL(spin_kernel, dim3(64), dim3(256), 0, st, sink, dur * 100); };   // ~100 clocks of 100 MHz s_memrealtime per us
+      hipGraphExec_t serial = capture(s, [&] { for (int i = 0; i < G; ++i) { K(s); K(s); K(s); K(s); } });
+      hipGraphExec_t forked = capture(s, [&] {
+        for (int i = 0; i < G; ++i) {
+          K(s);
+          CK(hipEventRecord(ef, s)); CK(hipStreamWaitEvent(s2, ef, 0));
+          K(s2); K(s);
+          CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s, ej, 0));
+          K(s);
+        }
+      });
+      printf("4 kernels of ~%2d us: serial %.2f us per group, with one fork / join (2 run side by side) %.2f us per group\n", dur,
+             time_graph(serial, s, 10) * 1e3 / G, time_graph(forked, s, 10) * 1e3 / G);
+    }
   }
   const int NBUF = 6;                                           // rotating buffers: 6 x 200 MB > the 256 MB memory-side cache
   const int64_t MAXB = 200ll << 20;
