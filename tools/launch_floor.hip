@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <utility>
 typedef int v4i __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -51,6 +52,17 @@ __global__ __launch_bounds__(256) void rw_kernel(const v4i* __restrict__ a, cons
   }
 }
 template <int LM, int SM> static void launch_rw(const v4i* a, const v4i* b, v4i* c, int64_t n16, int grid, hipStream_t s) { hipLaunchKernelGGL((rw_kernel<LM, SM>), dim3(grid), dim3(256), 0, s, a, b, c, n16); }
+
+// distinct kernels of a few KB of code each (I-dependent constants in an unrolled chain): does a launch pay for a cold instruction cache?
+template <int I>
+__global__ __launch_bounds__(256) void code_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  float x = in[blockIdx.x * 256 + threadIdx.x];
+#pragma unroll
+  for (int j = 0; j < 256; ++j) x = x * (1.0f + 1e-6f * (float)(I * 256 + j)) + (float)(j ^ I) * 1e-7f;
+  out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+typedef void (*code_fn)(const float*, float*);
+template <int... Is> static void fill_code_fns(code_fn* f, std::integer_sequence<int, Is...>) { ((f[Is] = code_kernel<Is>), ...); }
 
 static float time_graph(hipGraphExec_t g, hipStream_t s, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -101,6 +113,15 @@ int main() {
       });
       printf("4 kernels of ~%2d us: serial %.2f us per group, with one fork / join (2 run side by side) %.2f us per group\n", dur,
              time_graph(serial, s, 10) * 1e3 / G, time_graph(forked, s, 10) * 1e3 / G);
+    }
+  }
+  {
+    code_fn fns[64];
+    fill_code_fns(fns, std::make_integer_sequence<int, 64>());
+    float *a, *b; CK(hipMalloc(&a, 1 << 20)); CK(hipMalloc(&b, 1 << 20)); CK(hipMemset(a, 0, 1 << 20));
+    for (int distinct : {1, 2, 8, 64}) {
+      hipGraphExec_t g = capture(s, [&] { for (int i = 0; i < 256; ++i) hipLaunchKernelGGL(fns[i % distinct], dim3(512), dim3(256), 0, s, (const float*)a, b); });
+      printf("chain of 256 launches (512 workgroups, ~3 KB of code each) cycling over %2d distinct kernels: %.2f us per node\n", distinct, time_graph(g, s, 10) * 1e3 / 256);
     }
   }
   const int NBUF = 6;                                           // rotating buffers: 6 x 200 MB > the 256 MB memory-side cache
