@@ -224,13 +224,26 @@ template <int GL> __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs; like the GEMMs (gemm.hip), give XCD x the CONTIGUOUS row range x of 8: a
+// consumer then finds what the producer's workgroups of the same XCD have just written in that XCD's L2 instead of the memory-side
+// cache (tools/launch_floor.hip, profiles/r4_stream_policy.txt part 5: 6 MB handed over in 1.65 us instead of 4.8 us; it holds up to
+// ~1 MB per XCD).  Bijective for any grid size.  -DCSTS_LN_NO_XCD_MAP: the plain order (A/B builds).
+__device__ __forceinline__ int64_t xcd_block(int64_t bid, int64_t nwg) {
+#ifdef CSTS_LN_NO_XCD_MAP
+  return bid;
+#else
+  const int64_t q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+#endif
+}
+
 template <int GL, int NCH, int R, bool XF32, bool YF32>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, void* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
                                                          int C, float eps, FwdAdd fa) {
   const int sub = threadIdx.x % GL;
-  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) / GL, ngrp = (int64_t)gridDim.x * 256 / GL;
+  const int64_t grp = (xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) / GL, ngrp = (int64_t)gridDim.x * 256 / GL;
   int c0[NCH];
   bool act[NCH];
   float gm[NCH][8], bt[NCH][8];
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const void* __restrict_
   ws += (int64_t)blockIdx.y * gridDim.x * 2 * C;
   const int sub = threadIdx.x % GL, gib = threadIdx.x / GL;    // group in block
   constexpr int GPB = 512 / GL;
-  const int64_t grp = (int64_t)blockIdx.x * GPB + gib, ngrp = (int64_t)gridDim.x * GPB;
+  const int64_t grp = xcd_block(blockIdx.x, gridDim.x) * GPB + gib, ngrp = (int64_t)gridDim.x * GPB;
   int c0[NCH];
   bool act[NCH];
   float gm[NCH][8], dg[NCH][8], db[NCH][8];

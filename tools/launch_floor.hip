@@ -64,6 +64,20 @@ __global__ __launch_bounds__(256) void code_kernel(const float* __restrict__ in,
 typedef void (*code_fn)(const float*, float*);
 template <int... Is> static void fill_code_fns(code_fn* f, std::integer_sequence<int, Is...>) { ((f[Is] = code_kernel<Is>), ...); }
 
+// Does a consumer find the producer's lines in the XCD's L2?  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8); the
+// writer's workgroup b writes chunk b; the reader's workgroup b reads chunk (b + shift) % grid: shift 0 = the same XCD as the writer,
+// shift 1 = the next XCD.  Chunks of 16 KB, whole buffer S bytes.
+__global__ __launch_bounds__(256) void chunk_writer(v4i* __restrict__ out, int seed) {
+  v4i* o = out + (int64_t)blockIdx.x * 1024;
+  for (int i = threadIdx.x; i < 1024; i += 256) { v4i v = {seed, i, (int)blockIdx.x, 7}; o[i] = v; }
+}
+__global__ __launch_bounds__(256) void chunk_reader(const v4i* __restrict__ in, int shift, int* __restrict__ sink) {
+  const v4i* p = in + (int64_t)((blockIdx.x + shift) % gridDim.x) * 1024;
+  v4i acc = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < 1024; i += 256) acc ^= p[i];
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) sink[0] = 1;
+}
+
 static float time_graph(hipGraphExec_t g, hipStream_t s, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(g, s));
@@ -122,6 +136,24 @@ int main() {
     for (int distinct : {1, 2, 8, 64}) {
       hipGraphExec_t g = capture(s, [&] { for (int i = 0; i < 256; ++i) hipLaunchKernelGGL(fns[i % distinct], dim3(512), dim3(256), 0, s, (const float*)a, b); });
       printf("chain of 256 launches (512 workgroups, ~3 KB of code each) cycling over %2d distinct kernels: %.2f us per node\n", distinct, time_graph(g, s, 10) * 1e3 / 256);
+    }
+  }
+  {
+    v4i* cb[4];
+    for (auto& b : cb) CK(hipMalloc(&b, 64 << 20));
+    printf("\nproducer -> consumer through the XCD's L2?  us per [writer, reader] pair (writer alone in brackets), rotating over 4 buffers\n");
+    for (int mb : {2, 6, 12, 24, 48}) {
+      const int grid = mb * 64;                                   // 16 KB chunks
+      float w_only, r[3];
+      { hipGraphExec_t g = capture(s, [&] { for (int i = 0; i < 64; ++i) hipLaunchKernelGGL(chunk_writer, dim3(grid), dim3(256), 0, s, cb[i % 4], i); });
+        w_only = time_graph(g, s, 5) * 1e3 / 64; }
+      int k = 0;
+      for (int shift : {0, 1, 4}) {
+        hipGraphExec_t g = capture(s, [&] { for (int i = 0; i < 64; ++i) { hipLaunchKernelGGL(chunk_writer, dim3(grid), dim3(256), 0, s, cb[i % 4], i);
+                                                                         hipLaunchKernelGGL(chunk_reader, dim3(grid), dim3(256), 0, s, (const v4i*)cb[i % 4], shift, sink); } });
+        r[k++] = time_graph(g, s, 5) * 1e3 / 64;
+      }
+      printf("%3d MB: same XCD %.2f   next XCD %.2f   XCD + 4 %.2f   (writer alone %.2f)\n", mb, r[0], r[1], r[2], w_only);
     }
   }
   const int NBUF = 6;                                           // rotating buffers: 6 x 200 MB > the 256 MB memory-side cache
