@@ -519,6 +519,23 @@ __device__ __forceinline__ void stage_rows_out_wave(bf16* S, void* dst, int64_t 
 // ---------------------------------------------------------------------------------------------- forward
 // hd 96 / bf16: a 256-register budget = two workgroups (2 waves per SIMD) per CU; unconstrained the compiler took 272
 // registers and the kernel ran one wave per SIMD (63 -> 44 us on the 32 k-query x 512-key block, 108 -> 64 us on the decoder)
+// Workgroups are dealt round-robin over the 8 XCDs in linear-id order (x fastest), so the query tiles (forward, dQ) or key blocks and
+// splits (dK/dV) of ONE (clip, head) land on all eight XCDs and each XCD's L2 fetches that head's K / V (or Q / dO) again: PMC traffic
+// 1.8 x (forward) and 2.9 x (backward) the algorithmic bytes (profiles/r4_v6_mfma_util.txt).  The remap gives XCD x the contiguous
+// eighth x of the linear ids -- all workgroups of a (clip, head) on one XCD.  Bijective for any grid.  -DCSTS_ATTN_NO_XCD_MAP: plain order.
+__device__ __forceinline__ void xcd_remap3(int& bx, int& by, int& bz) {
+#ifdef CSTS_ATTN_NO_XCD_MAP
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#else
+  const int gx = gridDim.x, gy = gridDim.y, n = gx * gy * (int)gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int q = n >> 3, r = n & 7, xcd = lin & 7, slot = lin >> 3;
+  const int l2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  bx = l2 % gx;
+  by = (l2 / gx) % gy;
+  bz = l2 / (gx * gy);
+#endif
+}
 template <int HD, bool F32>
 __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_kernel(AttnP p) {
   typedef typename El<F32>::T T;
@@ -527,8 +544,10 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_ke
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  int BX, BY, BZ;
+  xcd_remap3(BX, BY, BZ);                // XCD-contiguous workgroup order: see xcd_remap3
+  const int b = BZ, head = BY;
+  const int qraw = BX * 128 + w * 32 + (lane & 31);
   const bool qvalid = qraw < p.Nq;
   const int qi = qvalid ? qraw : p.Nq - 1;
 
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_ke
   if constexpr (F32) {
     qf.load(p.Q, (int64_t)b * p.q_bs + (int64_t)qi * p.q_ts + (int64_t)head * p.q_hs, h);
   } else {
-    stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+    stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, BX * 128, p.Nq, tid);
     __syncthreads();
     frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
     __syncthreads();          // the K/V tile loop reuses this LDS
@@ -612,7 +631,7 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_ke
   if constexpr (F32) {
     if (qvalid) store_rows<HD>(p.O, p.dt, (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + (int64_t)head * p.o_hs, O, 1.f / lsum, h);
   } else {
-    stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, O, 1.f / lsum,
+    stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, BX * 128, p.Nq, O, 1.f / lsum,
                        w * 32 + (lane & 31), h, tid);
   }
   if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
@@ -629,13 +648,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_fast_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  int BX, BY, BZ;
+  xcd_remap3(BX, BY, BZ);                // XCD-contiguous workgroup order: see xcd_remap3
+  const int b = BZ, head = BY;
+  const int qraw = BX * 128 + w * 32 + (lane & 31);
   const bool qvalid = qraw < p.Nq;
   const int qi = qvalid ? qraw : p.Nq - 1;
 
   RowFrag<HD, false> qf;
-  stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+  stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, BX * 128, p.Nq, tid);
   __syncthreads();
   frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
   __syncthreads();          // the K/V tile loop reuses this LDS
@@ -724,7 +745,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_fast_kernel(AttnP p) {
     });
   });
   lsum += __shfl_xor(lsum, 32, 64);
-  stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, O, 1.f / lsum,
+  stage_rows_out<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, BX * 128, p.Nq, O, 1.f / lsum,
                      w * 32 + (lane & 31), h, tid);
   if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
 }
@@ -738,8 +759,10 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  int BX, BY, BZ;
+  xcd_remap3(BX, BY, BZ);                // XCD-contiguous workgroup order: see xcd_remap3
+  const int b = BZ, head = BY;
+  const int qraw = BX * 128 + w * 32 + (lane & 31);
   const bool qvalid = qraw < p.Nq;
   const int qi = qvalid ? qraw : p.Nq - 1;
 
@@ -754,9 +777,9 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
     // two LDS staging regions
     constexpr int LDS_LD = HD + 8;
     TileStage<HD, 128> tq, tdo, to;
-    tq.gload(p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
-    tdo.gload(p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, blockIdx.x * 128, p.Nq, tid);
-    to.gload(p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+    tq.gload(p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, BX * 128, p.Nq, tid);
+    tdo.gload(p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, BX * 128, p.Nq, tid);
+    to.gload(p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, BX * 128, p.Nq, tid);
     tq.lstore(smem, LDS_LD, tid);
     tdo.lstore(smem + 128 * LDS_LD, LDS_LD, tid);
     __syncthreads();
@@ -768,11 +791,11 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
     frag_from_lds<HD>(of_pre, smem, w * 32 + (lane & 31), h);
     __syncthreads();
   } else {
-    stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
+    stage_rows_in<HD>(smem, p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, BX * 128, p.Nq, tid);
     __syncthreads();
     frag_from_lds<HD>(qf, smem, w * 32 + (lane & 31), h);
     __syncthreads();
-    stage_rows_in<HD>(smem, p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, blockIdx.x * 128, p.Nq, tid);
+    stage_rows_in<HD>(smem, p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, BX * 128, p.Nq, tid);
     __syncthreads();
     frag_from_lds<HD>(dof, smem, w * 32 + (lane & 31), h);
     __syncthreads();
@@ -791,7 +814,7 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
       if constexpr (PRE3) {
         of = of_pre;
       } else {
-        stage_rows_in<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+        stage_rows_in<HD>(smem, p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, BX * 128, p.Nq, tid);
         __syncthreads();
         frag_from_lds<HD>(of, smem, w * 32 + (lane & 31), h);
         __syncthreads();
@@ -844,7 +867,7 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
     if (qvalid)
       store_rows<HD>(p.dQ, p.dt, (int64_t)b * p.dq_bs + (int64_t)qi * p.dq_ts + (int64_t)head * p.dq_hs, acc, p.scale, h);
   } else {
-    stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, blockIdx.x * 128, p.Nq, acc, p.scale,
+    stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, BX * 128, p.Nq, acc, p.scale,
                        w * 32 + (lane & 31), h, tid);
   }
 }
@@ -863,8 +886,10 @@ __global__ __launch_bounds__(256, (KT == 2 ? 2 : 1)) void attn_dq_fast_kernel(At
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int qraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  int BX, BY, BZ;
+  xcd_remap3(BX, BY, BZ);                // XCD-contiguous workgroup order: see xcd_remap3
+  const int b = BZ, head = BY;
+  const int qraw = BX * 128 + w * 32 + (lane & 31);
   const bool qvalid = qraw < p.Nq;
   const int qi = qvalid ? qraw : p.Nq - 1;
 
@@ -875,9 +900,9 @@ __global__ __launch_bounds__(256, (KT == 2 ? 2 : 1)) void attn_dq_fast_kernel(At
     // two LDS staging regions
     RowFrag<HD, false> of;
     TileStage<HD, 128> tq, tdo, to;
-    tq.gload(p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, blockIdx.x * 128, p.Nq, tid);
-    tdo.gload(p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, blockIdx.x * 128, p.Nq, tid);
-    to.gload(p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, blockIdx.x * 128, p.Nq, tid);
+    tq.gload(p.Q, (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, p.q_ts, BX * 128, p.Nq, tid);
+    tdo.gload(p.dO, (int64_t)b * p.do_bs + (int64_t)head * p.do_hs, p.do_ts, BX * 128, p.Nq, tid);
+    to.gload(p.O, (int64_t)b * p.o_bs + (int64_t)head * p.o_hs, p.o_ts, BX * 128, p.Nq, tid);
     tq.lstore(smem, LD, tid);
     tdo.lstore(smem + 128 * LD, LD, tid);
     __syncthreads();
@@ -975,7 +1000,7 @@ __global__ __launch_bounds__(256, (KT == 2 ? 2 : 1)) void attn_dq_fast_kernel(At
       __builtin_amdgcn_sched_barrier(0);
     });
   });
-  stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, blockIdx.x * 128, p.Nq, acc, p.scale,
+  stage_rows_out<HD>(smem, p.dQ, (int64_t)b * p.dq_bs + (int64_t)head * p.dq_hs, p.dq_ts, BX * 128, p.Nq, acc, p.scale,
                      w * 32 + (lane & 31), h, tid);
 }
 
@@ -997,9 +1022,11 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.z / p.H, head = blockIdx.z % p.H;
-  const int split = blockIdx.y;
-  const int kraw = blockIdx.x * 128 + w * 32 + (lane & 31);
+  int BX, BY, BZ;
+  xcd_remap3(BX, BY, BZ);                // XCD-contiguous workgroup order: see xcd_remap3
+  const int b = BZ / p.H, head = BZ % p.H;
+  const int split = BY;
+  const int kraw = BX * 128 + w * 32 + (lane & 31);
   const bool kvalid = kraw < p.Nk;
   const int ki = kvalid ? kraw : p.Nk - 1;
 
@@ -1018,7 +1045,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   const float* Drow = p.delta + ((int64_t)b * p.H + head) * p.Nq;
   const int fk = frame_of(p, ki);
 #ifdef CSTS_ATTN_STAMPS
-  const bool stamp_on = tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  const bool stamp_on = tid == 0 && BX == 0 && BY == 0 && BZ == 0;
   int nstamp = 1;
 #endif
   AT_STAMP();
@@ -1185,8 +1212,10 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
   float* Ls = reinterpret_cast<float*>(smem + 5 * TILE);   // LSE and delta of the tile's 128 queries
   float* Ds = Ls + 128;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int b = blockIdx.y / p.H, head = blockIdx.y % p.H;
-  const int split = blockIdx.x;
+  int BX, BY, BZ;
+  xcd_remap3(BX, BY, BZ);                // XCD-contiguous workgroup order: see xcd_remap3
+  const int b = BY / p.H, head = BY % p.H;
+  const int split = BX;
   const int qbeg = split * p.q_chunk, qend = min(p.Nq, qbeg + p.q_chunk);
   const int64_t kbase = (int64_t)b * p.k_bs + (int64_t)head * p.k_hs, vbase = (int64_t)b * p.v_bs + (int64_t)head * p.v_hs;
   const int64_t qbase = (int64_t)b * p.q_bs + (int64_t)head * p.q_hs, dobase = (int64_t)b * p.do_bs + (int64_t)head * p.do_hs;
