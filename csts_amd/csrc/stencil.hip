@@ -14,7 +14,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
 #include <vector>
 
 namespace {
