@@ -440,7 +440,7 @@ def flush_wgrads(side: bool = False):
     key = (dev.index, side)
     tab = _wg_tables.get(key)
     if tab is None:
-        tab = _wg_tables[key] = HostTable(C.sizeof(L.WgradItem) * 16384, dev, ring=8, captures=40 if side else 16)
+        tab = _wg_tables[key] = HostTable(C.sizeof(L.WgradItem) * 24576, dev, ring=8, captures=40 if side else 16)
     keep = []
     launch_stream = None
     if side:
@@ -461,6 +461,7 @@ def flush_wgrads(side: bool = False):
         if WGRAD8 and t[5] % 192 == 0 and t[6] % 384 == 0 and t[4] % 64 == 0 and WGRAD8_CHUNK % 64 == 0:
             return (False, 192)
         return (False, 256 if t[5] % 256 == 0 else 128)
+    pend = []           # (item table image, items, tile rows, fp32 dY) per tile class
     for a_f32, rows in ((False, 192), (False, 256), (False, 128), (True, 128)):
         probs = [t for t in q if tile_class(t) == (a_f32, rows)]
         if not probs:
@@ -490,12 +491,23 @@ def flush_wgrads(side: bool = False):
         arr["B"][valid] = B[pidx]
         arr["C"][valid] = Cb[pidx] + ch * cstride[pidx]
         arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
-        with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
-            ptr = tab.upload(arr.tobytes())
-            if WG_STATS is not None:      # dY + X read once, dW written once; 2 tokens N K flop
-                WG_STATS.append(("csts_wgrad_grouped8" if rows == 192 else "csts_wgrad_grouped",
-                                 sum(t[4] * t[5] * t[0].element_size() + t[4] * t[6] * 2 + t[5] * t[6] * 4 for t in probs),
-                                 sum(2.0 * t[4] * t[5] * t[6] for t in probs)))
+        if WG_STATS is not None:      # dY + X read once, dW written once; 2 tokens N K flop
+            WG_STATS.append(("csts_wgrad_grouped8" if rows == 192 else "csts_wgrad_grouped",
+                             sum(t[4] * t[5] * t[0].element_size() + t[4] * t[6] * 2 + t[5] * t[6] * 4 for t in probs),
+                             sum(2.0 * t[4] * t[5] * t[6] for t in probs)))
+        pend.append((arr.tobytes(), n_items, rows, a_f32))
+    # the item tables of all tile classes travel in ONE host -> device copy (a copy node per class cost ~12 us each in the replayed
+    # step, gap included); one copy per class only when they do not fit the table together
+    with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
+        offs, total = [], 0
+        for blob, *_ in pend:
+            offs.append(total)
+            total += (len(blob) + 255) // 256 * 256
+        base = None
+        if pend and total <= tab.nbytes:
+            base = tab.upload(b"".join(blob + bytes((-len(blob)) % 256) for blob, *_ in pend))
+        for (blob, n_items, rows, a_f32), off in zip(pend, offs):
+            ptr = base + off if base is not None else tab.upload(blob)
             if rows == 192:
                 L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
             else:
