@@ -1189,6 +1189,18 @@ bool pick4(const csts_gemm_args* a, int split, int* variant) {
   // the GEMMs with a bf16 output (qkv, fc1 + GELU, the data gradients that feed bf16) and LOSES 5-15 % on the fp32
   // residual-stream outputs (proj, fc2: C and the residual are 4 bytes per element and the register epilogue reaches them in
   // 32-byte row segments, where gemm2's LDS-staged epilogue moves whole 128-byte lines): bf16 outputs only.
+  // Round 4 (end): the fp32 residual-stream outputs have their own form now (gemm4 FORM 5: unswapped MFMA operands, so that the
+  // register epilogue touches whole 128-byte row runs): the whole-tile N % 192 == 0, K % 64 == 0 cases without an up-sampled skip take it
+  // (inside the replayed step 0.70-1.00 x the time of gemm2 / gemm3 on every routed shape, -0.1 ms per step in all:
+  // profiles/r4_gemm4_res_form.txt).  CSTS_GEMM4_RES=0 is the A/B switch.
+  if (a->c_dt == CSTS_F32 && a->residual != nullptr) {
+    static const bool res_on = [] { const char* e = getenv("CSTS_GEMM4_RES"); return !(e && e[0] == '0'); }();
+    if (!res_on || a->r_dt != CSTS_F32 || a->res_row_mod != 0 || a->epilogue != CSTS_EPI_NONE || a->M % 128 != 0 || a->N % 192 != 0 ||
+        (a->M / 128) * (a->N / 192) < 128)
+      return false;
+    *variant = 63;        // the 3-stage ring at one workgroup per CU: FORM 5 needs more than the 128 registers of the two-workgroup variants (62: 1.6 x slower)
+    return true;
+  }
   if (a->c_dt != CSTS_BF16 || a->residual != nullptr) return false;
   const int64_t rows = cdiv(a->M, 128);
   if (a->N % 192 == 0 && rows * (a->N / 192) >= 256) {

@@ -192,7 +192,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
       // vector memory retires in order on one counter, so a count without them drained every store of the previous tile
       // before the first MFMA of the next one (EPI_ST is exact for the straight-line forms; 0 = over-wait for the generic one)
       if constexpr (NP == 0) {
-        constexpr int EPI_ST = (FORM == 0) ? 0 : MT * NT * 2;      // a lower bound (FORM 2 stores twice as many when it keeps the pre-activation): under-counting only over-waits
+        constexpr int EPI_ST = (FORM == 0 || FORM == 5) ? 0 : MT * NT * 2;      // a lower bound (FORM 2 stores twice as many when it keeps the pre-activation): under-counting only over-waits
         static_assert(2 * LPT + EPI_ST <= 63, "vmcnt immediate");
         const int ahead = min(S - 2, total_k - 1 - cidx);
         if (EPI_ST > 0 && STORE_AWARE && t != t_first && kt < S - 1) {
@@ -243,7 +243,8 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            acc[i][j] = CSTS_MFMA16(fb[ks & (DB - 1)][j], fa[ks & (DB - 1)][i], acc[i][j], 0, 0, 0);
+            if constexpr (FORM == 5) acc[i][j] = CSTS_MFMA16(fa[ks & (DB - 1)][i], fb[ks & (DB - 1)][j], acc[i][j], 0, 0, 0);   // rows = tokens: see the FORM 5 epilogue
+            else acc[i][j] = CSTS_MFMA16(fb[ks & (DB - 1)][j], fa[ks & (DB - 1)][i], acc[i][j], 0, 0, 0);
         if (DB == 1 && ks + 1 < NKS) frags(ks + 1, 0);
       }
       if (refill) advance();
@@ -264,7 +265,52 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
     // 8.5 k cycles of epilogue against 5.9 k of MFMA work per tile, 19.8 k with GELU.  Here the epilogue kind is a compile-time
     // case, the code is straight-line, and the loads of column unit ni + 1 are issued BEFORE the stores of unit ni, so the wait
     // for them is a counted one that leaves the stores in flight.  Same arithmetic, same order: bit-identical results.
-    if constexpr (FORM != 0) {
+    if constexpr (FORM == 5) {
+      // fp32 residual-stream form (proj / fc2 forward: C = (acc + bias) * row_scale + residual, all fp32, whole tiles).  The MFMA
+      // operands are NOT swapped here: accumulator r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of its
+      // 32 x 32 block, so every load / store instruction of a half-wave covers one whole 128-byte run of a row -- the register
+      // epilogue of the swapped layout reached fp32 rows in 32-byte segments, which is why this family lost to gemm2's LDS-staged
+      // epilogue on these shapes (profiles/r2_gemm4_instep_ab.txt).  The residual runs of column block ni + 1 are requested before
+      // the stores of block ni (vector memory retires in order).  Same arithmetic order as gemm2: bit-identical.
+      float* __restrict__ Cf = reinterpret_cast<float*>(p.C);
+      const float* __restrict__ Rf = reinterpret_cast<const float*>(p.residual);
+      const int64_t mb = m0 - (lane & 31) + 4 * hi, nb = n0 - 4 * hi + (lane & 31);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int64_t mrow = mb + mi * 32;
+        float sc[16];
+        if (p.row_scale != nullptr) {
+          const int64_t s_lo = (mrow - 4 * hi) / p.rows_per_scale, s_hi = (mrow - 4 * hi + 31) / p.rows_per_scale;      // wave-uniform
+          if (s_lo == s_hi) {
+            const float v = p.row_scale[s_lo];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = v;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = p.row_scale[(mrow + (r & 3) + 8 * (r >> 2)) / p.rows_per_scale];
+          }
+        }
+        float rr[2][16];
+        auto loads = [&](int ni, int buf) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rr[buf][r] = Rf[(mrow + (r & 3) + 8 * (r >> 2)) * p.ldr + nb + ni * 32];
+        };
+        loads(0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int cur = ni & 1;
+          const float bq = p.bias != nullptr ? p.bias[nb + ni * 32] : 0.f;
+          if (ni + 1 < NT) loads(ni + 1, cur ^ 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[mi][ni][r] + bq;
+            if (p.row_scale != nullptr) v *= sc[r];
+            Cf[(mrow + (r & 3) + 8 * (r >> 2)) * p.ldc + nb + ni * 32] = v + rr[cur][r];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else if constexpr (FORM != 0) {
       bf16* __restrict__ Cb = reinterpret_cast<bf16*>(p.C);
       bf16* __restrict__ Xb = reinterpret_cast<bf16*>(p.aux);
       const int hi16 = hi << 4;
@@ -404,6 +450,9 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
 
 // which epilogue form (see gemm4_kernel) a problem takes on BM x BN tiles
 int gemm4_form(const Params& p, int BM, int BN) {
+  if (p.M % BM == 0 && p.N % BN == 0 && p.c_dt == CSTS_F32 && p.residual != nullptr && p.r_dt == CSTS_F32 && p.res_row_mod == 0 && p.ru_To == 0 &&
+      p.epilogue == CSTS_EPI_NONE && p.split_k <= 1)
+    return 5;
   if (p.M % BM != 0 || p.N % BN != 0 || p.c_dt != CSTS_BF16 || p.residual != nullptr || p.row_scale != nullptr) return 0;
   if (p.bias != nullptr) {
     if (p.epilogue == CSTS_EPI_NONE) return 1;
@@ -431,6 +480,7 @@ bool launch4(Params p, int wpc, hipStream_t s) {
     if (form == 2) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 2, NP>), grid, block, 0, s, p); return true; }
     if (form == 3) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 3, NP>), grid, block, 0, s, p); return true; }
     if (form == 4) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 4, NP>), grid, block, 0, s, p); return true; }
+    if (form == 5) { hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 5, NP>), grid, block, 0, s, p); return true; }
   }
   hipLaunchKernelGGL((gemm4_kernel<WM, MT, NT, S, 0, NP>), grid, block, 0, s, p);
   return true;
