@@ -112,6 +112,29 @@ def test_gemm_nt_persistent_kernel(algo, M, N, K):
     assert rel_l2(out32[:M], (pre - b) * hf.grad) < 1e-3
 
 
+@pytest.mark.parametrize("algo", [0, 462, 463])
+@pytest.mark.parametrize("rps", [512, 100])
+def test_gemm4_fp32_residual_form(algo, rps):
+    """gemm4 FORM 5 (fp32 C = (A W^T + bias) * drop-path scale + fp32 residual on unswapped MFMA operands: attention.py:238-248 proj / fc2
+    with the residual add): forced 2- and 3-stage variants and the library's own pick (which routes this shape there) against fp32
+    torch; per-sample scales whose boundaries fall INSIDE a 32-row unit (rps = 100) take the per-row path of the epilogue."""
+    M, N, K = 2048, 384, 192
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, scale=0.2).bfloat16(), rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    rs = rnd((M + rps - 1) // rps, seed=5).abs() + 0.5
+    out = torch.full((M + 1, N), 7.0, device=DEV)
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out, N, M, N, K, compute=L.BF16, bias=b, residual=res, ldr=N, row_scale=rs, rows_per_scale=rps, algo=algo)
+    ref = (A.float() @ W.float().t() + b) * rs.repeat_interleave(rps)[:M, None] + res
+    assert rel_l2(out[:M], ref) < 1e-4 and (out[M] == 7).all()
+    out2 = torch.full((M + 1, N), 7.0, device=DEV)
+    ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out2, N, M, N, K, compute=L.BF16, residual=res, ldr=N, algo=algo)          # no bias, no scale
+    assert rel_l2(out2[:M], A.float() @ W.float().t() + res) < 1e-4 and (out2[M] == 7).all()
+    if algo != 0:                                    # the same arithmetic in the same order as the LDS-staged epilogue of gemm2: the same bits
+        base = torch.empty(M, N, device=DEV)
+        ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, base, N, M, N, K, compute=L.BF16, bias=b, residual=res, ldr=N, row_scale=rs, rows_per_scale=rps, algo=2)
+        assert torch.equal(base, out[:M])
+
+
 @pytest.mark.parametrize("compute", [L.F32, L.BF16])
 def test_linear_and_mlp_autograd(compute):
     dt = tdt(compute)
