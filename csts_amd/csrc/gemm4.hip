@@ -291,7 +291,9 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
           }
         }
         float rr[2][16];
-        auto loads = [&](int ni, int buf) {
+        const int64_t nwave = n0 - 4 * hi;                      // wave-uniform: first column of this wave's 32-column blocks
+        auto loads = [&](int ni, int buf) {                      // (N % 32 == 0: a block is wholly inside the matrix or wholly outside)
+          if (nwave + ni * 32 >= p.N) return;
 #pragma unroll
           for (int r = 0; r < 16; ++r) rr[buf][r] = Rf[(mrow + (r & 3) + 8 * (r >> 2)) * p.ldr + nb + ni * 32];
         };
@@ -299,6 +301,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
           const int cur = ni & 1;
+          if (nwave + ni * 32 >= p.N) break;
           const float bq = p.bias != nullptr ? p.bias[nb + ni * 32] : 0.f;
           if (ni + 1 < NT) loads(ni + 1, cur ^ 1);
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ __launch_bounds__((G4<WM, MT, NT, S, NP>::NTHR), (G4<WM, MT, NT, S, N
 
 // which epilogue form (see gemm4_kernel) a problem takes on BM x BN tiles
 int gemm4_form(const Params& p, int BM, int BN) {
-  if (p.M % BM == 0 && p.N % BN == 0 && p.c_dt == CSTS_F32 && p.residual != nullptr && p.r_dt == CSTS_F32 && p.res_row_mod == 0 && p.ru_To == 0 &&
+  if (p.M % BM == 0 && p.N % 32 == 0 && p.c_dt == CSTS_F32 && p.residual != nullptr && p.r_dt == CSTS_F32 && p.res_row_mod == 0 && p.ru_To == 0 &&
       p.epilogue == CSTS_EPI_NONE && p.split_k <= 1)
     return 5;
   if (p.M % BM != 0 || p.N % BN != 0 || p.c_dt != CSTS_BF16 || p.residual != nullptr || p.row_scale != nullptr) return 0;

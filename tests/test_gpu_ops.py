@@ -129,6 +129,12 @@ def test_gemm4_fp32_residual_form(algo, rps):
     out2 = torch.full((M + 1, N), 7.0, device=DEV)
     ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out2, N, M, N, K, compute=L.BF16, residual=res, ldr=N, algo=algo)          # no bias, no scale
     assert rel_l2(out2[:M], A.float() @ W.float().t() + res) < 1e-4 and (out2[M] == 7).all()
+    # narrow outputs: N = 96 on 128-column tiles, the last 32-column block of every tile is outside the matrix
+    Mn, Nn = 1024, 96
+    An, Wn, bn, rn = rnd(Mn, K, seed=6).bfloat16(), rnd(Nn, K, seed=7, scale=0.2).bfloat16(), rnd(Nn, seed=8), rnd(Mn, Nn, seed=9)
+    on = torch.full((Mn + 1, Nn), 7.0, device=DEV)
+    ops.gemm(L.GEMM_NT, An, 0, K, Wn, 0, K, on, Nn, Mn, Nn, K, compute=L.BF16, bias=bn, residual=rn, ldr=Nn, algo=0 if algo == 0 else 433)
+    assert rel_l2(on[:Mn], An.float() @ Wn.float().t() + bn + rn) < 1e-4 and (on[Mn] == 7).all()
     if algo != 0:                                    # the same arithmetic in the same order as the LDS-staged epilogue of gemm2: the same bits
         base = torch.empty(M, N, device=DEV)
         ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, base, N, M, N, K, compute=L.BF16, bias=b, residual=res, ldr=N, row_scale=rs, rows_per_scale=rps, algo=2)
