@@ -791,13 +791,31 @@ def main():
         tot_sec = sum(a[3] for a in agg.values())
         tot_fl = sum(a[1] for a in agg.values())
         peak = PEAK_BF16_TFLOPS if args.compute in ("bf16", "fp16") else 157.3      # dense f16 MFMA rate == bf16 rate on gfx950
-        traffic = None
+        traffic, traffic_src = None, "profiles/pmc_traffic.json: no entry for this kernel"
         try:     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py), same command, same kernel
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if name in pmc["kernels"]:
-                traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import build_stamp
+            cur, st = build_stamp.current(), pmc.get("stamp")
+            key = "lib_f16_sha256" if args.compute == "fp16" else "lib_sha256"
+            ent = pmc["kernels"].get(name)
+            if st is None:
+                traffic_src = "profiles/pmc_traffic.json carries no build stamp (collected before round 5): traffic withheld"
+            elif st.get(key) != cur.get(key):
+                traffic_src = (f"profiles/pmc_traffic.json was collected on another build of the library (stamp {str(st.get(key))[:12]}, "
+                               f"running {str(cur.get(key))[:12]}): traffic withheld")
+            elif ent is None:
+                pass
+            elif ent.get("launches_per_step") is not None and int(round(ent["launches_per_step"])) != n // 2:
+                traffic_src = (f"profiles/pmc_traffic.json profiled {ent['launches_per_step']:g} launches of this kernel per step, this run "
+                               f"timed {n // 2}: another population, traffic withheld")
+            else:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH_SIZE doubled, "
+                               f"gfx950), {ent.get('launches_per_step', '?'):g} launches per step, library sha256 {str(st.get(key))[:16]}, "
+                               f"source commit {str(st.get('source_commit'))[:12]}{'+dirty' if st.get('source_dirty') else ''}")
+        except Exception as e:
+            traffic_src = f"profiles/pmc_traffic.json unreadable ({e!r})"
         # the binding roofline of this kernel: t_min = max(flops / P_mfma, algorithmic bytes / P_hbm)
         t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM_GBS * 1e9)
         hbm_bound = t_hbm > t_mfma
@@ -807,7 +825,7 @@ def main():
                 "frac": round(max(t_mfma, t_hbm) / sec, 4),
                 "mfma_tflops": round(fl / sec / 1e12, 2), "mfma_frac": round(t_mfma / sec, 4),
                 "algorithmic_gbps": round(by / sec / 1e9, 1), "hbm_frac": round(t_hbm / sec, 4),
-                "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed per round)",
+                "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": n // 2, "avg_launch_us": round(sec / max(n, 1) * 1e6, 2), "timing": timing, "graph_replay": replay,
                 "algorithmic_flop_per_launch": round(fl / max(n, 1)), "algorithmic_bytes_per_launch": round(by / max(n, 1)),
                 "epilogue_operand_bytes_per_launch": round(ext / max(n, 1)),     # GELU pre-activation out / in, residual in: on top of A + B + C

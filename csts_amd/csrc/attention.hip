@@ -17,14 +17,42 @@
 #include <utility>
 #include "common.h"
 
+// This source is compiled TWICE (round 5): part 0 (attention.hip itself, the library's default flags) holds every kernel and entry
+// point except the FAST dK/dV kernel; part 1 (attention_dkv.hip: `#define CSTS_ATTN_PART 1` + `#include "attention.hip"`, built with
+// -mllvm -amdgpu-mfma-vgpr-form -fno-slp-vectorize) holds only attn_dkv_kernel<96, false, false> and its launcher.  Why per kernel:
+// with the compiler's default AGPR form that kernel copied every S / dP accumulator out through v_accvgpr_read behind an s_nop
+// stall (192 copies per 96 MFMAs), with the VGPR form it does not (-9 ... -15 % per launch) -- while the one-pass decoder backward
+// and the hd-192 backward kernels measured 4-6 % SLOWER in the VGPR form, and the forward's softmax loses without SLP packing
+// (profiles/r5_attn_stream_ab.txt).
+#ifndef CSTS_ATTN_PART
+#define CSTS_ATTN_PART 0
+#endif
+#ifndef CSTS_DKV_DEPTH
+#define CSTS_DKV_DEPTH 4          // LDS operands requested this many MFMA slots ahead in the dK/dV stream
+#endif
+#ifndef CSTS_DKV_SWZ
+// FAST dK/dV kernel: 1 = 256-byte LDS rows with XOR-swizzled 16-byte chunks (conflict-free transposed reads), 0 = 208-byte padded
+// rows (transposed reads 2-way conflicted).  Measured alike per launch (profiles/r5_attn_stream_ab.txt: the kernel is not held by
+// its LDS reads at one wave per SIMD, and the swizzled image costs two more LDS-DMA instructions per wave and tile): padded rows
+// ship; the swizzled image is what an eight-wave form of this kernel would need (four waves already use the whole LDS port of
+// the conflicted transposed reads).
+#define CSTS_DKV_SWZ 0
+#endif
+
 // Diagnostics build (-DCSTS_ATTN_STAMPS, `make stamps`, tools/attn_stamps.py): thread 0 of workgroup (0,0,0) of the dK/dV
 // kernel records shader-clock stamps around the phases of every query tile.  No stamp code exists in the library build.
 #ifdef CSTS_ATTN_STAMPS
+#if CSTS_ATTN_PART == 1
 __device__ unsigned long long g_attn_stamps[4096];
+#else
+static __device__ unsigned long long g_attn_stamps[4096];     // never filled: the stamped kernel lives in part 1
+#endif
 #define AT_STAMP() do { if (stamp_on && nstamp < 4000) g_attn_stamps[nstamp++] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+#if CSTS_ATTN_PART == 1
 extern "C" int csts_debug_attn_stamps(unsigned long long* dst_host) {
   return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 4096);
 }
+#endif
 #define AT_STAMP_P() do { if (stamp_on && *nstamp_p < 4000) g_attn_stamps[(*nstamp_p)++] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define AT_STAMP_PARAMS , bool stamp_on = false, int* nstamp_p = nullptr
 #define AT_STAMP_ARGS , stamp_on, &nstamp
@@ -35,8 +63,7 @@ extern "C" int csts_debug_attn_stamps(unsigned long long* dst_host) {
 #define AT_STAMP_ARGS
 #endif
 
-namespace {
-
+namespace csts_attn {
 struct AttnP {
   const void* Q; const void* K; const void* V; void* O; float* LSE;
   const void* dO; float* delta; void* dQ; void* dK; void* dV; float* ws;
@@ -48,6 +75,12 @@ struct AttnP {
   float mask_inv_hw;
   int q_chunk, nsplit;
 };
+}  // namespace csts_attn
+// the FAST dK/dV kernel's launcher (part 1); false: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed
+bool csts_attn_dkv_fast_launch(const csts_attn::AttnP& p, dim3 grid, hipStream_t stream);
+
+namespace {
+using csts_attn::AttnP;
 
 __device__ __forceinline__ int rowoff(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -387,7 +420,15 @@ __device__ __forceinline__ void dma16(const char* base, unsigned lane_off, const
   const uint32_t l = (uint32_t)(uintptr_t)(attn_lptr_t)lds_dst;
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane_off), "s"(base) : "memory", "m0");
 }
-template <int HD, int ROWS, int LD, bool STATS = true, int LDY = LD, typename Body>
+// SWZ: 256-byte LDS rows (LD = 128) whose sixteen 16-byte chunks are XOR-swizzled by the row, chunk c of row r at position
+// c ^ swz16(r): conflict-free for BOTH access patterns of the backward kernels -- ds_read_b128 down a column of chunks (16 lanes =
+// 16 rows: 16 different positions) and ds_read_b64_tr_b16 (32 lanes = 4 rows x 64 bytes: the four rows land in different bank
+// quarters).  With the padded 208-byte rows the transposed reads were 2-way bank-conflicted (rows r and r + 1 overlap in 4 of 16
+// banks): 128 B/clk/CU, exactly what four waves ask for at one transposed operand per 32-cycle MFMA, so the dV / dK blocks ran at
+// ~70 cycles per MFMA (in-kernel stamps, profiles/r5_attn_stream_ab.txt).  LDS-DMA writes a wave's 64 chunks to consecutive
+// positions, so the swizzle is applied on the SOURCE side: the lane that fills position c' of row r fetches chunk c' ^ swz16(r).
+__device__ __forceinline__ constexpr int swz16(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+template <int HD, int ROWS, int LD, bool STATS = true, int LDY = LD, bool SPREAD = false, bool SWZ = false, typename Body>
 __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t xbase, int64_t xts, const void* Y,
                                               int64_t ybase, int64_t yts, int row_beg, int row_end, int tid, Body&& body,
                                               const float* S1 = nullptr, const float* S2 = nullptr AT_STAMP_PARAMS) {
@@ -395,39 +436,49 @@ __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t
   constexpr int MAXIX = (NIX + 3) / 4, MAXIY = (NIY + 3) / 4, TILE = ROWS * (LD + LDY);
   static_assert(LD % 8 == 0 && LDY % 8 == 0 && (ROWS * SPRX) % 64 == 0 && (ROWS * SPRY) % 64 == 0 && SPRX >= CPR && SPRY >= CPR &&
                     (ROWS == 64 || ROWS == 128), "LDS images must be whole wave instructions");
+  static_assert(!SWZ || (LD == 128 && LDY == 128), "the swizzled image has 256-byte rows");
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned xo[MAXIX], yo[MAXIY];               // byte offsets of this lane's slot in instruction w + 4 i of a tile (tile-invariant)
+  auto src_chunk = [](int row, int pos) {      // which 16-byte chunk of the row goes to position pos of its LDS row
+    if constexpr (SWZ) { const int c = pos ^ swz16(row); return c < CPR ? c : (c & 7); }   // positions >= CPR: padding, never read
+    else return min(pos, CPR - 1);
+  };
 #pragma unroll
   for (int i = 0; i < MAXIX; ++i) {
-    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPRX, c = min(slot - row * SPRX, CPR - 1);
+    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPRX, c = src_chunk(row, slot - row * SPRX);
     xo[i] = (unsigned)(row * (int)xts + c * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < MAXIY; ++i) {
-    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPRY, c = min(slot - row * SPRY, CPR - 1);
+    const int slot = (w + 4 * i) * 64 + lane, row = slot / SPRY, c = src_chunk(row, slot - row * SPRY);
     yo[i] = (unsigned)(row * (int)yts + c * 8) * 2u;
   }
   float* stats = reinterpret_cast<float*>(smem + 2 * TILE);      // [2 buffers][2][ROWS]
-  auto issue = [&](int row0, int buf) {        // scalar tile base + 32-bit lane offset: the saddr form of the instruction
-    const char* xs = uniform_ptr(reinterpret_cast<const bf16*>(X) + xbase + (int64_t)row0 * xts);
-    const char* ys = uniform_ptr(reinterpret_cast<const bf16*>(Y) + ybase + (int64_t)row0 * yts);
+  constexpr int WPS = ROWS / 64;
+  // instruction i of this wave's share of a tile: i < MAXIX: X image, < MAXIX + MAXIY: Y image, == MAXIX + MAXIY: statistics
+  // (scalar tile base + 32-bit lane offset: the saddr form of the instruction)
+  auto tile_x = [&](int row0) { return uniform_ptr(reinterpret_cast<const bf16*>(X) + xbase + (int64_t)row0 * xts); };
+  auto tile_y = [&](int row0) { return uniform_ptr(reinterpret_cast<const bf16*>(Y) + ybase + (int64_t)row0 * yts); };
+  auto issue_one = [&](auto ic, const char* xs, const char* ys, int row0, int buf) {
+    constexpr int i = decltype(ic)::value;
     char* dx = reinterpret_cast<char*>(smem + buf * TILE);
-    char* dy = dx + ROWS * LD * 2;
-#pragma unroll
-    for (int i = 0; i < MAXIX; ++i) {
+    if constexpr (i < MAXIX) {
       const int t = w + 4 * i;                 // wave-uniform
       if (t < NIX) dma16(xs, xo[i], dx + t * 1024);
+    } else if constexpr (i < MAXIX + MAXIY) {
+      const int t = w + 4 * (i - MAXIX);
+      if (t < NIY) dma16(ys, yo[i - MAXIX], dx + ROWS * LD * 2 + t * 1024);
+    } else {
+      // LSE and delta of the tile's rows, one dword per lane: 64 rows -> waves 0 / 1; 128 rows -> waves 0, 1 / 2, 3
+      if (STATS && w < 2 * WPS)
+        __builtin_amdgcn_global_load_lds((attn_gptr_t)((w < WPS ? S1 : S2) + row0 + (w % WPS) * 64 + lane),
+                                         (attn_lptr_t)(stats + buf * 2 * ROWS + (w / WPS) * ROWS + (w % WPS) * 64), 4, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < MAXIY; ++i) {
-      const int t = w + 4 * i;
-      if (t < NIY) dma16(ys, yo[i], dy + t * 1024);
-    }
-    // LSE and delta of the tile's rows, one dword per lane: 64 rows -> waves 0 / 1; 128 rows -> waves 0, 1 / 2, 3
-    constexpr int WPS = ROWS / 64;
-    if (STATS && w < 2 * WPS)
-      __builtin_amdgcn_global_load_lds((attn_gptr_t)((w < WPS ? S1 : S2) + row0 + (w % WPS) * 64 + lane),
-                                       (attn_lptr_t)(stats + buf * 2 * ROWS + (w / WPS) * ROWS + (w % WPS) * 64), 4, 0, 0);
+  };
+  auto issue = [&](int row0, int buf) {
+    const char* xs = tile_x(row0);
+    const char* ys = tile_y(row0);
+    static_for<MAXIX + MAXIY + 1>([&](auto ic) { issue_one(ic, xs, ys, row0, buf); });
   };
   issue(row_beg, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -435,14 +486,29 @@ __device__ __forceinline__ void tile_loop_dma(bf16* smem, const void* X, int64_t
   int it = 0;
   for (int row0 = row_beg; row0 < row_end; row0 += ROWS, ++it) {
     bf16* cur = smem + (it & 1) * TILE;
-    if (row0 + ROWS < row_end) issue(row0 + ROWS, (it + 1) & 1);   // that buffer was last read before the previous barrier
-    AT_STAMP_P();
-    if constexpr (STATS) body(cur, cur + ROWS * LD, row0, stats + (it & 1) * 2 * ROWS);
-    else body(cur, cur + ROWS * LD, row0);
+    const bool more = row0 + ROWS < row_end;   // wave-uniform.  (The other buffer was last read before the previous barrier.)
+    if constexpr (SPREAD) {
+      // the body issues the next tile's instructions itself, one per call of dma(integral_constant<i>), i < NDMA, between its MFMAs:
+      // issued in one burst in front of the body they were ~1000 cycles per tile in which the wave (alone on its SIMD) did nothing else
+      const char* xs = tile_x(more ? row0 + ROWS : row0);
+      const char* ys = tile_y(more ? row0 + ROWS : row0);
+      auto dma = [&](auto ic) { if (more) issue_one(ic, xs, ys, row0 + ROWS, (it + 1) & 1); };
+      AT_STAMP_P();
+      body(cur, cur + ROWS * LD, row0, stats + (it & 1) * 2 * ROWS, dma);
+    } else {
+      if (more) issue(row0 + ROWS, (it + 1) & 1);
+      AT_STAMP_P();
+      if constexpr (STATS) body(cur, cur + ROWS * LD, row0, stats + (it & 1) * 2 * ROWS);
+      else body(cur, cur + ROWS * LD, row0);
+    }
     AT_STAMP_P();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+}
+// number of dma(i) calls a SPREAD body owes per tile
+template <int ROWS, int LD, int LDY = LD> constexpr int tile_dma_count() {
+  return (ROWS * (LD / 8) / 64 + 3) / 4 + (ROWS * (LDY / 8) / 64 + 3) / 4 + 1;
 }
 
 // Row-per-lane operands (the 128 query rows of a workgroup, one per lane) are moved through LDS: the tile is loaded /
@@ -637,6 +703,7 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_ke
   if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
 }
 
+#if CSTS_ATTN_PART == 0     // (non-template kernels are emitted by every translation unit that sees them)
 // forward, FAST form (hd 96, bf16, no mask, every 64-key tile whole): K / V tiles by LDS-DMA (K rows padded to 104 elements,
 // V -- read transposed only -- unpadded) and the MFMA slot stream of the backward kernels: 12 slots S = Q K^T (two 32-key
 // units), the online softmax of the tile (it needs the maximum over both units, so it cannot ride on its own block), 12 slots
@@ -750,6 +817,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_fast_kernel(AttnP p) {
   if (qvalid && h == 0 && p.LSE) p.LSE[((int64_t)b * p.H + head) * p.Nq + qi] = m + __builtin_amdgcn_logf(lsum);  // log2 domain
 }
 
+#endif
 // ---------------------------------------------------------------------------------------------- dQ
 template <int HD, bool F32>
 __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_kernel(AttnP p) {
@@ -1018,6 +1086,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
   typedef typename El<F32>::T T;
   typedef Cfg<HD, F32> C;
   constexpr bool FAST = !F32 && HD == 96 && !SLOW;
+  constexpr bool SWZ = FAST && (CSTS_DKV_SWZ != 0);                  // swizzled 256-byte LDS rows (tile_loop_dma)
+  constexpr int LDF = SWZ ? 128 : C::LD_ROW;                         // LDS row stride of the staged Q / dO tiles
   constexpr int QBLK = FAST ? 128 : C::KVBLK, QT = QBLK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -1047,10 +1117,11 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
 #ifdef CSTS_ATTN_STAMPS
   const bool stamp_on = tid == 0 && BX == 0 && BY == 0 && BZ == 0;
   int nstamp = 1;
+  const unsigned long long rt0 = (unsigned long long)__builtin_amdgcn_s_memrealtime();
 #endif
   AT_STAMP();
 
-  auto tile_body = [&](const T* Qs, const T* dOs, int q0, const float* Ls) {
+  auto tile_body = [&](const T* Qs, const T* dOs, int q0, const float* Ls, auto&& dma) {
     const float* Ds = Ls + QBLK;
     AT_STAMP();                                // tile body begins
     // P = exp2(S * scale - LSE), dS = P * (dP - delta) for registers r0 .. r0 + n - 1 (n <= 4, inside one quad: the 4
@@ -1095,33 +1166,58 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       //    every slot keeps it that way (with the read next to its MFMA -- what the compiler schedules on its own -- every
       //    MFMA waited a whole LDS round trip and the matrix pipe was busy 18 % of the time);
       //  * blocks of 12 slots are ordered SC(0) SC(1) PV(0) SC(2) PV(1) ... SC(QT-1) PV(QT-2) PV(QT-1)  (SC(u): S and dP of
-      //    the 32-query unit u, PV(u): its dV and dK products) and the softmax backward of unit u is cut into 8 two-register
-      //    pieces that ride on the first 8 slots of the block after SC(u): its exponentials issue under MFMAs that do not
-      //    depend on them.  S / dP and their bf16 forms are double-buffered by unit parity.
-      constexpr int LD = C::LD_ROW, NS = HD / 16, ND = HD / 32, BLK = 2 * NS, DEPTH = 4, NBLK = 2 * QT, TOTAL = BLK * NBLK;
+      //    the 32-query unit u, PV(u): its dV and dK products).  S / dP and their bf16 forms are double-buffered by unit parity;
+      //  * round 5: the softmax backward of unit u is 16 HALF-pieces of two registers -- (a) P = exp2(S c - LSE), (b) dS = P (dP -
+      //    delta) and the two bf16 packs -- spread evenly over every slot between the end of SC(u) and the start of PV(u): the
+      //    block after SC(u) for the first and the last unit, two blocks (PV(u-1), SC(u+1)) for the others.  A half-piece is
+      //    ~25 cycles of vector issue and hides under one 32-cycle MFMA; the 8 two-register pieces on 8 of 12 slots of round 3
+      //    were ~60 cycles each, and their LSE / delta came from LDS in the slot that consumed them (one exposed LDS round
+      //    trip per piece: the in-loop rate was 70 cycles per MFMA, not the 35 the round-3 notes claim -- their count of
+      //    MFMAs per tile was off by two).  LSE / delta of a unit are now read into registers under its own SC block;
+      //  * the next tile's LDS-DMA instructions are issued one per slot under SC(0), which carries no softmax.
+      constexpr int LD = LDF, NS = HD / 16, ND = HD / 32, BLK = 2 * NS, DEPTH = CSTS_DKV_DEPTH, NBLK = 2 * QT, TOTAL = BLK * NBLK;
       static_assert(BLK == 4 * ND, "S/dP and dV/dK blocks have the same number of slots");
+      static_assert(QT >= 2, "the block order needs two units");
       typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
       const int g1 = (lane >> 4) & 1, qq = (lane & 15) >> 2, pp = lane & 3;
-      const bf16* rowQ = Qs + (lane & 31) * LD + 8 * h;
-      const bf16* rowD = dOs + (lane & 31) * LD + 8 * h;
-      const bf16* trQ = Qs + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
-      const bf16* trD = dOs + (4 * h + qq) * LD + 16 * g1 + 4 * pp;
+      constexpr int DOFF = QBLK * LD;          // the dO image follows the Q image
+      // element offsets of this lane's operands inside a 32-query unit of the Q image (the dO image: + DOFF; unit u: + u * 32 * LD;
+      // second half of a transposed step: + 16 * LD).  Padded rows: one base + compile-time chunk offsets.  Swizzled rows: the
+      // chunk position depends on the row, so every (chunk | d, read) has its own offset (12 registers instead of 4).
+      int rowo[NS], tro[ND][2];
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        rowo[k] = (lane & 31) * LD + (SWZ ? (((2 * k + h) ^ swz16(lane & 15)) * 8) : (16 * k + 8 * h));
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          const int row = 4 * h + qq + 8 * rd;
+          tro[d][rd] = row * LD + (SWZ ? ((((4 * d + 2 * g1 + (pp >> 1)) ^ swz16(row)) * 8) + 4 * (pp & 1)) : (32 * d + 16 * g1 + 4 * pp));
+        }
       bf16x8 ring[DEPTH + 1];
       // block bi -> (is it a dV/dK block, which unit)
       auto blk_pv = [](int bi) constexpr { return bi == NBLK - 1 || (bi >= 2 && (bi & 1) == 0); };
       auto blk_unit = [](int bi) constexpr { return bi == 0 ? 0 : bi == NBLK - 1 ? QT - 1 : (bi & 1) ? (bi + 1) / 2 : bi / 2 - 1; };
+      // slot of half-piece j (0 .. 15) of unit u: its window starts one slot after SC(u) ends (the first read of S does not wait
+      // for the accumulator of the MFMA issued just before it) and ends where PV(u) starts
+      auto hp_slot = [](int u, int j) constexpr {
+        const int w0 = (u == 0 ? BLK : u == QT - 1 ? BLK * (NBLK - 2) : BLK * 2 * u) + 1;
+        const int n = ((u == 0 || u == QT - 1) ? BLK : 2 * BLK) - 1;
+        return w0 + j * n / 16;
+      };
       auto request = [&](auto gc) {
         constexpr int g = decltype(gc)::value, bi = g / BLK, k = g % BLK;
         constexpr bool is_pv = blk_pv(bi);
         constexpr int u = blk_unit(bi);
         bf16x8& dst = ring[g % (DEPTH + 1)];
         if constexpr (!is_pv) {
-          dst = *reinterpret_cast<const bf16x8*>((k < NS ? rowQ : rowD) + u * 32 * LD + 16 * (k % NS));
+          dst = *reinterpret_cast<const bf16x8*>(Qs + rowo[k % NS] + (k < NS ? 0 : DOFF) + u * 32 * LD);
         } else {
           constexpr int idx = k % (2 * ND), s2 = idx / ND, d = idx % ND;
-          const bf16* Yb = (k < 2 * ND ? trD : trQ) + (u * 32 + 16 * s2) * LD + 32 * d;
-          const bf16x4 b0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb)));
-          const bf16x4 b1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + 8 * LD)));
+          const bf16* Yb = Qs + (k < 2 * ND ? DOFF : 0) + (u * 32 + 16 * s2) * LD;
+          const bf16x4 b0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + tro[d][0])));
+          const bf16x4 b1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Yb + tro[d][1])));
           dst[0] = b0[0]; dst[1] = b0[1]; dst[2] = b0[2]; dst[3] = b0[3];
           dst[4] = b1[0]; dst[5] = b1[1]; dst[6] = b1[2]; dst[7] = b1[3];
         }
@@ -1129,48 +1225,105 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnP p) {
       static_for<DEPTH>([&](auto gc) { request(gc); });
       f32x16 S[2], dP[2];
       bf16x8 bpS[2][2], bpD[2][2];
+      float4 Lq[2][4], Dq[2][4];                // LSE / delta of the unit's 4 register quads (4 consecutive queries each)
+      auto comp = [](const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; };
+      auto half_piece = [&](auto uc, auto jc) {
+        constexpr int u = decltype(uc)::value, j = decltype(jc)::value, sp = u & 1, r0 = 2 * (j / 2), quad = r0 >> 2;
+        if constexpr ((j & 1) == 0) {
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) {
+            float e = __builtin_amdgcn_exp2f(__builtin_fmaf(S[sp][r], p.scale_log2, -comp(Lq[sp][quad], r & 3)));
+            if constexpr (SLOW) {
+              // clamped (invalid) key lanes are never stored, so they need no masking
+              const int q = q0 + u * 32 + 8 * quad + 4 * h + (r & 3);
+              const bool dead = (q >= qend) | ((p.mask_mode != 0) & (frame_of(p, q) != fk));
+              e = dead ? 0.f : e;
+            }
+            S[sp][r] = e;
+          }
+        } else {
+#pragma unroll
+          for (int r = r0; r < r0 + 2; ++r) dP[sp][r] = S[sp][r] * (dP[sp][r] - comp(Dq[sp][quad], r & 3));
+          constexpr int s2 = r0 / 8, e0 = r0 % 8;
+          bpS[sp][s2][e0] = (bf16)S[sp][r0]; bpS[sp][s2][e0 + 1] = (bf16)S[sp][r0 + 1];
+          bpD[sp][s2][e0] = (bf16)dP[sp][r0]; bpD[sp][s2][e0 + 1] = (bf16)dP[sp][r0 + 1];
+        }
+      };
+      constexpr int NDMA = tile_dma_count<QBLK, LD>();
       static_for<TOTAL>([&](auto gc) {
         constexpr int g = decltype(gc)::value, bi = g / BLK, k = g % BLK;
         constexpr bool is_pv = blk_pv(bi);
         constexpr int u = blk_unit(bi), par = u & 1;
+        if constexpr (k == 0) { AT_STAMP(); }   // diagnostics build only: one stamp per 12-slot block
         if constexpr (!is_pv && k == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { S[par][r] = 0.f; dP[par][r] = 0.f; }
         }
+        if constexpr (!is_pv && k < 8) {        // this unit's statistics: one 16-byte broadcast read per slot
+          const int qo = u * 32 + 8 * (k & 3) + 4 * h;
+          if constexpr (k < 4) Lq[par][k] = *reinterpret_cast<const float4*>(Ls + qo);
+          else Dq[par][k - 4] = *reinterpret_cast<const float4*>(Ds + qo);
+        }
+#ifndef CSTS_DKV_DIAG_NOREAD                // (timing diagnostics only, wrong results: the stream without its LDS operand reads)
         if constexpr (g + DEPTH < TOTAL) request(std::integral_constant<int, g + DEPTH>{});
+#endif
         const bf16x8 a = ring[g % (DEPTH + 1)];
         if constexpr (!is_pv) {
           if constexpr (k < NS) S[par] = CSTS_MFMA16(a, kf.b[k], S[par], 0, 0, 0);
           else dP[par] = CSTS_MFMA16(a, vf.b[k - NS], dP[par], 0, 0, 0);
         } else {
           constexpr int idx = k % (2 * ND), s2 = idx / ND, d = idx % ND;
+#if defined(CSTS_DKV_DIAG_BFRAG) || defined(CSTS_DKV_DIAG_BZERO)
+          asm volatile("" ::"v"(bpS[par][s2]), "v"(bpD[par][s2]));     // keeps the softmax backward alive without consuming it
+#endif
+#ifdef CSTS_DKV_DIAG_BFRAG                  // (timing diagnostics only: real data in B without any dependence on the softmax)
+          if constexpr (k < 2 * ND) dV[d] = CSTS_MFMA16(a, kf.b[s2 + 2 * par], dV[d], 0, 0, 0);
+          else dK[d] = CSTS_MFMA16(a, vf.b[s2 + 2 * par], dK[d], 0, 0, 0);
+#elif defined(CSTS_DKV_DIAG_BZERO)          // (timing diagnostics only: zeros in B)
+          bf16x8 zz;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) zz[e] = (bf16)0.f;
+          asm volatile("" : "+v"(zz));
+          if constexpr (k < 2 * ND) dV[d] = CSTS_MFMA16(a, zz, dV[d], 0, 0, 0);
+          else dK[d] = CSTS_MFMA16(a, zz, dK[d], 0, 0, 0);
+#else
           if constexpr (k < 2 * ND) dV[d] = CSTS_MFMA16(a, bpS[par][s2], dV[d], 0, 0, 0);
           else dK[d] = CSTS_MFMA16(a, bpD[par][s2], dK[d], 0, 0, 0);
+#endif
         }
-        // the softmax backward of the unit whose S / dP block came just before this block
-        if constexpr (bi >= 1 && k < 8) {
-          constexpr int su = bi == 1 ? 0 : bi / 2, sp = su & 1;     // SC(su) is block 2 su - 1 (block 0 for su = 0)
-          if constexpr ((bi == 1) || ((bi & 1) == 0 && bi / 2 <= QT - 1)) {
-            softmax_bwd(S[sp], dP[sp], su, 2 * k, 2);
-            constexpr int s2 = (2 * k) / 8, e0 = (2 * k) % 8;
-            bpS[sp][s2][e0] = (bf16)S[sp][2 * k]; bpS[sp][s2][e0 + 1] = (bf16)S[sp][2 * k + 1];
-            bpD[sp][s2][e0] = (bf16)dP[sp][2 * k]; bpD[sp][s2][e0 + 1] = (bf16)dP[sp][2 * k + 1];
-          }
-        }
+#ifdef CSTS_DKV_DIAG_NOSM
+        if constexpr (!is_pv && k == BLK - 1) asm volatile("" ::"v"(S[par]), "v"(dP[par]));     // S / dP stay alive (their MFMAs are not dead code)
+#endif
+#ifndef CSTS_DKV_DIAG_NOSM                  // (timing diagnostics only, wrong results: the stream without its softmax backward)
+        // the half-pieces of the softmax backward that live on this slot
+        static_for<QT * 16>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, su = i / 16, j = i % 16;
+          if constexpr (hp_slot(su, j) == g) half_piece(std::integral_constant<int, su>{}, std::integral_constant<int, j>{});
+        });
+#endif
+#ifndef CSTS_DKV_DIAG_NODMA                 // (timing diagnostics only: the next tile is not fetched)
+        // the next tile's LDS-DMA instructions: under SC(0) (and the first slots of SC(1) when there are more than 12)
+        if constexpr (g < NDMA) dma(std::integral_constant<int, g>{});
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     }
     AT_STAMP();                                // tile body done
   };
   if constexpr (FAST)
-    tile_loop_dma<HD, QBLK, C::LD_ROW>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid, tile_body, Lrow,
-                                       Drow AT_STAMP_ARGS);
+    tile_loop_dma<HD, QBLK, LDF, true, LDF, true, SWZ>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid, tile_body,
+                                                       Lrow, Drow AT_STAMP_ARGS);
   else
     tile_loop<HD, QBLK, C::LD_ROW, C::LD_ROW, F32, true>(smem, p.Q, qbase, p.q_ts, p.dO, dobase, p.do_ts, qbeg, qend, tid,
-                                                         tile_body, Lrow, Drow AT_STAMP_ARGS);
+                                                         [&](const T* Qs, const T* dOs, int q0, const float* Ls) {
+                                                           tile_body(Qs, dOs, q0, Ls, [](auto) {});
+                                                         }, Lrow, Drow AT_STAMP_ARGS);
   AT_STAMP();
 #ifdef CSTS_ATTN_STAMPS
-  if (stamp_on) g_attn_stamps[0] = nstamp;
+  if (stamp_on) {
+    g_attn_stamps[0] = nstamp;
+    g_attn_stamps[4095] = (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt0;     // 100 MHz ticks over the kernel body
+  }
 #endif
   if (!kvalid) return;
   if (p.nsplit == 1) {
@@ -1344,6 +1497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(AttnP p) {
   }
 }
 
+#if CSTS_ATTN_PART == 0
 // second pass: dK/dV[b, k, head, :] = sum_split ws[...]; a thread owns 8 consecutive channels of one key row (two 16-byte
 // loads per split, one 16-byte bf16 store; the element-per-thread form spent its time in 64-bit index divisions)
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnP p, int HD) {
@@ -1387,6 +1541,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnP p, int HD, float*
   }
 }
 
+#endif
+#if CSTS_ATTN_PART == 0
 template <int HD, bool F32> size_t smem_fwd() {
   typedef Cfg<HD, F32> C;
   return (size_t)C::KVBLK * (C::LD_ROW + C::LD_TR) * (F32 ? 4 : 2 * 2);   // bf16: double-buffered
@@ -1500,10 +1656,7 @@ static bool attn_launch(int which, const AttnP& p, dim3 grid, hipStream_t stream
       if (slow) hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, true>), grid, dim3(256), sm, stream, p);
       else hipLaunchKernelGGL((attn_dkv_kernel<HD, F32, F32 || HD == 96>), grid, dim3(256), sm, stream, p);
     } else if constexpr (!F32 && HD == 96) {
-      // 128-query tiles, double-buffered, + statistics: 108 KB of dynamic LDS (one workgroup per CU either way)
-      constexpr size_t smf = (size_t)2 * 128 * 2 * Cfg<96, false>::LD_ROW * 2 + 2 * 2 * 128 * sizeof(float);
-      if (!csts_dyn_lds_optin(reinterpret_cast<const void*>(&attn_dkv_kernel<96, false, false>), (int)smf)) return false;
-      hipLaunchKernelGGL((attn_dkv_kernel<96, false, false>), grid, dim3(256), smf, stream, p);
+      if (!csts_attn_dkv_fast_launch(p, grid, stream)) return false;      // part 1 of this source (see the top of the file)
     }
   }
   return true;
@@ -1591,3 +1744,13 @@ extern "C" int csts_attn_probs(const csts_attn_args* a, float* probs, hipStream_
   CSTS_LAUNCH_CHECK();
   return 0;
 }
+#else   // CSTS_ATTN_PART == 1: the FAST dK/dV kernel alone
+}  // namespace
+bool csts_attn_dkv_fast_launch(const csts_attn::AttnP& p, dim3 grid, hipStream_t stream) {
+  // 128-query tiles, double-buffered, + statistics: 108 KB of dynamic LDS (one workgroup per CU either way)
+  constexpr size_t smf = (size_t)2 * 128 * 2 * (CSTS_DKV_SWZ ? 128 : Cfg<96, false>::LD_ROW) * 2 + 2 * 2 * 128 * sizeof(float);
+  if (!csts_dyn_lds_optin(reinterpret_cast<const void*>(&attn_dkv_kernel<96, false, false>), (int)smf)) return false;
+  hipLaunchKernelGGL((attn_dkv_kernel<96, false, false>), grid, dim3(256), smf, stream, p);
+  return true;
+}
+#endif

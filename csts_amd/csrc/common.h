@@ -117,20 +117,23 @@ void csts_set_error(const std::string& s);
     if (e__ != hipSuccess) CSTS_FAIL(std::string("launch: ") + hipGetErrorString(e__)); \
   } while (0)
 
-// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute is per (function, device): done once for each pair a
-// process launches on, and a failure is reported to the caller instead of surfacing as an opaque launch error.
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute is per (function, device): set once for each pair a
+// process launches on and RAISED when a later launch needs more than the size opted in before (a kernel whose dynamic LDS
+// depends on an argument: opt_adamw_factored_kernel); a failure is reported to the caller instead of surfacing as an opaque
+// launch error.
+#include <map>
 #include <mutex>
-#include <set>
 #include <utility>
 static inline bool csts_dyn_lds_optin(const void* fn, int bytes) {
   static std::mutex mu;
-  static std::set<std::pair<const void*, int>> done;
+  static std::map<std::pair<const void*, int>, int> done;     // (function, device) -> bytes opted in
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   std::lock_guard<std::mutex> lock(mu);
-  if (done.count({fn, dev})) return true;
+  auto it = done.find({fn, dev});
+  if (it != done.end() && it->second >= bytes) return true;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
-  done.insert({fn, dev});
+  done[{fn, dev}] = bytes;
   return true;
 }
 

@@ -905,6 +905,42 @@ extern "C" int csts_rows_scatter_add(const csts_kv_rows_geom* g, const void* src
   CSTS_LAUNCH_CHECK();
   return 0;
 }
+namespace {
+struct TokenSegs { csts_token_segment s[4]; int64_t chunks_end[4]; };     // chunks_end[i]: 16-byte chunks of segments 0 .. i
+__global__ __launch_bounds__(256) void copy_token_segments_kernel(TokenSegs ts, int nseg, int64_t total, int row16, int elsz) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int k = 0;
+    while (k + 1 < nseg && i >= ts.chunks_end[k]) ++k;               // (wave-uniform except at a segment seam)
+    const int64_t j = i - (k ? ts.chunks_end[k - 1] : 0);
+    const int64_t per_b = (int64_t)ts.s[k].n * row16;                // chunks of this segment per batch element
+    const int64_t b = j / per_b, r = j - b * per_b;
+    const char* sp = reinterpret_cast<const char*>(ts.s[k].src) + (b * ts.s[k].src_bs + ts.s[k].src_off) * elsz + r * 16;
+    char* dp = reinterpret_cast<char*>(ts.s[k].dst) + (b * ts.s[k].dst_bs + ts.s[k].dst_off) * elsz + r * 16;
+    *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+  }
+}
+}  // namespace
+extern "C" int csts_copy_token_segments(const csts_token_segment* segs, int nseg, int B, int C, int dt, hipStream_t stream) {
+  CSTS_REQUIRE(segs && nseg >= 1 && nseg <= 4 && B > 0 && C > 0 && (dt == CSTS_F32 || dt == CSTS_BF16), "bad args");
+  const int elsz = dt == CSTS_F32 ? 4 : 2;
+  CSTS_REQUIRE(((int64_t)C * elsz) % 16 == 0, "rows must be whole 16-byte chunks");
+  TokenSegs ts;
+  int64_t total = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const csts_token_segment& s = segs[i];
+    CSTS_REQUIRE(s.src && s.dst && s.n >= 0 && aligned16(s.src) && aligned16(s.dst), "bad segment");
+    CSTS_REQUIRE((s.src_bs * elsz) % 16 == 0 && (s.dst_bs * elsz) % 16 == 0 && (s.src_off * elsz) % 16 == 0 && (s.dst_off * elsz) % 16 == 0,
+                 "segment strides / offsets must keep 16-byte alignment");
+    ts.s[i] = s;
+    total += (int64_t)B * s.n * ((int64_t)C * elsz / 16);
+    ts.chunks_end[i] = total;
+  }
+  for (int i = nseg; i < 4; ++i) { ts.s[i] = ts.s[0]; ts.chunks_end[i] = total; }
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(copy_token_segments_kernel, dim3(grid_for(total)), dim3(256), 0, stream, ts, nseg, total, (int)((int64_t)C * elsz / 16), elsz);
+  CSTS_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
                                int64_t M, int64_t N, hipStream_t stream) {
   CSTS_REQUIRE(x && row_scale && out && rows_per_scale > 0 && M > 0 && N > 0, "bad args");

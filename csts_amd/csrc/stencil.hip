@@ -723,8 +723,12 @@ struct WgItem {
   int block_begin, nblocks;
 };
 constexpr int WG_GROUP_THREADS = 512;
+// Register budget (round 5): two 512-thread workgroups per CU = four waves per SIMD = 128 registers.  The bf16 build landed on exactly
+// 128 by itself, the IEEE-half build on 130 -- one allocation granule more, ONE workgroup per CU, and the launch took 1.09 ms instead of
+// 0.65: that launch alone was the whole "fp16 mode is 4 % slower than bf16" of round 4 (per-entry diff of the two bench lines on one
+// box, profiles/r5_fp16_vs_bf16.txt).  (The second __launch_bounds__ argument is waves per SIMD.)
 template <bool F32>
-__global__ __launch_bounds__(WG_GROUP_THREADS) void dwconv_wgrad_grouped_kernel(const WgItem* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(WG_GROUP_THREADS, (F32 ? 2 : 4)) void dwconv_wgrad_grouped_kernel(const WgItem* __restrict__ items, int nitems) {
   __shared__ __attribute__((aligned(16))) float red[192 * 27];
   int it = 0;
   while (it + 1 < nitems && (int)blockIdx.x >= items[it + 1].block_begin) ++it;

@@ -42,7 +42,7 @@ def half_dtype():
     return torch.float16 if HALF == "fp16" else torch.bfloat16
 
 
-ABI_VERSION = 5   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
+ABI_VERSION = 6   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
@@ -113,6 +113,10 @@ class Im2colGeom(C.Structure):
     _fields_ = [("B", C.c_int), ("Cin", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("kernel", C.c_int * 3), ("stride", C.c_int * 3), ("padding", C.c_int * 3),
                 ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("Kpad", C.c_int)]
+
+
+class TokenSegment(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("src_bs", i64), ("dst_bs", i64), ("src_off", i64), ("dst_off", i64), ("n", C.c_int), ("pad_", C.c_int)]
 
 
 class KvRowsGeom(C.Structure):
@@ -199,6 +203,7 @@ SYMBOLS = {
     "csts_colsum": (_I, [vp, _I, vp, vp, i64, i64, i64, vp, sz, vp]),
     "csts_axpby": (_I, [vp, _I, vp, _I, vp, _I, i64, _F, _F, vp]),
     "csts_rows_gather": (_I, [C.POINTER(KvRowsGeom), vp, _I, vp, vp]),
+    "csts_copy_token_segments": (_I, [C.POINTER(TokenSegment), _I, _I, _I, _I, vp]),
     "csts_rows_scatter_add": (_I, [C.POINTER(KvRowsGeom), vp, _I, vp, _I, vp]),
     "csts_scale_rows": (_I, [vp, _I, vp, i64, vp, _I, i64, i64, vp]),
     "csts_add2": (_I, [vp, _I, vp, _I, vp, vp, i64, vp]),

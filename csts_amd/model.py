@@ -590,7 +590,7 @@ class CSTS(nn.Module):
                                     w16=c16(self.vision_pool))
             y_tmp = ops.fusion_conv(yt, self.audio_pool2.weight, self.audio_pool2.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
                                     w16=c16(self.audio_pool2))
-            return self.temporal_fusion(torch.cat([x_tmp, y_tmp], dim=1), (2, 2, 2), want_attn=return_temporal_attn)
+            return self.temporal_fusion(ops.cat_tokens(x_tmp, y_tmp), (2, 2, 2), want_attn=return_temporal_attn)
 
         # The temporal fusion (16 tokens per clip: every kernel of it is one latency-bound round trip) does not depend on the spatial
         # one unless SPATIAL_AUDIO_ATTN re-weights its input (:438-440): it runs on the side stream beside the spatial fusion, and
@@ -605,10 +605,10 @@ class CSTS(nn.Module):
                 av_t, _, t_extra = temporal_branch(xt)
         y_sp = ops.fusion_conv(yt, self.audio_pool.weight, self.audio_pool.bias, thw_a[0], HWa, rt.act_dt, rt.compute,
                                w16=c16(self.audio_pool))
-        av_sp = torch.cat([xt, y_sp], dim=1)
+        av_sp = ops.cat_tokens(xt, y_sp)
         av_sp, _, sp_extra = self.spatial_fusion(av_sp, thw, want_attn=return_spatial_attn,
                                                  spatial_audio_attn=self.spatial_audio_attn)
-        x_spatial = av_sp[:, :Nv, :]
+        x_spatial, _ = ops.split_tokens(av_sp, Nv)        # (y_spatial, the audio half, is unused in the reference too: :432)
         # ---- temporal fusion (:435-451)
         if side is not None:
             main.wait_stream(side)
@@ -621,7 +621,7 @@ class CSTS(nn.Module):
                 x_t = ops.row_weight(xt, sp_extra[1])
             av_t, _, t_extra = temporal_branch(x_t)
         # ---- re-weight (:454-461)
-        x_w, y_w = av_t[:, :Tn, :], av_t[:, Tn:, :]
+        x_w, y_w = ops.split_tokens(av_t, Tn)
         x_rw = ops.reweight(x_spatial, x_w, Tn, HW)
         y_rw = ops.reweight(yt, y_w, thw_a[0], HWa)
         # ---- embeddings (:493-497) early, on the side stream beside the decoder (their EgoNCE backward runs there too)

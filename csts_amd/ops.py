@@ -1710,7 +1710,7 @@ def patch_embed(x, W, b, pos_s, pos_t, kernel, stride, padding, act_dt, compute)
 # [A_0; ..; A_W-1]: the ranks exchange the FACTORS (all-gather of 32 x 768 fp32 + 32 x 49152 16-bit rows: 3.2 MB per conv) and each
 # forms the product itself, instead of all-reducing the 151 MB.  While a sink is set, FusionConvFn.backward hands its factors over
 # and computes no dW (the parameter's gradient is written later by the step that owns the sink).
-_factor_sink = None          # None, or {"params": set of weight data_ptrs, "items": [(W, dy, A, compute)]}
+_factor_sink = None          # None, or {"params": set of weight data_ptrs, "items": [(W, dy, A, compute)], optional "accept": f(W, rows)}
 
 
 def set_factor_sink(sink=None):
@@ -1750,7 +1750,8 @@ class FusionConvFn(Function):
         dy = dy.contiguous()
         Wv = Wop.reshape(Cout, K)
         sink = _factor_sink
-        if sink is not None and W.data_ptr() in sink["params"] and ctx.needs_input_grad[1]:
+        if (sink is not None and W.data_ptr() in sink["params"] and ctx.needs_input_grad[1]
+                and ("accept" not in sink or sink["accept"](W, BT))):
             sink["items"].append((W, dy, A, compute))      # factors only: the owner of the sink forms dW after the exchange
             dW = None
         else:
@@ -1869,6 +1870,87 @@ class TapFn(Function):
         if out16 is not None:
             _attach16(out, out16, cs)
         return out, None
+
+
+# ----------------------------------------------------------------------------------------- token-axis cat / split
+# torch.cat(dim=1) and x[:, :n] / x[:, n:] of (B, N, C) tensors as ONE library launch per direction (csts_copy_token_segments).  Through
+# torch the fusion head's joins and cuts were ~30 cat / slice-copy / zero-fill / gradient-add nodes per captured step (0.15 ms of
+# 5 us kernels).  CSTS_TOKEN_GLUE=0: the torch ops again (same values: pure copies).
+TOKEN_GLUE = os.environ.get("CSTS_TOKEN_GLUE", "1") != "0"
+
+
+def _copy_segments(pairs, B, Cc, dt):
+    """pairs: [(src tensor, src batch stride, src element offset, dst tensor, dst batch stride, dst element offset, rows)]"""
+    arr = (L.TokenSegment * len(pairs))()
+    for i, (src, sbs, soff, dst, dbs, doff, n) in enumerate(pairs):
+        arr[i].src, arr[i].dst = src.data_ptr(), dst.data_ptr()
+        arr[i].src_bs, arr[i].dst_bs, arr[i].src_off, arr[i].dst_off, arr[i].n = sbs, dbs, soff, doff, n
+    L.check(_lib().csts_copy_token_segments(arr, len(pairs), B, Cc, dt, _stream()), "csts_copy_token_segments")
+
+
+class CatTokensFn(Function):
+    """torch.cat([a, b], dim=1) of (B, Na, C) and (B, Nb, C)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        B, Na, Cc = a.shape
+        Nb = b.shape[1]
+        out = torch.empty(B, Na + Nb, Cc, dtype=a.dtype, device=a.device)
+        _copy_segments([(a, Na * Cc, 0, out, (Na + Nb) * Cc, 0, Na), (b, Nb * Cc, 0, out, (Na + Nb) * Cc, Na * Cc, Nb)], B, Cc, _dt(a))
+        ctx.meta = (B, Na, Nb, Cc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Na, Nb, Cc = ctx.meta
+        dout = dout.contiguous()
+        da = torch.empty(B, Na, Cc, dtype=dout.dtype, device=dout.device)
+        db = torch.empty(B, Nb, Cc, dtype=dout.dtype, device=dout.device)
+        _copy_segments([(dout, (Na + Nb) * Cc, 0, da, Na * Cc, 0, Na), (dout, (Na + Nb) * Cc, Na * Cc, db, Nb * Cc, 0, Nb)], B, Cc, _dt(dout))
+        return da, db
+
+
+class SplitTokensFn(Function):
+    """(x[:, :n], x[:, n:]) of a (B, N, C) tensor as two contiguous tensors."""
+
+    @staticmethod
+    def forward(ctx, x, n: int):
+        _need_gpu(x)
+        x = x.contiguous()
+        B, N, Cc = x.shape
+        a = torch.empty(B, n, Cc, dtype=x.dtype, device=x.device)
+        b = torch.empty(B, N - n, Cc, dtype=x.dtype, device=x.device)
+        _copy_segments([(x, N * Cc, 0, a, n * Cc, 0, n), (x, N * Cc, n * Cc, b, (N - n) * Cc, 0, N - n)], B, Cc, _dt(x))
+        ctx.meta = (B, N, n, Cc)
+        return a, b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        B, N, n, Cc = ctx.meta
+        # a part nobody used has no gradient (None): zeros, like the slice's backward
+        ref = da if da is not None else db
+        if da is None:
+            da = torch.zeros(B, n, Cc, dtype=ref.dtype, device=ref.device)
+        if db is None:
+            db = torch.zeros(B, N - n, Cc, dtype=ref.dtype, device=ref.device)
+        da, db = da.contiguous(), db.contiguous()
+        dx = torch.empty(B, N, Cc, dtype=da.dtype, device=da.device)
+        _copy_segments([(da, n * Cc, 0, dx, N * Cc, 0, n), (db, (N - n) * Cc, 0, dx, N * Cc, n * Cc, N - n)], B, Cc, _dt(da))
+        return dx, None
+
+
+def cat_tokens(a, b):
+    if not TOKEN_GLUE or a.dtype != b.dtype or (a.shape[2] * a.element_size()) % 16:
+        return torch.cat([a, b], dim=1)
+    return CatTokensFn.apply(a, b)
+
+
+def split_tokens(x, n: int):
+    if not TOKEN_GLUE or (x.shape[2] * x.element_size()) % 16:
+        return x[:, :n, :], x[:, n:, :]
+    return SplitTokensFn.apply(x, n)
 
 
 def tap(x, compute):

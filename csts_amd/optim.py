@@ -135,6 +135,7 @@ class FusedAdamW:
         if len(fac) > 8:
             raise L.CstsError("at most 8 factored parameters")
         self._factored = fac
+        self.last_factored_params = [self.params[i] for i, _, _ in fac]     # introspection: which weights the last step updated from factors
 
     @staticmethod
     def factored_ok(p, T):

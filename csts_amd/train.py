@@ -80,6 +80,13 @@ def construct_optimizer(model, cfg, capturable: bool = False, device_fused: bool
             core.w16_external = True
         return FusedAdamW(groups, lr=cfg.SOLVER.BASE_LR, eps=1e-8, max_grad_norm=float(cfg.SOLVER.CLIP_GRAD_L2NORM or 0.0),
                           shadows=shadows, loss_scaling=bool(getattr(getattr(core, "rt", None), "loss_scaling", False)))
+    if bool(getattr(getattr(core, "rt", None), "loss_scaling", False)):
+        # fp16 compute mode: the GradScaler semantics (unscale, non-finite check, skipped step, back-off / growth) live inside
+        # FusedAdamW's kernels.  A stock torch optimizer would train on unscaled fp16 gradients that underflow silently and the
+        # checkpoint would carry no scaler_state: refuse instead.
+        raise RuntimeError("CSTS_AMD.COMPUTE fp16 (TRAIN.MIXED_PRECISION) needs the device-fused optimizer: it carries the dynamic loss "
+                           "scaling.  Unset SOLVER.CLIP_GRAD_VAL (use CLIP_GRAD_L2NORM), keep the model on the GPU and "
+                           "device_fused=True, or train in CSTS_AMD.COMPUTE bf16 / fp32.")
     kw = {}
     if fused and capturable:      # lr lives in a device tensor so that a captured step can follow the schedule
         kw = {"capturable": True}
@@ -151,7 +158,9 @@ def backward_with_factors(cfg, model, loss, optimizer):
             optimizer.set_factored(None)
         backward_scaled(loss, optimizer)
         return
-    sink = {"params": {p.data_ptr() for p in fac}, "items": []}
+    # "accept": FusionConvFn.backward asks BEFORE it drops dW -- a geometry the factored update does not take (more than
+    # FusedAdamW.FACTORED_MAX_T token rows: large per-GPU batches) runs the ordinary TN GEMM and lands in p.grad as usual
+    sink = {"params": {p.data_ptr() for p in fac}, "items": [], "accept": lambda W, bt: optimizer.factored_ok(W, bt)}
     ops.set_factor_sink(sink)
     try:
         backward_scaled(loss, optimizer)
@@ -160,8 +169,6 @@ def backward_with_factors(cfg, model, loss, optimizer):
     items = []
     for W, dy, A, _ in sink["items"]:
         bt = dy.numel() // W.shape[0]
-        if not optimizer.factored_ok(W, bt):
-            raise RuntimeError("factored AdamW: unsupported fusion-conv geometry (set CSTS_AMD.FACTORED_ADAMW False)")
         items.append((W, dy.reshape(bt, W.shape[0]), A.reshape(bt, -1)))
     optimizer.set_factored(items)
 
@@ -188,6 +195,9 @@ def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: O
     Returns (loss, kld, nce) as device tensors (no host sync)."""
     if optimizer is not None and lr is not None:
         set_lr(optimizer, lr)
+    if optimizer is not None and getattr(optimizer, "_ext_grads", None) is not None:
+        # 16-bit bucket views left behind by a SegmentedTrainStep on this optimizer: this step's gradients are p.grad
+        optimizer.set_external_grads(None)
     if optimizer is not None and hasattr(optimizer, "params"):
         optimizer.zero_grad(set_to_none=True)        # cached parameter list (nn.Module.parameters() walks the tree: ~5 ms)
     else:
@@ -202,6 +212,10 @@ def train_step(cfg, model, batch: Dict[str, torch.Tensor], optimizer=None, lr: O
         model.finish()
     if optimizer is not None:
         _clip_and_step(cfg, model, optimizer)
+        if hasattr(optimizer, "set_factored") and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            # eager: the factors belong to THIS backward pass; a step() without a fresh backward must not reuse them.  (Under
+            # capture they are the graph's static tensors and stay installed for its replays.)
+            optimizer.set_factored(None)
     return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
 
 
@@ -313,6 +327,8 @@ class GraphedTrainStep:
             warmup = max(warmup, 3)          # bucket order and per-bucket streams are learnt in the first iterations
         self.cfg, self.model, self.opt = cfg, model, optimizer
         self.static = {k: example_batch[k].clone() for k in ("video", "audio", "labels_hm")}
+        if getattr(optimizer, "_ext_grads", None) is not None:
+            optimizer.set_external_grads(None)       # bucket views of an earlier SegmentedTrainStep on this optimizer
         from . import ops
         mode = ops.GROUP_WGRADS
         if mode == "capture":
@@ -709,11 +725,27 @@ class SegmentedTrainStep:
             return
         if hasattr(self.opt, "set_factored"):
             self.opt.set_factored(None)
-        tgt = self.averaged_grads()
+        tgt = self.averaged_grads() if self.dist else None
         for W, gdy, gA, compute, rows in self._gathered:
-            out = tgt[W].view(W.shape[0], -1)
+            if tgt is not None:
+                out = tgt[W].view(W.shape[0], -1)
+            else:
+                # one process (no buckets): a plain, persistent p.grad -- the optimizer graph captured its address
+                store = self.__dict__.setdefault("_dense_factor_grads", {})
+                if id(W) not in store:
+                    store[id(W)] = torch.empty(W.shape[0], W.numel() // W.shape[0], dtype=torch.float32, device=W.device)
+                out = store[id(W)]
+                W.grad = out.view(W.shape)
             K = out.shape[1]
             ops.gemm(L.GEMM_TN, gdy, 0, W.shape[0], gA, 0, K, out, K, W.shape[0], K, rows, compute=compute)
+
+    def close(self):
+        """Give the optimizer back: it reads p.grad again (not this step's 16-bit bucket views) and holds no gradient factors of
+        this step's graphs.  Call before running train_step / GraphedTrainStep on the same optimizer (both also reset it)."""
+        if hasattr(self.opt, "set_external_grads"):
+            self.opt.set_external_grads(None)
+        if hasattr(self.opt, "set_factored"):
+            self.opt.set_factored(None)
 
     def _bucket16_back(self):
         """16-bit buckets with an optimizer that reads p.grad (stock torch optimizers; the gloo CPU tests): the averaged 16-bit

@@ -32,10 +32,10 @@ enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 
 /* Version of this header's struct layouts and call semantics.  Bumped whenever a struct grows or a field changes meaning
- * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients).  csts_abi_version() returns the value the
+ * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients; 6: csts_copy_token_segments).  csts_abi_version() returns the value the
  * LIBRARY was built with: a caller must compare it with the CSTS_ABI_VERSION it was compiled against and refuse a mismatch
  * (the Python binding does, csts_amd/lib.py::load). */
-#define CSTS_ABI_VERSION 5
+#define CSTS_ABI_VERSION 6
 const char* csts_last_error(void);
 int csts_abi_version(void);
 int csts_half_kind(void);   /* the 16-bit type behind CSTS_BF16 in THIS library: 0 bfloat16 (libcsts_hip.so), 1 IEEE half (libcsts_hip_f16.so) */
@@ -265,6 +265,14 @@ int csts_add2_scaled_copy(const void* a, int a_dt, const void* b, int b_dt, floa
 typedef struct { int B, C, T, H, W, sh, sw, Hc, Wc; } csts_kv_rows_geom;
 int csts_rows_gather(const csts_kv_rows_geom* g, const void* src, int dt, void* dst, hipStream_t stream);
 int csts_rows_scatter_add(const csts_kv_rows_geom* g, const void* src, int src_dt, void* dst, int dst_dt, hipStream_t stream);
+
+/* ---- Token-axis concatenation / split of (B, N, C) tensors in ONE launch (round 5): the fusion head joins the visual tokens with
+ *      the pooled audio tokens (custom_multimodal_builder.py:421-423 torch.cat(dim=1), :448) and cuts the fused sequences apart again
+ *      (:432,454-455 x[:, :N], x[:, N:]); through torch those are cat / slice / copy / fill / add nodes in both directions.
+ *      Segment i copies n rows of C contiguous elements per batch element: dst[b * dst_bs + dst_off + r * C + c] =
+ *      src[b * src_bs + src_off + r * C + c] (offsets and batch strides in elements; all multiples of 16 bytes).  nseg <= 4. */
+typedef struct { const void* src; void* dst; int64_t src_bs, dst_bs, src_off, dst_off; int n; int pad_; } csts_token_segment;
+int csts_copy_token_segments(const csts_token_segment* segs, int nseg, int B, int C, int dt, hipStream_t stream);
 
 int csts_scale_rows(const void* x, int x_dt, const float* row_scale, int64_t rows_per_scale, void* out, int out_dt,
                     int64_t M, int64_t N, hipStream_t stream);   /* drop-path backward (common.py:46-59) */

@@ -511,7 +511,8 @@ def test_train_step_runs_bf16_b4():
     assert torch.isfinite(l0) and torch.isfinite(l1)
     # the three fusion-conv weights have no materialised gradient: FusedAdamW formed it on the fly from its rank-(B T') factors
     fac = {id(m.vision_pool.weight), id(m.audio_pool.weight), id(m.audio_pool2.weight)}
-    assert {id(opt.params[i]) for i, _, _ in opt._factored} == fac
+    assert {id(p) for p in opt.last_factored_params} == fac
+    assert opt._factored is None          # eager steps drop the factors after use (a step() without a fresh backward must not reuse them)
     assert all((p.grad is None) if id(p) in fac else (p.grad is not None and bool(torch.isfinite(p.grad).all())) for p in m.parameters())
     assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
     _MODELS.clear()     # weights were updated: do not reuse

@@ -1240,3 +1240,32 @@ def test_mlp_inference_forward_does_not_keep_the_preactivation_and_matches_train
     assert torch.equal(y_inf, y_tr.detach())
     ref = F.linear(F.gelu(F.linear(x.float(), W1 if compute == L.F32 else w16[0].float(), b1)), W2 if compute == L.F32 else w16[1].float(), b2) + res
     assert rel_l2(y_inf, ref) < (2e-5 if compute == L.F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_token_cat_and_split_equal_torch(dt):
+    """ops.cat_tokens / ops.split_tokens (csts_copy_token_segments) == torch.cat(dim=1) / x[:, :n], x[:, n:], values and gradients,
+    bit for bit (custom_multimodal_builder.py:421-423,432,448,454-455); an unused half of a split gets a zero gradient."""
+    B, Na, Nb, Cc = 3, 37, 5, 96
+    a = rnd(B, Na, Cc, seed=1).to(dt).requires_grad_(True)
+    b = rnd(B, Nb, Cc, seed=2).to(dt).requires_grad_(True)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    y = ops.cat_tokens(a, b)
+    y2 = torch.cat([a2, b2], dim=1)
+    assert isinstance(y.grad_fn, torch.autograd.function.BackwardCFunction) and torch.equal(y, y2)
+    g = rnd(B, Na + Nb, Cc, seed=3).to(dt)
+    y.backward(g); y2.backward(g)
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+    x = rnd(B, Na + Nb, Cc, seed=4).to(dt).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    p, q = ops.split_tokens(x, Na)
+    assert p.is_contiguous() and q.is_contiguous() and torch.equal(p, x2[:, :Na]) and torch.equal(q, x2[:, Na:])
+    gp, gq = rnd(B, Na, Cc, seed=5).to(dt), rnd(B, Nb, Cc, seed=6).to(dt)
+    (p * gp).sum().backward(retain_graph=True)         # only the first half is used
+    (x2[:, :Na] * gp).sum().backward()
+    assert torch.equal(x.grad, x2.grad)
+    x.grad = None; x2.grad = None
+    p, q = ops.split_tokens(x, Na)
+    ((p * gp).sum() + (q * gq).sum()).backward()
+    ((x2[:, :Na] * gp).sum() + (x2[:, Na:] * gq).sum()).backward()
+    assert torch.equal(x.grad, x2.grad)

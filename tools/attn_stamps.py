@@ -34,19 +34,23 @@ raw.csts_debug_attn_stamps.argtypes = [C.c_void_p]
 assert raw.csts_debug_attn_stamps(buf) == 0
 n = buf[0]
 t = [buf[i] for i in range(1, n)]
-print(f"{n - 1} stamps; kernel body {t[-1] - t[0]} cycles")
-# LDS-DMA tile loop: start | per tile: DMA issued, body begins, body done, loop stamp | end
-per = 4
+print(f"{n - 1} stamps; kernel body {t[-1] - t[0]} cycles" + (f"; {buf[4095]} ticks of the 100 MHz clock -> shader clock {(t[-1] - t[0]) / buf[4095] * 0.1:.2f} GHz" if buf[4095] else ""))
+# LDS-DMA tile loop (round 5, SPREAD form): start | per tile: loop top, body begins, 8 block starts (SC0 SC1 PV0 SC2 PV1 SC3 PV2 PV3),
+# body done, after body | end.  The wait for the next tile + barrier sits between "after body" and the next "loop top".
+per = 12
 rows = []
 i = 1
 prev = t[0]
 while i + per <= len(t) - 1:
     g = t[i:i + per]
-    rows.append(dict(sync=g[0] - prev, body=g[2] - g[1], tile=g[3] - prev))
-    prev = g[3]
+    blocks = [g[3 + j] - g[2 + j] for j in range(7)] + [g[10] - g[9]]
+    rows.append(dict(sync=g[0] - prev, body=g[10] - g[1], tile=g[11] - prev, blocks=blocks))
+    prev = g[11]
     i += per
 import statistics as st
 keys = ["sync", "body", "tile"]
-print("per 128-query tile, median shader-clock ticks: wait for the next tile + barrier + DMA issue | MFMA stream | whole tile "
-      "(192 MFMAs per wave = 6144 ticks at the matrix pipe's issue rate)")
+print("per 128-query tile, median shader-clock ticks: wait for the next tile + barrier | MFMA stream (96 MFMAs per wave = 3072 ticks at "
+      "the matrix pipe's issue rate) | whole tile")
 print("  " + " | ".join(f"{k} {int(st.median(r[k] for r in rows[1:]))}" for k in keys), f"({len(rows)} tiles)")
+print("  blocks SC0 SC1 PV0 SC2 PV1 SC3 PV2 PV3 (12 MFMAs = 384 ticks each): " +
+      " ".join(str(int(st.median(r["blocks"][j] for r in rows[1:]))) for j in range(8)))

@@ -19,7 +19,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ
   echo "pmc pass $i done"
 done
 python tools/mfma_util.py $O/trace $O/order.json $O/p1 $O/p2 $O/p3 $O/p4 $O/p5 > $O/mfma_util.txt
-python tools/pmc_traffic.py $O/p4 $O/p5 $O/pmc_traffic.json > $O/pmc_traffic_top.txt
+python tools/pmc_traffic.py $O/p4 $O/p5 $O/pmc_traffic.json --steps-profiled 2 > $O/pmc_traffic_top.txt      # 1 warm-up + 1 timed eager step per pass
 cp $(find $O/trace -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 python tools/step_kernel_counts.py $O/trace 200 > $O/step_inventory.txt
 python tools/sum_kernel_trace.py $O/trace _kernel > $O/kernel_by_grid.txt
