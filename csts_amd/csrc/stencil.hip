@@ -82,10 +82,27 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float
 // converted and accumulated.  Out-of-range taps read a ZERO weight row (strided / transposed) or are masked on the
 // raw bits (wgrad).  Measured with rocprofv3 PMC on MI355X: the earlier "load, convert, continue" form spent 79 %
 // of its wave cycles in s_waitcnt (one HBM/L2 round trip per tap).  Strides are powers of two (mask / shift).
+// n / d for 0 <= n < 2^31 as one 64-bit multiply-add and one shift (m = ceil(2^(31+s) / d), s = ceil(log2 d): exact, see fast_div()):
+// a division by a run-time integer is ~25 vector instructions, and every work item of the stencil kernels did five of them
+// (token -> (b, t, h, w), channel chunk, head) for ~500 instructions of arithmetic (round 5; profiles/r5_stencil_wgrad_isa.txt).
+struct FastDiv { unsigned m; int sh; int d; };
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)n * f.m) >> f.sh); }
 struct RowGeom {
   Geom g;
   int lt, lh, lw;        // log2 strides
+  FastDiv dNc, dHc, dWc; // coarse tokens per batch element, coarse H, W
+  FastDiv dNf, dHf, dWf; // fine tokens per batch element, fine H, W
+  FastDiv dN2, dH2, dW2; // the 2 x 2-block grid of dwconv_transposed_s22 (Tf * Hf/2 * Wf/2, Hf/2, Wf/2)
+  FastDiv dC4, dC8, dHD, dHeads;   // C / 4, C / 8 channel chunks per token, head_dim, heads
 };
+__device__ __forceinline__ void decompf(int bt, const FastDiv& dN, const FastDiv& dH, const FastDiv& dW, int& b, int& t, int& h, int& w) {
+  b = fdiv(bt, dN);
+  int o = bt - b * dN.d;
+  const int q = fdiv(o, dW);
+  w = o - q * dW.d;
+  t = fdiv(q, dH);
+  h = q - t * dH.d;
+}
 
 // 32-bit decomposition of a flat token index (host guarantees B*ntok*C < 2^31)
 __device__ __forceinline__ void decomp(int bt, int ntok, int H, int W, int& b, int& t, int& h, int& w) {
@@ -247,10 +264,10 @@ __global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const v
   const int total = g.B * ntok * CQ;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int bt = idx / CQ;
-    const int c = (idx - bt * CQ) * V, cw = c % g.HD;
+    const int bt = fdiv(idx, V == 8 ? rg.dC8 : rg.dC4);
+    const int c = (idx - bt * CQ) * V, cw = c - fdiv(c, rg.dHD) * g.HD;
     int b, ot, oh, ow;
-    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+    decompf(bt, rg.dNc, rg.dHc, rg.dWc, b, ot, oh, ow);
     int tof[3], hof[3], xof[3];
     bool tv[3], hv[3], xv[3];
 #pragma unroll
@@ -313,13 +330,6 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [nslots][28][HD]
   const Geom& g = rg.g;
   const int HD = g.HD, H = g.C / HD;
-  {   // stage both slots' weights (tap-major, one zero row each)
-    // POOLLN_SPLIT8 (round 4, -DCSTS_POOLLN_SPLIT8): the conflict-free row layout took SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS from 3.56
-    // to 0.53 and made the kernel 8-10 % SLOWER (tools/pool_ln_bench.py: 17.4 -> 19.1 us at the 384-channel stage): the kernel is
-    // bound by its dependent global-load rounds, and the permuted staging costs every workgroup more than the conflicts did.  Off.
-    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows<POOLLN_SPLIT8>(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
-    __syncthreads();
-  }
   const int lane_in = threadIdx.x % GL;
   const bool active = lane_in * 8 < HD;
   const int c8 = min(lane_in * 8, HD - 8);                    // idle lanes shadow the last active one (loads stay in range)
@@ -329,13 +339,33 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   const int total = per_slot * nslots;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   const float invHD = 1.f / HD;
-  for (int item = blockIdx.x * groups_per_block + threadIdx.x / GL; item < total; item += gridDim.x * groups_per_block) {
-    const int slot = item / per_slot;
+  // Round 5: the tap loads of the workgroup's FIRST items are in flight while the weight tables are staged (the loads do not depend on
+  // the weights; staged first, the tables were one more dependent round trip -- global -> registers -> LDS -> barrier -- in front of the
+  // three tap rounds of a kernel that is bound by exactly those round trips: profiles/r5_stencil_ab.txt).
+  bool staged = false;
+  auto stage = [&]() {   // both slots' weights (tap-major, one zero row each)
+    // POOLLN_SPLIT8 (round 4, -DCSTS_POOLLN_SPLIT8): the conflict-free row layout took SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS from 3.56
+    // to 0.53 and made the kernel 8-10 % SLOWER (tools/pool_ln_bench.py: 17.4 -> 19.1 us at the 384-channel stage): the kernel is
+    // bound by its dependent global-load rounds, and the permuted staging costs every workgroup more than the conflicts did.  Off.
+    for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows<POOLLN_SPLIT8>(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
+    __syncthreads();
+    staged = true;
+  };
+#ifdef CSTS_POOLLN_STAGE_FIRST                 // A/B build: tables staged in front of the first tap loads (rounds 1-4)
+  stage();
+#endif
+  const int item0 = blockIdx.x * groups_per_block + threadIdx.x / GL;
+  // every thread runs the first pass (an item past the end is clamped and only not stored): the barrier inside stage() is then reached
+  // by the whole workgroup at the same place
+  for (int item_raw = item0, pass = 0; pass == 0 || item_raw < total; item_raw += gridDim.x * groups_per_block, ++pass) {
+    const bool live = item_raw < total;
+    const int item = min(item_raw, total - 1);
+    const int slot = item >= per_slot ? 1 : 0;            // (nslots <= 2)
     int r = item - slot * per_slot;
-    const int head = r % H;
-    const int bt = r / H;
+    const int bt = fdiv(r, rg.dHeads);
+    const int head = r - bt * H;
     int b, ot, oh, ow;
-    decomp(bt, ntok, g.Hc, g.Wc, b, ot, oh, ow);
+    decompf(bt, rg.dNc, rg.dHc, rg.dWc, b, ot, oh, ow);
     const int c = head * HD + c8;
     int hof[3], xof[3];
     bool hv[3], xv[3];
@@ -370,6 +400,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw8_load<F32>(fb, tofk + hof[kh] + xof[kw]);
+      if (!staged) stage();                    // first pass, first round: the tables arrive under these loads
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -405,7 +436,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
 #pragma unroll
     for (int o = GL / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
     const float rs = rsqrtf(s2 * invHD + eps);
-    if (active) {
+    if (active && live) {
       const int64_t off = (int64_t)b * g.c_bs + (int64_t)(bt - b * ntok) * cts + c;
       st8t<F32>(sl.conv[slot], off, acc);
       const float4 g0 = *reinterpret_cast<const float4*>(sl.gamma[slot] + c8), g1 = *reinterpret_cast<const float4*>(sl.gamma[slot] + c8 + 4);
@@ -464,10 +495,10 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slot
   const int total = g.B * ntok * CQ;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int bt = idx / CQ;
-    const int c = (idx - bt * CQ) * V, cw = c % g.HD;
+    const int bt = fdiv(idx, V == 8 ? rg.dC8 : rg.dC4);
+    const int c = (idx - bt * CQ) * V, cw = c - fdiv(c, rg.dHD) * g.HD;
     int b, ft, fh, fw;
-    decomp(bt, ntok, g.Hf, g.Wf, b, ft, fh, fw);
+    decompf(bt, rg.dNf, rg.dHf, rg.dWf, b, ft, fh, fw);
     int kt[NT], ot[NT], kh[NH], oh[NH], kw[NW], ow[NW];
     bool vt[NT], vh[NH], vw[NW];
     axis_cand<NT>(ft, g.st, rg.lt, g.Tc, kt, ot, vt);
@@ -523,10 +554,10 @@ __global__ __launch_bounds__(256) void dwconv_transposed_s22_kernel(RowGeom rg, 
   const int total = g.B * nblk * CQ;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int bt = idx / CQ;
-    const int c = (idx - bt * CQ) * 8, cw = c % g.HD;
+    const int bt = fdiv(idx, rg.dC8);
+    const int c = (idx - bt * CQ) * 8, cw = c - fdiv(c, rg.dHD) * g.HD;
     int b, ft, mh, mw;
-    decomp(bt, nblk, H2, W2, b, ft, mh, mw);
+    decompf(bt, rg.dN2, rg.dH2, rg.dW2, b, ft, mh, mw);
     int kt[NT], ot[NT];
     bool vt[NT];
     axis_cand<NT>(ft, g.st, rg.lt, g.Tc, kt, ot, vt);
@@ -603,66 +634,78 @@ __device__ __forceinline__ void dwconv_wgrad_body(const Geom& g, const void* __r
   int b = 0, ot = 0, oh = 0, ow = 0;
   if (beg + ty < end) decomp(beg + ty, ntok, g.Hc, g.Wc, b, ot, oh, ow);
   const int tstep = lanes;
+  // Round 5: every tap address is ONE 32-bit add on top of a wave-uniform base (scalar base + 32-bit lane offset form of global_load:
+  // the host guarantees B * tokens * C < 2^31 elements).  The per-lane 64-bit base of rounds 1-4 (fine + b * f_bs as a pointer) made the
+  // compiler carry every one of the 27 addresses as a 64-bit quantity: 43 v_lshl_add_u64 + 17 v_mul_lo + sign extensions per token, a
+  // third of the loop's 430 vector instructions in a kernel that is bound by vector issue (profiles/r5_stencil_wgrad_isa.txt).
+  const char* fbase = reinterpret_cast<const char*>(fine);
+  const char* cbase = reinterpret_cast<const char*>(coarse);
+  constexpr unsigned FES = FF32 ? 4u : 2u, CES = CF32 ? 4u : 2u;
   for (int bt = beg + ty; bt < end; bt += tstep) {
-    int tof[3], hof[3], xof[3];
-    bool tv[3], hv[3], xv[3];
+    unsigned tof[3], hx[9];
+    bool tv[3], hxv[9];
+    {
+      unsigned hof[3], xof[3];
+      bool hv[3], xv[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int t = ot * g.st - 1 + k, h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
-      tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
-      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
-      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
+      for (int k = 0; k < 3; ++k) {
+        const int t = ot * g.st - 1 + k, h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
+        tv[k] = (unsigned)t < (unsigned)g.Tf; tof[k] = (unsigned)(min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts);
+        hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = (unsigned)(min(max(h, 0), g.Hf - 1) * g.Wf * fts);
+        xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = (unsigned)(min(max(x, 0), g.Wf - 1) * fts + c);
+      }
+      const unsigned boff = (unsigned)((int)g.f_bs * b);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { hx[kh * 3 + kw] = boff + hof[kh] + xof[kw]; hxv[kh * 3 + kw] = hv[kh] && xv[kw]; }
     }
-    const void* fb = bptr<FF32>(fine, (int64_t)b * g.f_bs);
-    const void* cb = bptr<CF32>(coarse, (int64_t)b * g.c_bs);
     float c0, c1;
-    if constexpr (CF32) {
-      const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(cb) + (bt - b * ntok) * cts + c);
-      c0 = v.x; c1 = v.y;
-    } else {
-      const unsigned v = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16*>(cb) + (bt - b * ntok) * cts + c);
-      c0 = h16_lo(v); c1 = h16_hi(v);
+    {
+      const unsigned coff = ((unsigned)((int)g.c_bs * b) + (unsigned)((bt - b * ntok) * cts + c)) * CES;
+      if constexpr (CF32) {
+        const float2 v = *reinterpret_cast<const float2*>(cbase + coff);
+        c0 = v.x; c1 = v.y;
+      } else {
+        const unsigned v = *reinterpret_cast<const unsigned*>(cbase + coff);
+        c0 = h16_lo(v); c1 = h16_hi(v);
+      }
     }
     if constexpr (FF32) {
       float2 raw[27];
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            raw[kt * 9 + kh * 3 + kw] = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(fb) + tof[kt] + hof[kh] + xof[kw]);
+        for (int j = 0; j < 9; ++j) raw[kt * 9 + j] = *reinterpret_cast<const float2*>(fbase + (tof[kt] + hx[j]) * FES);
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int tap = kt * 9 + kh * 3 + kw;
-            const bool ok = tv[kt] && hv[kh] && xv[kw];
-            a0[tap] += (ok ? raw[tap].x : 0.f) * c0;
-            a1[tap] += (ok ? raw[tap].y : 0.f) * c1;
-          }
+        for (int j = 0; j < 9; ++j) {
+          const int tap = kt * 9 + j;
+          const bool ok = tv[kt] && hxv[j];
+          a0[tap] += (ok ? raw[tap].x : 0.f) * c0;
+          a1[tap] += (ok ? raw[tap].y : 0.f) * c1;
+        }
     } else {
       unsigned raw[27];
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            raw[kt * 9 + kh * 3 + kw] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16*>(fb) + tof[kt] + hof[kh] + xof[kw]);
+        for (int j = 0; j < 9; ++j) raw[kt * 9 + j] = *reinterpret_cast<const unsigned*>(fbase + (tof[kt] + hx[j]) * FES);
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int tap = kt * 9 + kh * 3 + kw;
-            const unsigned r = (tv[kt] && hv[kh] && xv[kw]) ? raw[tap] : 0u;
-            a0[tap] += h16_lo(r) * c0;
-            a1[tap] += h16_hi(r) * c1;
-          }
+        for (int j = 0; j < 9; ++j) {
+          const int tap = kt * 9 + j;
+          const unsigned r = (tv[kt] && hxv[j]) ? raw[tap] : 0u;
+#ifdef CSTS_SWG_FMA            // A/B build: fused multiply-add (one rounding less per tap; NOT bit-identical to the shipped form)
+          a0[tap] = __builtin_fmaf(h16_lo(r), c0, a0[tap]);
+          a1[tap] = __builtin_fmaf(h16_hi(r), c1, a1[tap]);
+#else
+          a0[tap] += h16_lo(r) * c0;
+          a1[tap] += h16_hi(r) * c1;
+#endif
+        }
     }
     ow += tstep;
     while (ow >= g.Wc) {
@@ -1084,6 +1127,18 @@ int grid_for_staged(int64_t total) { return (int)std::min<int64_t>(cdiv(total, 2
 int ilog2(int v) { if (v <= 0 || (v & (v - 1)) != 0) return -1; int l = 0; while ((1 << l) < v) ++l; return l; }   // -1: not a power of two
 bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// FastDiv of d >= 1 for dividends below 2^31: with s = ceil(log2 d) and m = ceil(2^(31+s) / d) (< 2^32 because d > 2^(s-1)),
+// n m / 2^(31+s) = n / d + n e / 2^(31+s) with 0 <= e < 1, and n / 2^(31+s) < 1 / 2^s <= 1 / d: the floor is that of n / d.
+FastDiv fast_div(int d) {
+  FastDiv f; f.d = d;
+  if (d <= 1) { f.m = 1; f.sh = 0; return f; }
+  int sft = 0;
+  while ((1LL << sft) < d) ++sft;
+  const unsigned long long num = 1ULL << (31 + sft);
+  f.m = (unsigned)((num + d - 1) / d);
+  f.sh = 31 + sft;
+  return f;
+}
 int fill_geom(const csts_dwconv_geom* a, RowGeom& rg) {
   Geom& g = rg.g;
   g.B = a->B; g.C = a->C; g.HD = a->HD;
@@ -1092,6 +1147,10 @@ int fill_geom(const csts_dwconv_geom* a, RowGeom& rg) {
   g.f_bs = a->fine_batch_stride; g.f_ts = a->fine_token_stride;
   g.c_bs = a->coarse_batch_stride; g.c_ts = a->coarse_token_stride;
   rg.lt = ilog2(a->st); rg.lh = ilog2(a->sh); rg.lw = ilog2(a->sw);
+  rg.dNc = fast_div(a->Tc * a->Hc * a->Wc); rg.dHc = fast_div(a->Hc); rg.dWc = fast_div(a->Wc);
+  rg.dNf = fast_div(a->Tf * a->Hf * a->Wf); rg.dHf = fast_div(a->Hf); rg.dWf = fast_div(a->Wf);
+  rg.dN2 = fast_div(std::max(1, a->Tf * (a->Hf / 2) * (a->Wf / 2))); rg.dH2 = fast_div(std::max(1, a->Hf / 2)); rg.dW2 = fast_div(std::max(1, a->Wf / 2));
+  rg.dC4 = fast_div(std::max(1, a->C / 4)); rg.dC8 = fast_div(std::max(1, a->C / 8)); rg.dHD = fast_div(a->HD); rg.dHeads = fast_div(a->C / a->HD);
   return 0;
 }
 

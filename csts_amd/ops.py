@@ -446,7 +446,15 @@ def flush_wgrads(side: bool = False):
     if side:
         launch_stream = _wg_side.get(dev.index)
         if launch_stream is None:
-            launch_stream = _wg_side[dev.index] = torch.cuda.Stream(device=dev)
+            # CSTS_WG_SIDE_PRIO=low: the early weight-gradient flushes on a LOW-priority stream (experiment, round 5: they should only
+            # fill the CUs the activation-gradient chain leaves idle, not delay it)
+            prio = 0
+            if os.environ.get("CSTS_WG_SIDE_PRIO", "") == "low":
+                try:
+                    prio = max(torch.cuda.Stream.priority_range())
+                except Exception:
+                    prio = 0
+            launch_stream = _wg_side[dev.index] = torch.cuda.Stream(device=dev, priority=prio)
         for st in _wg_prod.values():          # autograd runs every node of this device on ONE thread: whatever produced the
             ev = torch.cuda.Event()           # queued operands is already enqueued on these streams
             ev.record(st)
@@ -462,7 +470,11 @@ def flush_wgrads(side: bool = False):
             return (False, 192)
         return (False, 256 if t[5] % 256 == 0 else 128)
     pend = []           # (item table image, items, tile rows, fp32 dY) per tile class
-    for a_f32, rows in ((False, 192), (False, 256), (False, 128), (True, 128)):
+    # WGRAD8_LAST (with CSTS_STENCIL_TAIL_SIDE=1): the 192 x 384 class -- one 144 KB-LDS workgroup per CU, nothing fits beside it -- goes
+    # last, so that the grouped stencil weight gradients on the side stream (vector-bound, 20 KB of LDS, 124 registers) start beside the
+    # 128-wide classes (memory-bound, 40 KB of LDS, 154 registers), which they CAN share a CU with
+    order = ((False, 256), (False, 128), (True, 128), (False, 192)) if WGRAD8_LAST else ((False, 192), (False, 256), (False, 128), (True, 128))
+    for a_f32, rows in order:
         probs = [t for t in q if tile_class(t) == (a_f32, rows)]
         if not probs:
             continue
@@ -522,7 +534,12 @@ def flush_wgrads(side: bool = False):
 # Same policy as the grouped Linear weight gradients: while the step is captured (GROUP_WGRADS), and only when the gradient may be
 # deferred; the operands (the saved q / k / v tensors and the conv-output gradients) stay alive until the flush.
 STENCIL_WGRAD_GROUPED = os.environ.get("CSTS_STENCIL_WGRAD_GROUPED", "1") != "0"
-STENCIL_TAIL_SIDE = os.environ.get("CSTS_STENCIL_TAIL_SIDE", "0") == "1"     # MEASURED NEUTRAL (20.85-21.05 vs 20.95-21.06 ms, profiles/r4_branch_streams_ab.txt): wgrad8's 144 KB of LDS leave no room for a second workgroup on its CUs; off
+# Round 5: the grouped stencil weight gradients (vector-issue-bound, 20 KB of LDS, 124 registers) run on a side stream BESIDE the 128-wide
+# classes of the grouped Linear weight gradients (memory-bound, 40 KB of LDS, 154 registers): the two share CUs, -0.2 ... -0.26 ms per step
+# (profiles/r5_wgrad_tail_ab.txt).  What made the same side stream neutral in round 4 was the ORDER: the 192 x 384 class went first, and
+# its one 144 KB-LDS workgroup per CU leaves no room for anything else -- it now goes last (WGRAD8_LAST).  =0 restores either.
+WGRAD8_LAST = os.environ.get("CSTS_WGRAD8_LAST", "1") != "0"
+STENCIL_TAIL_SIDE = os.environ.get("CSTS_STENCIL_TAIL_SIDE", "1") != "0"
 _tail_side = {}         # device index -> stream
 _swq = []               # (DwconvGeom copy, fine ptr, coarse ptr, workspace ptr, dt, (tensors kept alive))
 _swq_tables = {}        # device index -> HostTable
