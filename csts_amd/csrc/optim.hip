@@ -406,14 +406,16 @@ __global__ __launch_bounds__(256) void opt_adamw_factored_mfma_kernel(FactoredLi
 
 }  // namespace
 
-static int factored_fill(const csts_opt_factored* items, int nitems, FactoredList& l, int* max_k, int* max_n) {
+constexpr int FT_MFMA = 256;  // token rows the MFMA form of the update takes (no LDS tile, a k-loop over T): the data-parallel chain's W * B * T' rows at 8 ranks
+static int factored_fill(const csts_opt_factored* items, int nitems, FactoredList& l, int* max_k, int* max_n, int max_t = FT) {
   CSTS_REQUIRE(items != nullptr && nitems > 0 && nitems <= FMAX, "1 .. 8 items per call");
   *max_k = 0; *max_n = 0;
   int64_t off = 0;
   for (int i = 0; i < nitems; ++i) {
     const csts_opt_factored& it = items[i];
     CSTS_REQUIRE(it.p && it.m && it.v && it.dy && it.a, "null pointer");
-    CSTS_REQUIRE(it.T > 0 && it.T <= FT && it.K > 0 && it.K % FK == 0 && it.N > 0 && it.N % 16 == 0, "T <= 64, K % 256 == 0, N % 16 == 0");
+    CSTS_REQUIRE(it.T > 0 && it.T <= max_t && it.K > 0 && it.K % FK == 0 && it.N > 0 && it.N % 16 == 0,
+                 "T <= 64 (256 for the update with 16-bit operands), K % 256 == 0, N % 16 == 0");
     CSTS_REQUIRE(it.a_dt == CSTS_F32 || it.a_dt == CSTS_HALF, "bad a dtype");
     CSTS_REQUIRE(aligned16(it.p) && aligned16(it.m) && aligned16(it.v) && (it.w16 == nullptr || ((uintptr_t)it.w16 & 7) == 0), "alignment");
     l.it[i] = it;
@@ -456,7 +458,9 @@ extern "C" int csts_adamw_factored(const csts_opt_factored* items, int nitems, c
                                    float beta2, float eps, hipStream_t stream) {
   FactoredList l;
   int mk, mn;
-  if (int rc = factored_fill(items, nitems, l, &mk, &mn)) return rc;
+  bool half_ops = items != nullptr && nitems > 0 && nitems <= FMAX;
+  for (int i = 0; half_ops && i < nitems; ++i) half_ops = items[i].a_dt == CSTS_HALF && (int64_t)items[i].N * items[i].K * 4 < ((int64_t)1 << 31) && items[i].K % 64 == 0;
+  if (int rc = factored_fill(items, nitems, l, &mk, &mn, half_ops ? FT_MFMA : FT)) return rc;
   CSTS_REQUIRE(state != nullptr && lr != nullptr, "null state");
   int mt = 0;
   for (int i = 0; i < nitems; ++i) mt = std::max(mt, items[i].T);

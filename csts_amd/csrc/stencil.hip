@@ -253,8 +253,11 @@ __device__ __forceinline__ void stage_weights_z(const float* __restrict__ w, flo
 }
 
 // coarse[b,o,c] = sum_k fine[b, o*s-1+k, c] * w[c%HD][k]          (V channels per thread)
+#ifndef CSTS_DW_WAVES
+#define CSTS_DW_WAVES 1       // minimum waves per SIMD the strided / transposed stencils are compiled for (A/B builds: 3, 4)
+#endif
 template <bool FF32, bool CF32, int V>
-__global__ __launch_bounds__(256) void dwconv_strided_kernel(RowGeom rg, const void* __restrict__ fine,
+__global__ __launch_bounds__(256, CSTS_DW_WAVES) void dwconv_strided_kernel(RowGeom rg, const void* __restrict__ fine,
                                                              const float* __restrict__ w, void* __restrict__ coarse) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const Geom& g = rg.g;
@@ -339,9 +342,9 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   const int total = per_slot * nslots;
   const int fts = (int)g.f_ts, cts = (int)g.c_ts;
   const float invHD = 1.f / HD;
-  // Round 5: the tap loads of the workgroup's FIRST items are in flight while the weight tables are staged (the loads do not depend on
-  // the weights; staged first, the tables were one more dependent round trip -- global -> registers -> LDS -> barrier -- in front of the
-  // three tap rounds of a kernel that is bound by exactly those round trips: profiles/r5_stencil_ab.txt).
+  // -DCSTS_POOLLN_EARLY_LOADS (round 5, measured and NOT kept): the tap loads of the workgroup's first items in flight while the weight
+  // tables are staged (the loads do not depend on the weights).  With the staging inside the item loop the kernel spills 30-36 registers
+  // instead of 8-12 at its 128-register budget and runs 25-35 % SLOWER per launch, +0.37 ms per step (profiles/r5_stencil_ab.txt).
   bool staged = false;
   auto stage = [&]() {   // both slots' weights (tap-major, one zero row each)
     // POOLLN_SPLIT8 (round 4, -DCSTS_POOLLN_SPLIT8): the conflict-free row layout took SQ_LDS_BANK_CONFLICT / SQ_INSTS_LDS from 3.56
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
     __syncthreads();
     staged = true;
   };
-#ifdef CSTS_POOLLN_STAGE_FIRST                 // A/B build: tables staged in front of the first tap loads (rounds 1-4)
+#ifndef CSTS_POOLLN_EARLY_LOADS               // default: tables staged in front of the first tap loads
   stage();
 #endif
   const int item0 = blockIdx.x * groups_per_block + threadIdx.x / GL;
@@ -483,7 +486,7 @@ struct Slots2 {
 };
 
 template <int NT, int NH, int NW, bool CF32, bool FF32, int V>
-__global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slots2 sl) {
+__global__ __launch_bounds__(256, CSTS_DW_WAVES) void dwconv_transposed_kernel(RowGeom rg, Slots2 sl) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const void* __restrict__ coarse = sl.src[blockIdx.y];
   const float* __restrict__ w = sl.w[blockIdx.y];
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256) void dwconv_transposed_kernel(RowGeom rg, Slot
 // {mh, mh+1} x {mw, mw+1} once per temporal tap -- 4 loads per 4 outputs where the generic kernel issues 4 per output
 // (two of them on average for taps that do not exist at that parity).  The tap loads are what bounds these kernels.
 template <int NT>
-__global__ __launch_bounds__(256) void dwconv_transposed_s22_kernel(RowGeom rg, Slots2 sl) {
+__global__ __launch_bounds__(256, CSTS_DW_WAVES) void dwconv_transposed_s22_kernel(RowGeom rg, Slots2 sl) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const bf16* __restrict__ coarse = reinterpret_cast<const bf16*>(sl.src[blockIdx.y]);
   bf16* __restrict__ fine = reinterpret_cast<bf16*>(sl.dst[blockIdx.y]);

@@ -18,6 +18,7 @@
 // 16-byte stores (MFMA operands swapped so that a lane owns runs of 4 consecutive columns).  All Linear layers of the 384- and 768-channel stages
 // have output features % 192 == 0 and input features % 384 == 0; token chunks must be multiples of 64 (host-checked).
 #include "common.h"
+#include <algorithm>
 
 // Diagnostics build (-DCSTS_WGRAD8_STAMPS, `make stamps`, tools/wgrad8_stamps.py): thread 0 of workgroup 0 records shader-clock
 // stamps around the phases of every k-tile.  No stamp code exists in the library build.
@@ -70,12 +71,18 @@ __device__ __forceinline__ bf16x8 frag_rot(const char* S, int obase, int ks, int
 template <int N> __device__ __forceinline__ void w8_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BK, int S>
-__global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item* __restrict__ items) {
+__global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item* __restrict__ items, int nitems) {
   typedef W8<BK, S> G;
   constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE, NPW = G::NPW, REM = G::REM;
   __shared__ __attribute__((aligned(1024))) char smem[S * STAGE];
-  const csts_wgrad_item it = items[blockIdx.x];
-  if (it.A == nullptr) return;          // padding slot (the host equalises the per-XCD lists); block-uniform
+  // Round 5: a workgroup walks items blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8, so an item keeps the XCD its
+  // position in the table was chosen for).  With gridDim.x == nitems this is the one-item-per-workgroup launch of rounds 2-4; with fewer
+  // workgroups the launch occupies only that many CUs (its 144 KB of LDS leave room for nothing else on a CU) and can run BESIDE the
+  // memory-bound end of the backward chain instead of after it (csts_wgrad_grouped8_limited, ops.flush_wgrads(early192=True)).
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  if (item != (int)blockIdx.x) __syncthreads();   // everyone is done with the previous item's LDS (ring and column-sum scratch)
+  const csts_wgrad_item it = items[item];
+  if (it.A == nullptr) continue;        // padding slot (the host equalises the per-XCD lists); block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
     if (s2 < nk) issue(smem + s2 * STAGE, kbeg + (int64_t)s2 * BK);
   int cs = 0, ps = (S - 1) % S;                               // consumer stage, producer stage
 #ifdef CSTS_WGRAD8_STAMPS
-  const bool stamp_on = tid == 0 && blockIdx.x == 0;
+  const bool stamp_on = tid == 0 && item == 0;
   int nstamp = 1;
 #endif
   W8_STAMP();
@@ -215,20 +222,30 @@ __global__ __launch_bounds__(W8_THR, 2) void wgrad8_kernel(const csts_wgrad_item
           *reinterpret_cast<f32x4*>(it.C + m * it.ldc + n) = f32x4{acc[i][j][4 * t], acc[i][j][4 * t + 1], acc[i][j][4 * t + 2], acc[i][j][4 * t + 3]};
       }
   }
+  }   // item loop
 }
 
 }  // namespace
 
-// tile 192 x 384, bf16 dY and X; every item is a whole tile (M % 192 == 0, N % 384 == 0), its token range a multiple of 64,
-// rows 16-byte aligned
-extern "C" int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStream_t stream) {
+static int wgrad8_launch(const csts_wgrad_item* device_items, int nitems, int max_wgs, hipStream_t stream) {
   CSTS_REQUIRE(device_items != nullptr && nitems > 0, "no items");
   // CSTS_WGRAD8_RING=4: four stages of 32 tokens (three in flight: 108 KiB instead of 72) -- measured 20 % SLOWER on MI355X
   // (tools/wgrad8_bench.py: 862-877 us against 720-733 us for the 44 Linear layers of the 384-channel stage; a barrier every 18
   // MFMAs per wave costs more than the extra bytes in flight return).  Default: two stages of 64 tokens.
   static const bool ring4 = [] { const char* e = getenv("CSTS_WGRAD8_RING"); return e && e[0] == '4'; }();
-  if (ring4) hipLaunchKernelGGL((wgrad8_kernel<32, 4>), dim3((unsigned)nitems), dim3(W8_THR), 0, stream, device_items);
-  else hipLaunchKernelGGL((wgrad8_kernel<64, 2>), dim3((unsigned)nitems), dim3(W8_THR), 0, stream, device_items);
+  int grid = nitems;
+  if (max_wgs > 0 && max_wgs < nitems) grid = std::max(8, max_wgs / 8 * 8);      // a multiple of 8: items keep their XCD
+  if (ring4) hipLaunchKernelGGL((wgrad8_kernel<32, 4>), dim3((unsigned)grid), dim3(W8_THR), 0, stream, device_items, nitems);
+  else hipLaunchKernelGGL((wgrad8_kernel<64, 2>), dim3((unsigned)grid), dim3(W8_THR), 0, stream, device_items, nitems);
   CSTS_LAUNCH_CHECK();
   return 0;
+}
+// tile 192 x 384, bf16 dY and X; every item is a whole tile (M % 192 == 0, N % 384 == 0), its token range a multiple of 64,
+// rows 16-byte aligned
+extern "C" int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStream_t stream) {
+  return wgrad8_launch(device_items, nitems, 0, stream);
+}
+// the same on at most max_wgs workgroups (rounded down to a multiple of 8, at least 8), each walking several items
+extern "C" int csts_wgrad_grouped8_limited(const csts_wgrad_item* device_items, int nitems, int max_wgs, hipStream_t stream) {
+  return wgrad8_launch(device_items, nitems, max_wgs, stream);
 }

@@ -166,6 +166,7 @@ SYMBOLS = {
     "csts_gemm_v2_eligible": (_I, [C.POINTER(GemmArgs)]),
     "csts_wgrad_grouped": (_I, [vp, _I, _I, _I, vp]),
     "csts_wgrad_grouped8": (_I, [vp, _I, vp]),
+    "csts_wgrad_grouped8_limited": (_I, [vp, _I, _I, vp]),
     "csts_gemm_kernel_name": (_I, [C.POINTER(GemmArgs), C.c_char_p, _I, C.POINTER(_I)]),
     "csts_gemm_plan": (_I, [C.POINTER(GemmArgs), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),

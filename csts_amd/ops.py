@@ -112,8 +112,8 @@ class HostTable:
             if not self._pool:
                 raise L.CstsError("HostTable: out of capture buffers")
             host = self._pool.pop()
-            self._captured.append(host)
             host[:n].copy_(src)
+            self._captured.append(host)
             self.dev[:n].copy_(host[:n], non_blocking=True)
         else:
             k = self._pos
@@ -167,6 +167,7 @@ def reset_deferred():
     _wg_pending.clear()
     _wg_prod.clear()
     _wg_work[0] = 0.0
+    _w8_count[0] = 0
     _deferred_task[0] = -1
 
 
@@ -243,6 +244,9 @@ def flush_deferred():
     """Finish the queued weight gradients and every deferred reduction on the current stream, then hand the results to
     their parameters (idempotent)."""
     _deferred_task[0] = -1
+    if _w8_count[0]:
+        _w8_total[0] = _w8_count[0]
+    _w8_count[0] = 0
     # the grouped stencil weight gradients (0.8 ms of load-latency-bound work, no matrix math) run on a side stream BESIDE the
     # grouped Linear weight gradients (MFMA-bound, one persistent workgroup per CU whose last items leave most CUs idle)
     tail = None
@@ -352,7 +356,26 @@ def queue_wgrad(dY, X, tokens, N, K, Wp, bp):
     _wg_work[0] += 2.0 * tokens * N * K
     if WG_FLUSH_FLOP > 0 and _wg_work[0] >= WG_FLUSH_FLOP:
         flush_wgrads(side=True)
+    if W8_EARLY_WGS > 0 and _is_w8(dY, tokens, N, K):
+        # the 192 x 384 class goes out EARLY, on few workgroups, as soon as its last problem of this backward pass is queued (the count
+        # of the previous pass tells which one that is; a wrong guess only moves work between this launch and the final one)
+        _w8_count[0] += 1
+        if _w8_count[0] == _w8_total[0]:
+            flush_wgrads(side=True, only_w8=True)
     return True
+
+
+# Round 5 (CSTS_WGRAD8_EARLY_WGS = n > 0): the grouped weight gradients of the 384- / 768-channel stages (wgrad8: matrix-bound, 1.1 ms, one
+# 144 KB-LDS workgroup per CU) are launched on n workgroups on the side stream as soon as the backward pass has produced their last operand
+# -- the rest of backward (the 96- / 192-channel stages: large-M, memory-bound kernels, a third of the trunk backward) runs beside them on
+# the remaining CUs -- instead of on all CUs after the pass (profiles/r5_wgrad8_early_ab.txt).
+W8_EARLY_WGS = int(os.environ.get("CSTS_WGRAD8_EARLY_WGS", "0"))
+_w8_count = [0]         # 192 x 384-class problems queued so far in this backward pass
+_w8_total = [0]         # ... in the whole previous pass
+
+
+def _is_w8(dY, tokens, N, K):
+    return bool(WGRAD8 and dY.dtype != torch.float32 and N % 192 == 0 and K % 384 == 0 and tokens % 64 == 0 and WGRAD8_CHUNK % 64 == 0)
 
 
 _WG_DTYPE = None
@@ -427,15 +450,24 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
     return plan
 
 
-def flush_wgrads(side: bool = False):
+def flush_wgrads(side: bool = False, only_w8: bool = False):
     """Launch the queued weight gradients: on the current stream (end of backward), or -- side=True, from queue_wgrad in
-    the middle of backward -- on the side stream, after everything the producing streams have enqueued so far."""
+    the middle of backward -- on the side stream, after everything the producing streams have enqueued so far.  only_w8: just the
+    192 x 384-class problems (on W8_EARLY_WGS workgroups); everything else stays queued."""
     if not _wgq:
         return
     import numpy as np
-    q = list(_wgq)
-    _wgq.clear()
-    _wg_work[0] = 0.0
+    if only_w8:
+        q = [t for t in _wgq if _is_w8(t[0], t[4], t[5], t[6])]
+        rest = [t for t in _wgq if not _is_w8(t[0], t[4], t[5], t[6])]
+        _wgq.clear()
+        _wgq.extend(rest)
+        if not q:
+            return
+    else:
+        q = list(_wgq)
+        _wgq.clear()
+        _wg_work[0] = 0.0
     dev = q[0][0].device
     key = (dev.index, side)
     tab = _wg_tables.get(key)
@@ -520,7 +552,9 @@ def flush_wgrads(side: bool = False):
             base = tab.upload(b"".join(blob + bytes((-len(blob)) % 256) for blob, *_ in pend))
         for (blob, n_items, rows, a_f32), off in zip(pend, offs):
             ptr = base + off if base is not None else tab.upload(blob)
-            if rows == 192:
+            if rows == 192 and only_w8:
+                L.check(_lib().csts_wgrad_grouped8_limited(ptr, n_items, W8_EARLY_WGS, _stream()), "csts_wgrad_grouped8_limited")
+            elif rows == 192:
                 L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
             else:
                 L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")

@@ -112,6 +112,7 @@ class FusedAdamW:
 
     # ------------------------------------------------------------------ factored gradients (fusion convs)
     FACTORED_MAX_T = 64
+    FACTORED_MAX_T_16 = 256     # with 16-bit operands (MFMA form of the update + Gram norm through the library GEMM)
 
     def set_factored(self, items=None):
         """items: [(param, dy [T, N] fp32, a [T, K] fp32 / 16-bit)] with param.view(N, K) -- the weight gradient dY^T A of these
@@ -129,8 +130,8 @@ class FusedAdamW:
             K = p.numel() // N
             T = dy.shape[0]
             if not (dy.dtype == torch.float32 and dy.is_contiguous() and a.is_contiguous() and tuple(dy.shape) == (T, N) and tuple(a.shape) == (T, K)
-                    and T <= self.FACTORED_MAX_T and K % 256 == 0 and N % 16 == 0):
-                raise L.CstsError("factored gradient: dy [T, N] fp32 and a [T, K] contiguous, T <= 64, K % 256 == 0, N % 16 == 0")
+                    and self.factored_ok(p, T, a.dtype != torch.float32)):
+                raise L.CstsError("factored gradient: dy [T, N] fp32 and a [T, K] contiguous, T <= 64 (256 with 16-bit a), K % 256 == 0, N % 16 == 0")
             fac.append((i, dy, a))
         if len(fac) > 8:
             raise L.CstsError("at most 8 factored parameters")
@@ -138,9 +139,14 @@ class FusedAdamW:
         self.last_factored_params = [self.params[i] for i, _, _ in fac]     # introspection: which weights the last step updated from factors
 
     @staticmethod
-    def factored_ok(p, T):
+    def factored_ok(p, T, a16: bool = True):
+        """Can a gradient dY[T, N]^T A[T, K] of p stay factored?  T <= 64 always; up to FACTORED_MAX_T_16 = 256 rows when A is in the
+        library's 16-bit type (the MFMA form of the update loops over T; the Gram norm then goes through the library GEMM): the
+        data-parallel chain's W * B * T' gathered rows at eight ranks."""
         N = p.shape[0]
-        return T <= FusedAdamW.FACTORED_MAX_T and (p.numel() // N) % 256 == 0 and N % 16 == 0
+        K = p.numel() // N
+        lim = FusedAdamW.FACTORED_MAX_T_16 if (a16 and K % 64 == 0 and N * K * 4 < 2 ** 31) else FusedAdamW.FACTORED_MAX_T
+        return T <= lim and K % 256 == 0 and N % 16 == 0
 
     def _factored_items(self):
         arr = (L.OptFactored * len(self._factored))()
@@ -187,7 +193,9 @@ class FusedAdamW:
             host.copy_(torch.tensor(ptrs, dtype=torch.int64))
             self._captured_hosts.append(host)
             self._grads_dev.copy_(host, non_blocking=True)
+            grads_dev = self._grads_dev
         else:
+            grads_dev = self._grads_dev
             k = self._ring_pos
             self._ring_pos = (k + 1) % len(self._ring)
             if self._ring_ev[k] is not None:
@@ -200,7 +208,7 @@ class FusedAdamW:
         a = L.OptArgs()
         a.chunk_tensor, a.chunk_off = self._chunk_tensor.data_ptr(), self._chunk_off.data_ptr()
         a.nchunks, a.chunk_elems = self.nchunks, CHUNK
-        a.tensors, a.grads, a.ntensors = self._tensors.data_ptr(), self._grads_dev.data_ptr(), len(self.params)
+        a.tensors, a.grads, a.ntensors = self._tensors.data_ptr(), grads_dev.data_ptr(), len(self.params)
         a.partial, a.state, a.lr = self._partial.data_ptr(), self.state_t.data_ptr(), self._lr.data_ptr()
         a.beta1, a.beta2, a.eps, a.max_grad_norm = self.betas[0], self.betas[1], self.eps, self.max_grad_norm
         a.grad_dt = self.grad_dt
@@ -213,14 +221,38 @@ class FusedAdamW:
         if self._factored:
             items = self._factored_items()
             n = len(self._factored)
-            nb = int(lib.csts_factored_sqnorm_workspace(items, n))
-            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.device)
-            L.check(lib.csts_factored_sqnorm(items, n, self._extra_sq.data_ptr(), ws.data_ptr(), ws.numel(), st), "csts_factored_sqnorm")
+            if max(dy.shape[0] for _, dy, _ in self._factored) <= self.FACTORED_MAX_T:
+                nb = int(lib.csts_factored_sqnorm_workspace(items, n))
+                ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=self.device)
+                L.check(lib.csts_factored_sqnorm(items, n, self._extra_sq.data_ptr(), ws.data_ptr(), ws.numel(), st), "csts_factored_sqnorm")
+            else:
+                self._factored_sqnorm_gemm(st)
             a.extra_sq, a.n_extra_sq = self._extra_sq.data_ptr(), n
         L.check(lib.csts_adamw_step(C.byref(a), st), "csts_adamw_step")
         if items is not None:
             L.check(lib.csts_adamw_factored(items, len(self._factored), self.state_t.data_ptr(), self._lr.data_ptr(), self.betas[0],
                                             self.betas[1], self.eps, st), "csts_adamw_factored")
+
+    def _factored_sqnorm_gemm(self, st):
+        """||dY^T A||_F^2 = sum_{t,t'} (dY dY^T)[t,t'] (A A^T)[t,t'] for more than 64 token rows (the data-parallel chain at W > 2 ranks:
+        T = W * B * T'): both T x T Gram matrices on the matrix cores through the library's own NT GEMM (A A^T: K = 49152 deep, split-K;
+        dY rounded to the 16-bit type first -- the gradient the MFMA update forms is that of the rounded dY), then their inner product
+        with csts_rowdot2 + csts_reduce_rows.  Fixed summation orders: reproducible."""
+        from . import ops
+        lib = L.load()
+        half = L.half_dtype()
+        for j, (i, dy, a) in enumerate(self._factored):
+            T, N = dy.shape
+            K = a.shape[1]
+            g2 = torch.empty(T, T, dtype=torch.float32, device=self.device)
+            ops.gemm(L.GEMM_NT, a, 0, K, a, 0, K, g2, T, T, T, K, compute=L.BF16, split_k=max(1, min(128, K // 512)))
+            dy16 = torch.empty(T, N, dtype=half, device=self.device)
+            L.check(lib.csts_axpby(dy.data_ptr(), L.F32, None, L.F32, dy16.data_ptr(), L.BF16, T * N, 1.0, 0.0, st), "csts_axpby")
+            g1 = torch.empty(T, T, dtype=torch.float32, device=self.device)
+            ops.gemm(L.GEMM_NT, dy16, 0, N, dy16, 0, N, g1, T, T, T, N, compute=L.BF16)
+            r = torch.empty(T, dtype=torch.float32, device=self.device)
+            L.check(lib.csts_rowdot2(g1.data_ptr(), L.F32, g2.data_ptr(), L.F32, r.data_ptr(), T, T, st), "csts_rowdot2")
+            L.check(lib.csts_reduce_rows(r.data_ptr(), self._extra_sq.data_ptr() + 4 * j, T, 1, 1.0, st), "csts_reduce_rows")
 
     @property
     def loss_scale(self):

@@ -32,7 +32,7 @@ enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 
 /* Version of this header's struct layouts and call semantics.  Bumped whenever a struct grows or a field changes meaning
- * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients; 6: csts_copy_token_segments).  csts_abi_version() returns the value the
+ * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients; 6: csts_copy_token_segments, csts_wgrad_grouped8_limited).  csts_abi_version() returns the value the
  * LIBRARY was built with: a caller must compare it with the CSTS_ABI_VERSION it was compiled against and refuse a mismatch
  * (the Python binding does, csts_amd/lib.py::load). */
 #define CSTS_ABI_VERSION 6
@@ -94,6 +94,10 @@ int csts_wgrad_grouped(const csts_wgrad_item* device_items, int nitems, int a_f3
 /* the same items as 192 x 384 tiles on 8-wave workgroups (bf16 dY; M % 192 == 0 and N % 384 == 0 layers): half the operand
  * bytes per FLOP through the L2 -> CU path */
 int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStream_t stream);
+/* the same launch on at most max_wgs workgroups (a multiple of 8 below it, >= 8), each walking several items: the kernel's 144 KB of LDS
+ * take a whole CU, so a launch of max_wgs < 256 workgroups leaves the other CUs to whatever runs beside it (round 5: the grouped weight
+ * gradients of the 384- / 768-channel stages beside the memory-bound end of the backward pass).  max_wgs <= 0: one workgroup per item. */
+int csts_wgrad_grouped8_limited(const csts_wgrad_item* device_items, int nitems, int max_wgs, hipStream_t stream);
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */
@@ -358,7 +362,10 @@ int csts_adamw_step(const csts_opt_args* args, hipStream_t stream);
  * it reads -- call it after csts_adamw_step of the same iteration).  csts_factored_sqnorm gives the squared Frobenius norm of
  * every item's never-materialised gradient for that step's clip norm (csts_opt_args.extra_sq) as
  * sum_{t,t'} (dY dY^T)[t,t'] (A A^T)[t,t'], from T x T Gram matrices.  dy fp32 [T][N]; a [T][K] in a_dt; T <= 64, K % 256 == 0,
- * N % 16 == 0.  workspace: csts_factored_sqnorm_workspace(items) bytes. */
+ * N % 16 == 0.  workspace: csts_factored_sqnorm_workspace(items) bytes.  Round 5: csts_adamw_factored takes T <= 256 when every
+ * item's `a` is in the library's 16-bit type (the MFMA form of the update has no T x K tile in LDS: it loops over T) -- the
+ * data-parallel chain's W * B * T' gathered rows at eight ranks; for T > 64 the caller forms the two Gram matrices with csts_gemm
+ * (A A^T and dY dY^T, split-K) and their inner product with csts_rowdot2 + csts_reduce_rows (csts_amd/optim.py). */
 typedef struct {
   float* p; float* m; float* v; void* w16;
   const float* dy; const void* a; int a_dt;

@@ -551,6 +551,30 @@ def test_backward_is_bitwise_reproducible():
     assert not bad, bad[:10]
 
 
+def test_early_wgrad8_flush_is_bitwise_identical(monkeypatch):
+    """CSTS_WGRAD8_EARLY_WGS: the 192 x 384-class weight gradients launched early, on few workgroups (each walking several items), on
+    the side stream beside the rest of backward give bit-identical gradients: an item's arithmetic does not depend on the grid it is
+    launched in, and the final callback joins the side stream before the gradients are handed to the parameters."""
+    m, cfg = make_model("bf16")
+    batch = T.synthetic_batch(2, 8, 256, 77, DEV)
+    monkeypatch.setattr(ops, "GROUP_WGRADS", "always")
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        T.train_step(cfg, m, batch)
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    g0 = grads()
+    monkeypatch.setattr(ops, "W8_EARLY_WGS", 64)
+    g1 = grads()           # the first pass with the switch on only counts the class's problems
+    assert ops._w8_total[0] > 0
+    g2 = grads()           # this one launches them early
+    bad = [n for n in g0 if not (torch.equal(g0[n], g1[n]) and torch.equal(g0[n], g2[n]))]
+    assert not bad, bad[:10]
+
+
 def test_rccl_single_rank_collective_paths():
     """The N>1 code path (bucketed async all-reduce from autograd hooks, EgoNCE all-gather with grad, fused scalar
     all-reduce) executed for real on RCCL with a 1-rank group: API / stream / thread semantics, not transport."""

@@ -1269,3 +1269,31 @@ def test_token_cat_and_split_equal_torch(dt):
     ((p * gp).sum() + (q * gq).sum()).backward()
     ((x2[:, :Na] * gp).sum() + (x2[:, Na:] * gq).sum()).backward()
     assert torch.equal(x.grad, x2.grad)
+
+
+@pytest.mark.parametrize("T", [96, 256])
+def test_factored_adamw_many_token_rows(T):
+    """The data-parallel chain gathers the fusion-conv factors of W ranks: T = W * B * T' rows, 256 at eight ranks.  With 16-bit operands
+    FusedAdamW keeps the gradient factored up to 256 rows (MFMA form of the update; clip norm from the two T x T Gram matrices through the
+    library GEMM): same update and same norm as clip_grad_norm_ + torch AdamW on the materialised dW; more rows (or fp32 operands beyond
+    64) are refused by factored_ok so that the caller materialises."""
+    from csts_amd.optim import FusedAdamW
+    N, K = 64, 2048
+    pa = [rnd(N, K, seed=3, scale=0.5).requires_grad_(), rnd(300, seed=4, scale=0.5).requires_grad_()]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    fused = FusedAdamW([{"params": pa, "weight_decay": 0.05}], lr=1e-3, eps=1e-8, max_grad_norm=1.0)
+    ref = torch.optim.AdamW([{"params": pb, "weight_decay": 0.05}], lr=1e-3, eps=1e-8)
+    assert FusedAdamW.factored_ok(pa[0], T) and not FusedAdamW.factored_ok(pa[0], 257) and not FusedAdamW.factored_ok(pa[0], T, a16=False)
+    for step, gscale in enumerate([1.0, 1e-3]):                          # clipped, un-clipped
+        dy = rnd(T, N, seed=20 + step, scale=gscale)
+        a = rnd(T, K, seed=30 + step).to(torch.bfloat16)
+        pb[0].grad = dy.bfloat16().float().t() @ a.float()
+        g = rnd(300, seed=40 + step, scale=gscale)
+        pa[0].grad, pa[1].grad, pb[1].grad = None, g.clone(), g.clone()
+        fused.set_factored([(pa[0], dy, a)])
+        norm_ref = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ref.step()
+        fused.step()
+        assert abs(float(fused.grad_norm) - float(norm_ref)) < 1e-4 * float(norm_ref), (step, float(fused.grad_norm), float(norm_ref))
+        for i, (a_, b_) in enumerate(zip(pa, pb)):
+            assert rel_l2(a_.detach(), b_.detach()) < 3e-6, (step, i)
