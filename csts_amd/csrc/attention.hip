@@ -708,7 +708,10 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_fwd_ke
 // V -- read transposed only -- unpadded) and the MFMA slot stream of the backward kernels: 12 slots S = Q K^T (two 32-key
 // units), the online softmax of the tile (it needs the maximum over both units, so it cannot ride on its own block), 12 slots
 // O += P V; the operand of slot g + DEPTH is requested before the MFMA of slot g, across the softmax as well.
-__global__ __launch_bounds__(256, 3) void attn_fwd_fast_kernel(AttnP p) {
+#ifndef CSTS_ATTN_FWD_WAVES
+#define CSTS_ATTN_FWD_WAVES 3     // waves per SIMD attn_fwd_fast_kernel is compiled for (A/B builds: 2, 4)
+#endif
+__global__ __launch_bounds__(256, CSTS_ATTN_FWD_WAVES) void attn_fwd_fast_kernel(AttnP p) {
   constexpr int HD = 96;
   typedef Cfg<HD, false> C;
   constexpr int KBLK = 64, LDK = C::LD_ROW, LDV = C::LD_TR;
@@ -947,7 +950,10 @@ __global__ __launch_bounds__(256, ((HD == 96 && !F32) ? 2 : 1)) void attn_dq_ker
 // pieces on the block after SC(u): dS(0) on SC(1) (one piece per slot), dS(u >= 1) on PV(u - 1) (8 pieces on 6 slots).
 // KT = 2: 64-key tiles, two workgroups per CU.  KT = 4: 128-key tiles, one workgroup per CU (106 KB of LDS).
 template <int KT>
-__global__ __launch_bounds__(256, (KT == 2 ? 2 : 1)) void attn_dq_fast_kernel(AttnP p) {
+#ifndef CSTS_ATTN_DQ_WAVES
+#define CSTS_ATTN_DQ_WAVES 2      // waves per SIMD attn_dq_fast_kernel<2> is compiled for (A/B build: 3)
+#endif
+__global__ __launch_bounds__(256, (KT == 2 ? CSTS_ATTN_DQ_WAVES : 1)) void attn_dq_fast_kernel(AttnP p) {
   constexpr int HD = 96;
   typedef Cfg<HD, false> C;
   constexpr int KBLK = 32 * KT, LD = C::LD_ROW;

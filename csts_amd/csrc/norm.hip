@@ -310,8 +310,14 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const void* __restrict_
   }
 }
 
+#ifndef CSTS_LN_BWD_R
+#define CSTS_LN_BWD_R 1            // rows per lane group and pass of ln_bwd_vec_kernel at C <= 512.  Round 5: 1 instead of 2 (-0.1 ms per step, profiles/r5_stencil_ab.txt)
+#endif
+#ifndef CSTS_LN_BWD_MINW
+#define CSTS_LN_BWD_MINW 1         // minimum waves per SIMD ln_bwd_vec_kernel is compiled for (A/B builds: 6 with R = 1)
+#endif
 template <int GL, int NCH, int R, bool DYF32, bool XF32>
-__global__ __launch_bounds__(512) void ln_bwd_vec_kernel(const void* __restrict__ dy, const void* __restrict__ x,
+__global__ __launch_bounds__(512, CSTS_LN_BWD_MINW) void ln_bwd_vec_kernel(const void* __restrict__ dy, const void* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, void* __restrict__ dx,
                                                          const void* __restrict__ addend, float* __restrict__ ws, int64_t rows,
@@ -575,20 +581,26 @@ static bool ln_vec_ok(int C, std::initializer_list<const void*> ptrs) {
   return true;
 }
 static int ln_group_lanes(int C) { return C <= 128 ? 16 : (C <= 256 ? 32 : 64); }
-static int64_t ln_fwd_vec_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows * ln_group_lanes(C), 256 * 2), 4096); }
+#ifndef CSTS_LN_FWD_R
+#define CSTS_LN_FWD_R 2            // rows per lane group and pass of ln_fwd_vec_kernel at C <= 512 (A/B build: 1)
+#endif
+static int64_t ln_fwd_vec_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows * ln_group_lanes(C), 256 * (C <= 512 ? CSTS_LN_FWD_R : 2)), 4096); }
 static bool ln_bwd_vec(bool df, bool xf, dim3 grid, hipStream_t st, const void* dy, const void* x, const float* g, const float* mean,
                        const float* rstd, void* dx, const void* addend, float* ws, int64_t rows, int C, const float* g1, Copy16 dx16) {
   const size_t sh = (size_t)(512 / ln_group_lanes(C)) * 2 * C * sizeof(float);
   if (sh > 65536) return false;
-  if (C <= 128) ln_bwd_vec_launch<16, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
-  else if (C <= 256) ln_bwd_vec_launch<32, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
-  else if (C <= 512) ln_bwd_vec_launch<64, 1, 2>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  if (C <= 128) ln_bwd_vec_launch<16, 1, CSTS_LN_BWD_R>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (C <= 256) ln_bwd_vec_launch<32, 1, CSTS_LN_BWD_R>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
+  else if (C <= 512) ln_bwd_vec_launch<64, 1, CSTS_LN_BWD_R>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   else ln_bwd_vec_launch<64, 2, 1>(df, xf, grid, sh, st, dy, x, g, mean, rstd, dx, addend, ws, rows, C, g1, dx16);
   return true;
 }
 static int rows_per_wave(int C) { return C <= 192 ? 4 : (C <= 384 ? 2 : 1); }
 static int64_t ln_fwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, 4 * rows_per_wave(C)), 4096); }
-static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, LN_BWD_WAVES * rows_per_wave(C)), 512); }
+#ifndef CSTS_LN_BWD_CAP
+#define CSTS_LN_BWD_CAP 512        // workgroups of a LayerNorm-backward launch (two 512-thread workgroups per CU; A/B builds: 768 with CSTS_LN_BWD_MINW=6)
+#endif
+static int64_t ln_bwd_blocks(int64_t rows, int C) { return std::min<int64_t>(cdiv(rows, LN_BWD_WAVES * rows_per_wave(C)), CSTS_LN_BWD_CAP); }
 
 extern "C" int csts_layernorm_fwd(const void* x, int x_dt, const float* gamma, const float* beta, void* y, int y_dt,
                                   float* mean, float* rstd, int64_t rows, int C, float eps, hipStream_t stream) {
@@ -606,9 +618,9 @@ extern "C" int csts_layernorm_fwd_add(const void* x, const void* addend, void* s
   fa.addend = addend; fa.sum = sum_out;
   if (ln_vec_ok(C, {x, y, gamma, beta, addend, sum_out})) {
     const dim3 vgrid((unsigned)ln_fwd_vec_blocks(rows, C));
-    if (C <= 128) ln_fwd_vec_launch<16, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
-    else if (C <= 256) ln_fwd_vec_launch<32, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
-    else if (C <= 512) ln_fwd_vec_launch<64, 1, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+    if (C <= 128) ln_fwd_vec_launch<16, 1, CSTS_LN_FWD_R>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+    else if (C <= 256) ln_fwd_vec_launch<32, 1, CSTS_LN_FWD_R>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
+    else if (C <= 512) ln_fwd_vec_launch<64, 1, CSTS_LN_FWD_R>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
     else ln_fwd_vec_launch<64, 2, 2>(xf, yf, vgrid, stream, x, gamma, beta, y, mean, rstd, rows, C, eps, fa);
     CSTS_LAUNCH_CHECK();
     return 0;

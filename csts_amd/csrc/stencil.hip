@@ -316,7 +316,8 @@ constexpr bool POOLLN_SPLIT8 = true;
 constexpr bool POOLLN_SPLIT8 = false;
 #endif
 #ifndef POOL_LN_WGS
-#define POOL_LN_WGS 4      // workgroups per CU the register budget is set for (128 VGPRs: the 1024-workgroup launches run in ONE round)
+#define POOL_LN_WGS 3      // workgroups per CU the register budget is set for.  Round 5: 3 (168 registers, ~no spills) instead of 4 (128 registers,
+                           // 8-12 spilled): -0.19 ms per step once the index arithmetic had shrunk (profiles/r5_stencil_ab.txt); 2: -0.14 ms
 #endif
 struct PoolLnSlots {
   const void* fine[2];
