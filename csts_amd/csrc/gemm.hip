@@ -1224,6 +1224,14 @@ bool pick4(const csts_gemm_args* a, int split, int* variant) {
   return false;
 }
 
+// Library heuristic for the streaming thin-operand kernel (gemm5.hip): every problem it can run with at least one 32-row unit per wave of
+// the persistent grid twice over.  CSTS_GEMM5=0 switches it off (A/B runs).
+bool pick5(const csts_gemm_args* a, int split) {
+  static const bool enabled = [] { const char* e = getenv("CSTS_GEMM5"); return !(e && e[0] == '0'); }();
+  if (!enabled || a->algo != 0 || a->tile_rows != 0 || a->M < 16384) return false;
+  return csts_gemm5_ok(a, split);
+}
+
 template <int MT>
 void launch3_mt(const Params& p, int stages, dim3 grid, hipStream_t s) {
   if (stages == 2) hipLaunchKernelGGL((gemm3_kernel<MT, 2>), grid, dim3(256), 0, s, p);
@@ -1392,6 +1400,17 @@ extern "C" int csts_gemm(const csts_gemm_args* a, hipStream_t stream) {
     CSTS_LAUNCH_CHECK();
     return 0;
   }
+  if (a->algo % 1000 == 500 || a->algo % 1000 == 503 || a->algo % 1000 == 506) {   // forced: the streaming thin-operand kernel (gemm5.hip; 503 / 506: 96 / 192 columns per workgroup at K = 192)
+    CSTS_REQUIRE(csts_gemm5_ok(a, split), "algo 500 (streaming thin-operand NT kernel) not applicable to this problem");
+    CSTS_REQUIRE(csts_gemm5_launch(p, a, stream), "gemm5 launch failed");
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
+  if (pick5(a, split)) {
+    CSTS_REQUIRE(csts_gemm5_launch(p, a, stream), "gemm5 launch failed");
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
   {
     int v4;
     if (pick4(a, split, &v4)) {
@@ -1463,6 +1482,12 @@ extern "C" int csts_gemm_plan(const csts_gemm_args* a, int* v2, int* tile_rows, 
     *tile_rows = 0;
     return 0;
   }
+  if (pick5(a, split)) {               // gemm5 (name: csts_gemm_kernel_name)
+    *v2 = 500;
+    *nsplit = 1;
+    *tile_rows = 0;
+    return 0;
+  }
   if (pick4(a, split, &v4)) {          // gemm4 variant v4 (name: csts_gemm_kernel_name)
     *v2 = 400 + v4;
     *nsplit = 1;
@@ -1493,6 +1518,10 @@ extern "C" int csts_gemm_kernel_name(const csts_gemm_args* a, char* buf, int buf
   if (a->algo % 1000 >= 400 && a->algo % 1000 < 500) {
     *nsplit = 1;
     return csts_gemm4_name(q, a->algo % 1000 - 400, buf, buflen) ? 0 : -1;
+  }
+  if (a->algo % 1000 == 500 || a->algo % 1000 == 503 || a->algo % 1000 == 506 || v2 == 500) {
+    *nsplit = 1;
+    return csts_gemm5_name(a, buf, buflen) ? 0 : -1;
   }
   if (v2 < 0) {
     snprintf(buf, buflen, "gemm_tiny_kernel<%d, %s>", a->layout, tf(a->K > 16));

@@ -177,3 +177,8 @@ __device__ __forceinline__ void st4x2_bf16_whole(bf16* base, int64_t at, const f
 // variant = 10 * shape + stages (see gemm4.hip); returns false when the variant does not exist.
 bool csts_gemm4_launch(const csts_gemm_params& p, const csts_gemm_args* a, int variant, int wpc, hipStream_t s);
 bool csts_gemm4_name(const csts_gemm_params& p, int variant, char* buf, int buflen);
+
+// gemm5.hip: streaming NT kernel for the thin problems (K = 96 / 192, N % 96 == 0, large M): weights resident in LDS, one stream per wave.
+bool csts_gemm5_ok(const csts_gemm_args* a, int split);
+bool csts_gemm5_launch(const csts_gemm_params& p, const csts_gemm_args* a, hipStream_t s);
+bool csts_gemm5_name(const csts_gemm_args* a, char* buf, int buflen);

@@ -42,7 +42,7 @@ def half_dtype():
     return torch.float16 if HALF == "fp16" else torch.bfloat16
 
 
-ABI_VERSION = 6   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
+ABI_VERSION = 7   # == CSTS_ABI_VERSION of include/csts_hip.h this binding mirrors (struct layouts below)
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
@@ -167,6 +167,7 @@ SYMBOLS = {
     "csts_wgrad_grouped": (_I, [vp, _I, _I, _I, vp]),
     "csts_wgrad_grouped8": (_I, [vp, _I, vp]),
     "csts_wgrad_grouped8_limited": (_I, [vp, _I, _I, vp]),
+    "csts_wgrad_grouped5": (_I, [vp, _I, vp]),
     "csts_gemm_kernel_name": (_I, [C.POINTER(GemmArgs), C.c_char_p, _I, C.POINTER(_I)]),
     "csts_gemm_plan": (_I, [C.POINTER(GemmArgs), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "csts_layernorm_fwd": (_I, [vp, _I, vp, vp, vp, _I, vp, vp, i64, _I, _F, vp]),

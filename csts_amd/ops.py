@@ -317,6 +317,10 @@ GROUP_WGRADS = {"0": "never", "1": "always"}.get(os.environ.get("CSTS_GROUP_WGRA
 # interleaved pairs.  On by default; CSTS_WGRAD8=0 is the A/B switch.  Token chunk: 8192 (4096 / 2048 measured +0.05 / +0.15 ms).
 WGRAD8 = os.environ.get("CSTS_WGRAD8", "1") != "0"
 WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "8192"))
+# Round 5: the thin layers (output and input features multiples of 96 that the 192 x 384 class does not take; bf16 dY) as 96 x 96 tiles, one
+# (tile, token chunk) item per WAVE of csts_wgrad_grouped5 (wgrad5.hip: every wave its own LDS-DMA stream, no workgroup barrier)
+WGRAD5 = os.environ.get("CSTS_WGRAD5", "1") != "0"
+WGRAD5_CHUNK = int(os.environ.get("CSTS_WGRAD5_CHUNK", "4096"))
 WGRAD_CHUNK = int(os.environ.get("CSTS_WGRAD_CHUNK", "8192"))   # tokens per work item (measured per step: 4096 -> 24.93 ms, 8192 -> 24.95, 16384 -> 25.47)
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 WG_STATS = None         # a list while bench.py instruments a step: (C-ABI entry, algorithmic bytes, flop) per grouped launch
@@ -500,18 +504,21 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
             return (True, 128)
         if WGRAD8 and t[5] % 192 == 0 and t[6] % 384 == 0 and t[4] % 64 == 0 and WGRAD8_CHUNK % 64 == 0:
             return (False, 192)
+        if WGRAD5 and t[5] % 96 == 0 and t[6] % 96 == 0 and t[4] % 16 == 0 and WGRAD5_CHUNK % 16 == 0:
+            return (False, 96)
         return (False, 256 if t[5] % 256 == 0 else 128)
     pend = []           # (item table image, items, tile rows, fp32 dY) per tile class
     # WGRAD8_LAST (with CSTS_STENCIL_TAIL_SIDE=1): the 192 x 384 class -- one 144 KB-LDS workgroup per CU, nothing fits beside it -- goes
     # last, so that the grouped stencil weight gradients on the side stream (vector-bound, 20 KB of LDS, 124 registers) start beside the
     # 128-wide classes (memory-bound, 40 KB of LDS, 154 registers), which they CAN share a CU with
-    order = ((False, 256), (False, 128), (True, 128), (False, 192)) if WGRAD8_LAST else ((False, 192), (False, 256), (False, 128), (True, 128))
+    order = (((False, 96), (False, 256), (False, 128), (True, 128), (False, 192)) if WGRAD8_LAST
+             else ((False, 192), (False, 96), (False, 256), (False, 128), (True, 128)))
     for a_f32, rows in order:
         probs = [t for t in q if tile_class(t) == (a_f32, rows)]
         if not probs:
             continue
-        CH = WGRAD8_CHUNK if rows == 192 else WGRAD_CHUNK
-        tmpl, valid, pidx, chunk, n_items, CHs = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, 384 if rows == 192 else 128, CH)
+        CH = WGRAD8_CHUNK if rows == 192 else (WGRAD5_CHUNK if rows == 96 else WGRAD_CHUNK)
+        tmpl, valid, pidx, chunk, n_items, CHs = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, {192: 384, 96: 96}.get(rows, 128), CH)
         A = np.empty(len(probs), dtype=np.uint64); B = np.empty_like(A); Cb = np.empty_like(A); Cs = np.zeros_like(A)
         cstride = np.zeros(len(probs), dtype=np.uint64); sstride = np.zeros_like(cstride)
         for i, (dY, X, dW, db, tokens, N, K) in enumerate(probs):
@@ -536,7 +543,7 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
         arr["C"][valid] = Cb[pidx] + ch * cstride[pidx]
         arr["colsum"][valid] = Cs[pidx] + ch * sstride[pidx]
         if WG_STATS is not None:      # dY + X read once, dW written once; 2 tokens N K flop
-            WG_STATS.append(("csts_wgrad_grouped8" if rows == 192 else "csts_wgrad_grouped",
+            WG_STATS.append(("csts_wgrad_grouped8" if rows == 192 else ("csts_wgrad_grouped5" if rows == 96 else "csts_wgrad_grouped"),
                              sum(t[4] * t[5] * t[0].element_size() + t[4] * t[6] * 2 + t[5] * t[6] * 4 for t in probs),
                              sum(2.0 * t[4] * t[5] * t[6] for t in probs)))
         pend.append((arr.tobytes(), n_items, rows, a_f32))
@@ -556,6 +563,8 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
                 L.check(_lib().csts_wgrad_grouped8_limited(ptr, n_items, W8_EARLY_WGS, _stream()), "csts_wgrad_grouped8_limited")
             elif rows == 192:
                 L.check(_lib().csts_wgrad_grouped8(ptr, n_items, _stream()), "csts_wgrad_grouped8")
+            elif rows == 96:
+                L.check(_lib().csts_wgrad_grouped5(ptr, n_items, _stream()), "csts_wgrad_grouped5")
             else:
                 L.check(_lib().csts_wgrad_grouped(ptr, n_items, 1 if a_f32 else 0, rows, _stream()), "csts_wgrad_grouped")
     if side:

@@ -32,10 +32,10 @@ enum { CSTS_EPI_NONE = 0, CSTS_EPI_GELU = 1, CSTS_EPI_DGELU = 2 };
 enum { CSTS_MASK_NONE = 0, CSTS_MASK_SPATIAL = 1 };
 
 /* Version of this header's struct layouts and call semantics.  Bumped whenever a struct grows or a field changes meaning
- * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients; 6: csts_copy_token_segments, csts_wgrad_grouped8_limited).  csts_abi_version() returns the value the
+ * (2: csts_gemm_args.res_up; 3: compact k|v rows, 16-bit build, loss scaler in csts_opt_args; 4: csts_opt_args.extra_sq, factored AdamW; 5: grouped stencil weight gradients; 6: csts_copy_token_segments, csts_wgrad_grouped8_limited; 7: csts_wgrad_grouped5, csts_gemm algo 500).  csts_abi_version() returns the value the
  * LIBRARY was built with: a caller must compare it with the CSTS_ABI_VERSION it was compiled against and refuse a mismatch
  * (the Python binding does, csts_amd/lib.py::load). */
-#define CSTS_ABI_VERSION 6
+#define CSTS_ABI_VERSION 7
 const char* csts_last_error(void);
 int csts_abi_version(void);
 int csts_half_kind(void);   /* the 16-bit type behind CSTS_BF16 in THIS library: 0 bfloat16 (libcsts_hip.so), 1 IEEE half (libcsts_hip_f16.so) */
@@ -98,6 +98,10 @@ int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStre
  * take a whole CU, so a launch of max_wgs < 256 workgroups leaves the other CUs to whatever runs beside it (round 5: the grouped weight
  * gradients of the 384- / 768-channel stages beside the memory-bound end of the backward pass).  max_wgs <= 0: one workgroup per item. */
 int csts_wgrad_grouped8_limited(const csts_wgrad_item* device_items, int nitems, int max_wgs, hipStream_t stream);
+/* the thin layers (M % 96 == 0, N % 96 == 0, bf16 dY, token ranges in multiples of 16) as 96 x 96 tiles, one item per WAVE: eight
+ * consecutive slots of one XCD's list per 8-wave workgroup (nitems = 8 x the longest list, position slot * 8 + xcd, padding A == NULL);
+ * every wave streams its token range through a private LDS-DMA ring -- no workgroup barrier (round 5) */
+int csts_wgrad_grouped5(const csts_wgrad_item* device_items, int nitems, hipStream_t stream);
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
  *      on pooled q/k/v (attention.py:108,112,116).  mean/rstd are fp32 [rows]; dgamma,dbeta one [2*C] buffer. */

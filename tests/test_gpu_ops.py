@@ -141,6 +141,63 @@ def test_gemm4_fp32_residual_form(algo, rps):
         assert torch.equal(base, out[:M])
 
 
+@pytest.mark.parametrize("algo", [0, 500])
+@pytest.mark.parametrize("M,N,K", [(16384, 96, 96), (16416, 384, 96), (16384, 192, 96), (20000 // 32 * 32, 96, 192), (16384, 288, 192),
+                                   (16384, 768, 96)])
+def test_gemm5_streaming_thin_kernel(algo, M, N, K):
+    """gemm5 (weights resident in LDS, one LDS-DMA stream per wave, register epilogue on column pairs): every epilogue form it carries
+    -- bias / bias + GELU with the kept pre-activation / x gelu'(aux) / fp32 residual stream with per-sample drop-path scales / plain fp32
+    (reference nn.Linear + GELU + drop-path + residual: attention.py:130,159,238-248; common.py:26-34) -- forced (algo 500) and as the
+    library's own pick for these shapes, against fp32 torch AND bit for bit against the tiled kernel (same arithmetic, same order);
+    one / two / three / eight column tiles, K = 96 and 192, unit counts that do and do not divide over the waves."""
+    dt = torch.bfloat16
+    A, W, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.2).to(dt), rnd(N, seed=3)
+    pre = A.float() @ W.float().t() + b
+
+    def run(alg, **kw):
+        out = torch.full((M + 1, N), 7.0, device=DEV, dtype=kw.pop("odt", dt))
+        ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out, N, M, N, K, compute=L.BF16, algo=alg, **kw)
+        assert (out[M] == 7).all()
+        return out[:M]
+
+    aux = torch.full((M + 1, N), 7.0, device=DEV, dtype=dt)
+    got = run(algo, bias=b, epilogue=L.EPI_GELU, aux=aux)
+    assert rel_l2(aux[:M].float(), pre) < 6e-3 and rel_l2(got.float(), F.gelu(pre)) < 6e-3 and (aux[M] == 7).all()
+    aux2 = torch.empty(M, N, device=DEV, dtype=dt)
+    assert torch.equal(got, run(2, bias=b, epilogue=L.EPI_GELU, aux=aux2)) and torch.equal(aux[:M], aux2)
+    got = run(algo, bias=b, epilogue=L.EPI_GELU)                                  # inference: pre-activation not kept
+    assert rel_l2(got.float(), F.gelu(pre)) < 6e-3
+    got = run(algo)                                                               # no bias, bf16 out
+    assert rel_l2(got.float(), pre - b) < 6e-3 and torch.equal(got, run(2))
+    got = run(algo, bias=b)
+    assert rel_l2(got.float(), pre) < 6e-3 and torch.equal(got, run(2, bias=b))
+    h = rnd(M, N, seed=7).to(dt)                                                  # data gradient through GELU
+    got = run(algo, epilogue=L.EPI_DGELU, aux=h)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).sum().backward()
+    assert rel_l2(got.float(), (pre - b) * hf.grad) < 6e-3 and torch.equal(got, run(2, epilogue=L.EPI_DGELU, aux=h))
+    res = rnd(M, N, seed=4)                                                       # the fp32 residual stream
+    rps = 4096 + 32
+    rs = rnd((M + rps - 1) // rps, seed=5).abs() + 0.5
+    got = run(algo, odt=torch.float32, bias=b, residual=res, ldr=N, row_scale=rs, rows_per_scale=rps)
+    assert rel_l2(got, pre * rs.repeat_interleave(rps)[:M, None] + res) < 1e-4
+    assert torch.equal(got, run(2, odt=torch.float32, bias=b, residual=res, ldr=N, row_scale=rs, rows_per_scale=rps))
+    got = run(algo, odt=torch.float32, residual=res, ldr=N)
+    assert rel_l2(got, pre - b + res) < 1e-4 and torch.equal(got, run(2, odt=torch.float32, residual=res, ldr=N))
+    got = run(algo, odt=torch.float32, bias=b)                                    # plain fp32 output
+    assert rel_l2(got, pre) < 1e-4 and torch.equal(got, run(2, odt=torch.float32, bias=b))
+    if algo == 0:                                                                 # the library does route these shapes to gemm5
+        a = L.GemmArgs()
+        a.layout, a.M, a.N, a.K, a.compute = L.GEMM_NT, M, N, K, L.BF16
+        a.A, a.a_dt, a.lda, a.B, a.b_dt, a.ldb = A.data_ptr(), L.BF16, K, W.data_ptr(), L.BF16, K
+        o = torch.empty(M, N, device=DEV, dtype=dt)
+        a.C, a.c_dt, a.ldc = o.data_ptr(), L.BF16, N
+        import ctypes as C
+        buf, ns = C.create_string_buffer(160), C.c_int(0)
+        assert ops._lib().csts_gemm_kernel_name(C.byref(a), buf, 160, C.byref(ns)) == 0
+        assert buf.value.decode().startswith("gemm5_kernel<"), buf.value
+
+
 @pytest.mark.parametrize("compute", [L.F32, L.BF16])
 def test_linear_and_mlp_autograd(compute):
     dt = tdt(compute)
@@ -582,22 +639,24 @@ def test_losses_against_oracle():
             4 * math.log(4096)).mean())) < 1e-5
 
 
-def test_grouped_weight_gradients_match_inline():
+@pytest.mark.parametrize("M,Cin,Hd,Cout,out16", [(20000, 192, 768, 96, False), (12304, 96, 288, 96, True), (4112, 384, 96, 192, True)])
+def test_grouped_weight_gradients_match_inline(M, Cin, Hd, Cout, out16):
     """Linear / MLP weight and bias gradients through the grouped end-of-backward launch (several token chunks with
-    split-K partial slabs, fp32 and bf16 dY) == the in-line split-K GEMMs == torch, bf16 mode."""
-    M, Cin, Hd, Cout = 20000, 192, 768, 96          # 20000 tokens: 3 chunks of WGRAD_CHUNK
+    split-K partial slabs, fp32 and bf16 dY) == the in-line split-K GEMMs == torch, bf16 mode.  The thin layers (features in multiples
+    of 96, bf16 dY) take csts_wgrad_grouped5 -- 96 x 96 tiles, one item per wave, token counts that are multiples of 16 only, several
+    chunks, the fused bias gradient of the n0 == 0 tiles; the fp32-dY layers and the rest stay on the 128-wide classes."""
     x = rnd(M, Cin, seed=1).bfloat16()
     W1, b1 = rnd(Hd, Cin, seed=2, scale=0.05), rnd(Hd, seed=3, scale=0.1)
     W2, b2 = rnd(Cout, Hd, seed=4, scale=0.05), rnd(Cout, seed=5, scale=0.1)
-    res = rnd(M, Cout, seed=6)
-    dy = rnd(M, Cout, seed=7)
+    res = None if out16 else rnd(M, Cout, seed=6)
+    dy = rnd(M, Cout, seed=7).to(torch.bfloat16 if out16 else torch.float32)
 
     def run(grouped):
         old = ops.GROUP_WGRADS
         ops.GROUP_WGRADS = "always" if grouped else "never"
         try:
             ps = [t.clone().requires_grad_() for t in (W1, b1, W2, b2)]
-            y = ops.mlp(x, ps[0], ps[1], ps[2], ps[3], residual=res, act_dt=L.BF16, out_dt=L.F32, compute=L.BF16)
+            y = ops.mlp(x, ps[0], ps[1], ps[2], ps[3], residual=res, act_dt=L.BF16, out_dt=L.BF16 if out16 else L.F32, compute=L.BF16)
             y.backward(dy)
             torch.cuda.synchronize()
             return [p.grad.clone() for p in ps]
@@ -607,8 +666,8 @@ def test_grouped_weight_gradients_match_inline():
     g_grouped, g_inline = run(True), run(False)
     xr = x.float()
     w = [t.clone().requires_grad_() for t in (W1, b1, W2, b2)]
-    yr = F.linear(F.gelu(F.linear(xr, w[0].bfloat16().float(), w[1])), w[2].bfloat16().float(), w[3]) + res
-    yr.backward(dy)
+    yr = F.linear(F.gelu(F.linear(xr, w[0].bfloat16().float(), w[1])), w[2].bfloat16().float(), w[3])
+    (yr if res is None else yr + res).backward(dy.float())
     for a, b_, r in zip(g_grouped, g_inline, w):
         assert rel_l2(a, b_) < 2e-3
         assert rel_l2(a, r.grad) < 2e-2

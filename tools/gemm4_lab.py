@@ -16,7 +16,7 @@ SHAPES = [(8192, 1536, 384), (8192, 384, 1536), (8192, 1152, 384), (8192, 384, 3
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default=None)
 ap.add_argument("--algos", default="0,402,403,412,422,432,433,434,462,463,442,452")
-ap.add_argument("--epi", default="none", choices=["none", "gelu", "res"])
+ap.add_argument("--epi", default="none", choices=["none", "gelu", "res", "dgelu"])
 ap.add_argument("--rounds", type=int, default=3)
 a = ap.parse_args()
 if a.shapes:
@@ -33,6 +33,8 @@ def run(algo, A, B, Cm, M, N, K, bias, aux, res):
         ops.gemm(L.GEMM_NT, A, 0, K, B, 0, K, Cm, N, M, N, K, compute=L.BF16, bias=bias, epilogue=L.EPI_GELU, aux=aux, algo=algo)
     elif a.epi == "res":
         ops.gemm(L.GEMM_NT, A, 0, K, B, 0, K, Cm, N, M, N, K, compute=L.BF16, bias=bias, residual=res, ldr=N, algo=algo)
+    elif a.epi == "dgelu":        # the data gradient through GELU: x gelu'(saved pre-activation), no bias (aux is READ here)
+        ops.gemm(L.GEMM_NT, A, 0, K, B, 0, K, Cm, N, M, N, K, compute=L.BF16, epilogue=L.EPI_DGELU, aux=aux, algo=algo)
     else:
         ops.gemm(L.GEMM_NT, A, 0, K, B, 0, K, Cm, N, M, N, K, compute=L.BF16, bias=bias, algo=algo)
 
@@ -44,22 +46,26 @@ for (M, N, K) in SHAPES:
              torch.empty(M, N, device=dev, dtype=cdt)) for _ in range(NSET)]
     bias = torch.randn(N, device=dev)
     bias16 = bias.bfloat16()
-    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if a.epi == "gelu" else None
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if a.epi == "gelu" else (torch.randn(M, N, device=dev).bfloat16() if a.epi == "dgelu" else None)
     res = torch.randn(M, N, device=dev) if a.epi == "res" else None
     A, B, Cm = sets[0]
     rows = torch.cat([torch.randint(0, M, (192,), device=dev), torch.arange(M - 64, M, device=dev)])
     pre = A[rows].float() @ B.float().t() + bias
     ref = F.gelu(pre) if a.epi == "gelu" else (pre + res[rows] if a.epi == "res" else pre)
+    if a.epi == "dgelu":
+        hh = aux[rows].float().requires_grad_(True)
+        F.gelu(hh).sum().backward()
+        ref = (pre - bias) * hh.grad
     errs = []
     for al in ALGOS:
         Cm.zero_()
-        if aux is not None:
+        if aux is not None and a.epi == "gelu":
             aux.zero_()
         try:
             run(al, A, B, Cm, M, N, K, bias, aux, res)
             torch.cuda.synchronize()
             e = ((Cm[rows].float() - ref).norm() / ref.norm()).item()
-            if aux is not None:
+            if aux is not None and a.epi == "gelu":
                 e = max(e, ((aux[rows].float() - pre).norm() / pre.norm()).item())
         except L.CstsError as ex:
             e = float("nan")

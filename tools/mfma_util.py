@@ -99,6 +99,7 @@ def main():
            ("attention backward", r"^attn_(dq|dkv|bwd_fused)", ["attn_bwd"]),
            ("grouped weight gradients 192x384", r"^wgrad8", ["wgrad_grouped8"]),
            ("grouped weight gradients 128/256x128", r"^wgrad_grouped", ["wgrad_grouped"]),
+           ("grouped weight gradients 96x96 per wave", r"^wgrad5", ["wgrad_grouped5"]),
            ("clip + AdamW", r"^(opt_|factored_)", ["adamw_step", "adamw_factored", "factored_sqnorm"]),
            ("max-pool skip", r"^maxpool", ["maxpool_fwd", "maxpool_bwd"]),
            ("trilinear", r"^trilinear", ["trilinear_fwd", "trilinear_bwd"]),
