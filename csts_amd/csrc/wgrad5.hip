@@ -50,8 +50,12 @@ __global__ __launch_bounds__(64 * W5_W, 2) void wgrad5_kernel(const csts_wgrad_i
   const csts_wgrad_item it = items[idx];
   if (it.A == nullptr) return;                                // padding slot
   char* const ring = smem + wave * (S * W5_STAGE);
+  // token stages of this item: kbeg, kbeg + 16 step, ... < kend (whole stages: host-checked).  it.M = step > 1: the items of one tile INTERLEAVE
+  // their stages (item c of nch: stages c, c + nch, ...), so that the waves working on a layer read one moving window of its rows
   const int64_t kbeg = it.kbeg;
-  const int nk = (int)((it.kend - kbeg) / W5_TOK);            // whole stages only (host-checked: token ranges are multiples of 16)
+  const int step = it.M > 1 ? it.M : 1;
+  const int64_t hop = (int64_t)step * W5_TOK;
+  const int nk = (int)((it.kend - kbeg + hop - 1) / hop);
 
   // producer: the three 1-KiB pieces of each operand's 16 x 192 B image (LDS slot s = 64 i + lane: token row s / 12, 16-byte chunk s % 12)
   unsigned aoff[3], boff[3];
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(64 * W5_W, 2) void wgrad5_kernel(const csts_wgrad_i
 
 #pragma unroll
   for (int s2 = 0; s2 < S - 1; ++s2)
-    if (s2 < nk) issue(ring + s2 * W5_STAGE, kbeg + (int64_t)s2 * W5_TOK);
+    if (s2 < nk) issue(ring + s2 * W5_STAGE, kbeg + (int64_t)s2 * hop);
   int cs = 0, ps = S - 1;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed once at most the (S - 2) younger stages (6 wave instructions each) are outstanding
@@ -99,9 +103,16 @@ __global__ __launch_bounds__(64 * W5_W, 2) void wgrad5_kernel(const csts_wgrad_i
     const char* As = ring + cs * W5_STAGE;
     const char* Bs = As + W5_HALF;
     // the stage refilled next was consumed one iteration ago (its fragment reads have returned: their MFMAs have issued)
-    if (kt + S - 1 < nk) issue(ring + ps * W5_STAGE, kbeg + (int64_t)(kt + S - 1) * W5_TOK);
+#ifdef CSTS_W5_DIAG_NODMA      // diagnostics builds (tools/scripts/build_variant.sh): only the first refill is issued
+    if (kt + S - 1 < nk && kt < 1) issue(ring + ps * W5_STAGE, kbeg + (int64_t)(kt + S - 1) * hop);
+#else
+    if (kt + S - 1 < nk) issue(ring + ps * W5_STAGE, kbeg + (int64_t)(kt + S - 1) * hop);
+#endif
     cs = (cs + 1 == S) ? 0 : cs + 1;
     ps = (ps + 1 == S) ? 0 : ps + 1;
+#ifdef CSTS_W5_DIAG_NOMATH     // diagnostics builds: the stream without fragment reads and MFMAs
+    if (kt >= 0) continue;
+#endif
     if (do_colsum && lane < 48) {
 #pragma unroll
       for (int kk = 0; kk < W5_TOK; ++kk) {

@@ -319,8 +319,14 @@ WGRAD8 = os.environ.get("CSTS_WGRAD8", "1") != "0"
 WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "8192"))
 # Round 5: the thin layers (output and input features multiples of 96 that the 192 x 384 class does not take; bf16 dY) as 96 x 96 tiles, one
 # (tile, token chunk) item per WAVE of csts_wgrad_grouped5 (wgrad5.hip: every wave its own LDS-DMA stream, no workgroup barrier)
+WG_DUMP = os.environ.get("CSTS_WGRAD_DUMP", "")
 WGRAD5 = os.environ.get("CSTS_WGRAD5", "1") != "0"
 WGRAD5_CHUNK = int(os.environ.get("CSTS_WGRAD5_CHUNK", "4096"))
+WGRAD5_STRIDED = os.environ.get("CSTS_WGRAD5_STRIDED", "1") != "0"
+WGRAD5_MIN = int(os.environ.get("CSTS_WGRAD5_MIN", "96"))          # layers with min(N, K) below this stay on the 128-wide classes
+# first: beside the stencil weight gradients; mid (default): after the 128-wide classes -- the stencil launch then starts beside the fp32-dY class
+# and the remaining 128-wide items (wgrad5 and the stencil kernel side by side take the SUM of their times: profiles/r5_wgrad5.txt)
+WGRAD5_POS = os.environ.get("CSTS_WGRAD5_POS", "mid")
 WGRAD_CHUNK = int(os.environ.get("CSTS_WGRAD_CHUNK", "8192"))   # tokens per work item (measured per step: 4096 -> 24.93 ms, 8192 -> 24.95, 16384 -> 25.47)
 _wgq = []               # (dY, X, dW, db, tokens, N_out, K_in)
 WG_STATS = None         # a list while bench.py instruments a step: (C-ABI entry, algorithmic bytes, flop) per grouped launch
@@ -396,7 +402,7 @@ def _wg_dtype():
     return _WG_DTYPE
 
 
-def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
+def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None, strided=False):
     """Work-item layout of one grouped launch for the problem list `sig` = ((tokens, N, K), ...): everything except the
     device addresses, which change from step to step.  Cached: building ~7000 items in Python costs ~15 ms.
 
@@ -406,7 +412,7 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
     on different XCDs).  Padding slots keep A == NULL (the kernel skips them)."""
     import numpy as np
     CH = chunk_tokens or WGRAD_CHUNK
-    plan = _wg_plans.get((sig, rows, cols, CH))
+    plan = _wg_plans.get((sig, rows, cols, CH, strided))
     if plan is not None:
         return plan
     # (Cutting the layers with the fewest tiles into half-length chunks, so that the 192 x 384 class's 310 full-length items
@@ -419,10 +425,17 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
         nch = -(-tokens // CHp)
         for c in range(nch):
             kb, ke = c * CHp, min(tokens, (c + 1) * CHp)
+            if strided:
+                # csts_wgrad_grouped5: the nch items of a tile INTERLEAVE 16-token stages (item c takes stages c, c + nch, ...: kbeg = its
+                # first stage, kend = the layer's tokens, M = the stage stride) -- the waves that work on one layer then read ONE moving
+                # window of its token rows instead of nch distant ranges (2048 wave streams of 3 KB bursts: 3.0 TB/s, tools/wgrad5_bench.py)
+                nst = -(-tokens // 16)
+                groups.append([(16 * len(range(c, nst, nch)), pi, c, 16 * c, tokens, m0, n0, nch) for m0 in range(0, N, rows) for n0 in range(0, K, cols)])
+                continue
             # one group = ALL tiles of this (layer, token chunk): they run together on one XCD and stream the same
             # token range in near lockstep, so its L2 serves every dY / X panel slice to all the tiles that share it
             # (grouping by tile-row only reused the dY panel: rocprofv3 still counted 18.6 GB per launch)
-            groups.append([(ke - kb, pi, c, kb, ke, m0, n0) for m0 in range(0, N, rows) for n0 in range(0, K, cols)])
+            groups.append([(ke - kb, pi, c, kb, ke, m0, n0, 0) for m0 in range(0, N, rows) for n0 in range(0, K, cols)])
     # two levels of longest-first: groups go to the least-loaded XCD in order of their total work; inside an XCD's list the
     # groups with the longest ITEMS start first (a 8192-token item runs 4 x as long as a 2048-token one: started last it
     # is the tail of the launch, with most CUs idle -- 1448 -> 1317 us for the 192 x 384 class of the b=4 step)
@@ -444,13 +457,13 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None):
     pidx = np.full(n_items, -1, dtype=np.int64)
     chunk = np.zeros(n_items, dtype=np.int64)
     for x in range(8):
-        for slot, (_, pi, c, kb, ke, m0, n0) in enumerate(lists[x]):
+        for slot, (_, pi, c, kb, ke, m0, n0, stride) in enumerate(lists[x]):
             i = slot * 8 + x
             tokens, N, K = sig[pi]
-            tmpl[i] = (0, 0, 0, 0, N, K, K, kb, ke, N, K, m0, n0)
+            tmpl[i] = (0, 0, 0, 0, N, K, K, kb, ke, stride if rows == 96 else N, K, m0, n0)     # 96 x 96 per-wave class: M carries the stage step
             pidx[i], chunk[i] = pi, c
     valid = pidx >= 0
-    plan = _wg_plans[(sig, rows, cols, CH)] = (tmpl, valid, pidx[valid], chunk[valid], n_items, CHs)
+    plan = _wg_plans[(sig, rows, cols, CH, strided)] = (tmpl, valid, pidx[valid], chunk[valid], n_items, CHs)
     return plan
 
 
@@ -472,6 +485,10 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
         q = list(_wgq)
         _wgq.clear()
         _wg_work[0] = 0.0
+    if WG_DUMP and not os.path.exists(WG_DUMP):      # diagnostics: the problem list of one flush, for tools/wgrad5_bench.py
+        with open(WG_DUMP, "w") as f:
+            for t in q:
+                f.write(f"{'f32' if t[0].dtype == torch.float32 else 'h16'} {t[4]} {t[5]} {t[6]} {t[0].stride(0)} {t[1].stride(0)} {int(t[3] is not None)}\n")
     dev = q[0][0].device
     key = (dev.index, side)
     tab = _wg_tables.get(key)
@@ -504,7 +521,7 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
             return (True, 128)
         if WGRAD8 and t[5] % 192 == 0 and t[6] % 384 == 0 and t[4] % 64 == 0 and WGRAD8_CHUNK % 64 == 0:
             return (False, 192)
-        if WGRAD5 and t[5] % 96 == 0 and t[6] % 96 == 0 and t[4] % 16 == 0 and WGRAD5_CHUNK % 16 == 0:
+        if WGRAD5 and t[5] % 96 == 0 and t[6] % 96 == 0 and t[4] % 16 == 0 and WGRAD5_CHUNK % 16 == 0 and min(t[5], t[6]) >= WGRAD5_MIN:
             return (False, 96)
         return (False, 256 if t[5] % 256 == 0 else 128)
     pend = []           # (item table image, items, tile rows, fp32 dY) per tile class
@@ -513,12 +530,14 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
     # 128-wide classes (memory-bound, 40 KB of LDS, 154 registers), which they CAN share a CU with
     order = (((False, 96), (False, 256), (False, 128), (True, 128), (False, 192)) if WGRAD8_LAST
              else ((False, 192), (False, 96), (False, 256), (False, 128), (True, 128)))
+    if WGRAD8_LAST and WGRAD5_POS == "mid":
+        order = ((False, 256), (False, 128), (True, 128), (False, 96), (False, 192))
     for a_f32, rows in order:
         probs = [t for t in q if tile_class(t) == (a_f32, rows)]
         if not probs:
             continue
         CH = WGRAD8_CHUNK if rows == 192 else (WGRAD5_CHUNK if rows == 96 else WGRAD_CHUNK)
-        tmpl, valid, pidx, chunk, n_items, CHs = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, {192: 384, 96: 96}.get(rows, 128), CH)
+        tmpl, valid, pidx, chunk, n_items, CHs = _wg_plan(tuple((t[4], t[5], t[6]) for t in probs), rows, {192: 384, 96: 96}.get(rows, 128), CH, strided=(rows == 96 and WGRAD5_STRIDED))
         A = np.empty(len(probs), dtype=np.uint64); B = np.empty_like(A); Cb = np.empty_like(A); Cs = np.zeros_like(A)
         cstride = np.zeros(len(probs), dtype=np.uint64); sstride = np.zeros_like(cstride)
         for i, (dY, X, dW, db, tokens, N, K) in enumerate(probs):

@@ -100,7 +100,8 @@ int csts_wgrad_grouped8(const csts_wgrad_item* device_items, int nitems, hipStre
 int csts_wgrad_grouped8_limited(const csts_wgrad_item* device_items, int nitems, int max_wgs, hipStream_t stream);
 /* the thin layers (M % 96 == 0, N % 96 == 0, bf16 dY, token ranges in multiples of 16) as 96 x 96 tiles, one item per WAVE: eight
  * consecutive slots of one XCD's list per 8-wave workgroup (nitems = 8 x the longest list, position slot * 8 + xcd, padding A == NULL);
- * every wave streams its token range through a private LDS-DMA ring -- no workgroup barrier (round 5) */
+ * every wave streams its token range through a private LDS-DMA ring -- no workgroup barrier (round 5).  Item fields as above except
+ * M: the STAGE STEP -- M > 1: the item takes the 16-token stages kbeg, kbeg + 16 M, ... < kend (the M items of a tile interleave) */
 int csts_wgrad_grouped5(const csts_wgrad_item* device_items, int nitems, hipStream_t stream);
 
 /* ---- LayerNorm: nn.LayerNorm(C, eps=1e-6) block norms (attention.py:192,214) and nn.LayerNorm(hd, eps=1e-5)
