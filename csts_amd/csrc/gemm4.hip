@@ -492,13 +492,14 @@ bool launch4(Params p, int wpc, hipStream_t s) {
 struct Variant { int code, wm, mt, nt, s; };
 // shape ids: 0 = 256x128, 1 = 256x192, 2 = 256x256 (8 waves, wave tile 64 x 64/96/128);
 //            3 = 128x128, 6 = 128x192, 4 = 128x256 (8 waves, wave tile 32 x 64/96/128); 5 = 128x128 on 4 waves (wave tile 64 x 64);
+//            7 = 64x192 on 4 waves (wave tile 32 x 96; round 5: M = 8192 problems with 128 or fewer 128 x 192 tiles -- half the CUs idle);
 // (4-wave workgroups with 64 x 96 / 64 x 128 / 128 x 64 wave tiles -- fewer LDS fragment bytes per MFMA -- measured 10-90 %
 //  slower than the 8-wave 128 x 192 variant on every CSTS shape and were removed: profiles/r2_gemm4_lab2.txt)
 // last column: the specialised epilogue forms exist (the variants the library picks by itself)
 #define G4_VARIANTS(X) \
   X(2, 4, 2, 2, 2, false) X(3, 4, 2, 2, 3, false) X(12, 4, 2, 3, 2, false) X(22, 4, 2, 4, 2, false) \
   X(32, 4, 1, 2, 2, true) X(33, 4, 1, 2, 3, true) X(34, 4, 1, 2, 4, true) X(62, 4, 1, 3, 2, true) X(63, 4, 1, 3, 3, true) X(64, 4, 1, 3, 4, true) X(42, 4, 1, 4, 2, false) \
-  X(52, 2, 2, 2, 2, false)
+  X(52, 2, 2, 2, 2, false) X(72, 2, 1, 3, 2, true) X(73, 2, 1, 3, 3, true) X(74, 2, 1, 3, 4, true)
 
 }  // namespace
 

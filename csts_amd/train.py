@@ -121,6 +121,15 @@ def scaler_of(optimizer):
     return LossScaler(optimizer) if getattr(optimizer, "loss_scale", None) is not None else None
 
 
+def _dcopy(dst, src):
+    """dst <- src, both contiguous and of one dtype: one library launch on the GPU (csts_axpby), torch elsewhere"""
+    if dst.is_cuda and dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.dtype in (torch.float32, torch.bfloat16, torch.float16):
+        from . import ops
+        ops.cast_into(dst, src)
+    else:
+        dst.copy_(src)
+
+
 def backward_scaled(loss, optimizer):
     """scaler.scale(loss).backward() (train_avgaze_net.py:99) -- plain loss.backward() without loss scaling."""
     sc = getattr(optimizer, "loss_scale", None) if optimizer is not None else None
@@ -546,6 +555,71 @@ class SegmentedTrainStep:
             buf.copy_(leaf.grad)
         return loss.detach(), kld.detach(), (nce.detach() if nce is not None else None)
 
+    # ------------------------------------------------------------------ the loss section as a graph (round 5)
+    def _loss_graphable(self):
+        return (self.use_graphs and self.loss_fn is None and self.cfg.MODEL.LOSS_FUNC == "kldiv+egonce" and len(self.outs) == 3
+                and os.environ.get("CSTS_LOSS_GRAPH", "1") != "0")
+
+    def _loss_gather(self, coll):
+        """The EgoNCE embeddings of all ranks into the static buffers the loss graph reads (train_avgaze_net.py:82-83); without
+        collectives (one process, or the capture pass) the local rows stand in for every rank's."""
+        import torch.distributed as dist
+        _, v_emb, a_emb = self.outs
+        if coll and dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self._gv, v_emb.contiguous())
+            dist.all_gather_into_tensor(self._ga, a_emb.contiguous())
+        elif coll:                                   # gloo (tests): the list form over views
+            world = dist.get_world_size()
+            dist.all_gather(list(self._gv.chunk(world)), v_emb.contiguous())
+            dist.all_gather(list(self._ga.chunk(world)), a_emb.contiguous())
+        else:
+            B = v_emb.shape[0]
+            for r in range(self._gv.shape[0] // B):     # (library copies: a torch copy_ between two device buffers costs the host ~100 us here)
+                _dcopy(self._gv[r * B:(r + 1) * B], v_emb)
+                _dcopy(self._ga[r * B:(r + 1) * B], a_emb)
+
+    def _loss_scatter(self, coll):
+        """distributed._AllGatherWithGrad.backward on the loss graph's static gradients: sum over ranks, this rank's rows."""
+        import torch.distributed as dist
+        if coll:
+            dist.all_reduce(self._dgv)
+            dist.all_reduce(self._dga)
+        B = self.douts[1].shape[0]
+        r = dist.get_rank() if self.dist else 0
+        _dcopy(self.douts[1], self._dgv[r * B:(r + 1) * B])
+        _dcopy(self.douts[2], self._dga[r * B:(r + 1) * B])
+
+    def _loss_body(self):
+        """frame_softmax + KLDiv + LOSS_ALPHA * EgoNCE on static buffers and the backward of just that, into static gradient buffers: the
+        arithmetic of _loss_eager (same ops, same order) with the all-gather and its backward all-reduce taken OUT -- they are issued
+        eagerly around this graph.  ~20 small launches: issued eagerly they left ~0.5 ms of host-bound gaps per step on the device
+        (tools/gap_report.py on bench.py --rehearse-dist, round 5)."""
+        cfg = self.cfg
+        logits = self.outs[0].detach().requires_grad_(True)
+        gv, ga = self._gv.detach().requires_grad_(True), self._ga.detach().requires_grad_(True)
+        preds = losses.frame_softmax(logits, temperature=2)
+        kld = losses.KLDiv()(preds, self.static["labels_hm"])
+        nce = losses.EgoNCE()(losses.sim_matrix(gv, ga))
+        loss = kld + cfg.MODEL.LOSS_ALPHA * nce
+        backward_scaled(loss, self.opt)
+        self.douts[0].copy_(logits.grad)
+        self._dgv.copy_(gv.grad)
+        self._dga.copy_(ga.grad)
+        return loss.detach(), kld.detach(), nce.detach()
+
+    def _loss_graphed(self, capture, coll):
+        import torch.distributed as dist
+        if capture or not hasattr(self, "_gv"):
+            world = dist.get_world_size() if self.dist else 1
+            _, v_emb, a_emb = self.outs
+            self._gv = torch.zeros(world * v_emb.shape[0], *v_emb.shape[1:], dtype=v_emb.dtype, device=v_emb.device)
+            self._ga = torch.zeros(world * a_emb.shape[0], *a_emb.shape[1:], dtype=a_emb.dtype, device=a_emb.device)
+            self._dgv, self._dga = torch.zeros_like(self._gv), torch.zeros_like(self._ga)
+        self._loss_gather(coll)
+        res = self._segment("loss", self._loss_body, capture)
+        self._loss_scatter(coll)
+        return res
+
     def step_eager(self, batch=None, lr: Optional[float] = None):
         """One iteration of the chain without graphs (use_graphs=False)."""
         if batch is not None:
@@ -617,8 +691,11 @@ class SegmentedTrainStep:
         # (hipEventQuery), then has nothing to poll while a capture is open (two different HIP capture errors came out of
         # that thread otherwise, taking the process down).  Every rank takes the same branch.
         coll = self.dist and not capture
-        with (du.local_only() if (self.dist and capture) else contextlib.nullcontext()):
-            res = self._loss_eager()
+        if self._loss_graphable():
+            res = self._loss_graphed(capture, coll)
+        else:
+            with (du.local_only() if (self.dist and capture) else contextlib.nullcontext()):
+                res = self._loss_eager()
         if capture:
             self.result = res
 
@@ -790,11 +867,22 @@ class SegmentedTrainStep:
         if hasattr(self.core, "_refresh_w16"):
             self.core._refresh_w16()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if timed else None
-        mark = (lambda i: ev[i].record()) if timed else (lambda i: None)
+        host = [] if os.environ.get("CSTS_CHAIN_HOST_TIMES") else None          # diagnostics: host time of every stage of this call (us)
+        def mark(i):
+            if timed:
+                ev[i].record()
+            if host is not None:
+                host.append(time.perf_counter())
         mark(0)
         self.graphs["fwd"].replay()
         mark(1)
-        res = self._loss_eager()
+        if "loss" in self.graphs:
+            self._loss_gather(self.dist)
+            self.graphs["loss"].replay()
+            self._loss_scatter(self.dist)
+            res = self.result
+        else:
+            res = self._loss_eager()
         mark(2)
         self.graphs["bwd_head"].replay()
         works = [self._all_reduce(0)] if self.dist else []
@@ -816,6 +904,8 @@ class SegmentedTrainStep:
         mark(5)
         if timed:
             self.events = ev
+        if host is not None:
+            self.host_us = [round((b - a) * 1e6) for a, b in zip(host, host[1:])]     # fwd launch | loss section | head launch + collectives | trunk launches + waits + factor finish | opt launch
         return res
 
     def segment_ms(self):

@@ -49,7 +49,7 @@ def main():
     assert opt.max_grad_norm == 1.0                   # the YAML's clip; the kernels read the gradients, they never scale them in place
     step = T.SegmentedTrainStep(cfg, model, opt, batch, warmup=1)
     assert step.dist and step.use_graphs and step.trunk_cut == trunk_cut and not model.hooks_enabled
-    assert set(step.graphs) == {"fwd", "bwd_head", "bwd_trunk", "opt"} | ({"bwd_trunk_early"} if trunk_cut else set())
+    assert set(step.graphs) == {"fwd", "loss", "bwd_head", "bwd_trunk", "opt"} | ({"bwd_trunk_early"} if trunk_cut else set())
 
     # ---- step A: gradients as the optimizer sees them
     loss, kld, nce = step.run(batch, lr=0.0)
