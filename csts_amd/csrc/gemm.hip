@@ -1197,12 +1197,27 @@ bool pick4(const csts_gemm_args* a, int split, int* variant) {
     static const bool res_on = [] { const char* e = getenv("CSTS_GEMM4_RES"); return !(e && e[0] == '0'); }();
     if (!res_on || a->r_dt != CSTS_F32 || a->res_row_mod != 0 || a->epilogue != CSTS_EPI_NONE || a->M % 128 != 0) return false;
     // (narrow outputs -- N = 96 on 128 x 128 tiles with the last 32-column block masked, algo 433 -- measured 0.99 x gemm2 inside the step: not routed)
+    // Round 5: 64 x 192 tiles on 4-wave workgroups (variant 73) where the problem has at most 128 tiles of 128 x 192 -- half the CUs, or
+    // more, idle otherwise (M = 8192 / 2048 rows of the 384- / 768-channel stages: isolated 1.1 - 1.17 x, tools/gemm4_lab.py --shapes
+    // tools/shapes_m8192.txt).  CSTS_GEMM4_T64=0 is the A/B switch.
+    static const bool t64 = [] { const char* e = getenv("CSTS_GEMM4_T64"); return e && (e[0] == '1' || e[0] == '3'); }();
+    if (t64 && a->N % 192 == 0 && a->M % 64 == 0 && a->K >= 384 && (a->M / 128) * (a->N / 192) <= 128 && (a->M / 64) * (a->N / 192) >= 64) {
+      *variant = 73;
+      return true;
+    }
     if (a->N % 192 != 0 || (a->M / 128) * (a->N / 192) < 128) return false;
     *variant = 63;        // the 3-stage ring at one workgroup per CU: FORM 5 needs more than the 128 registers of the two-workgroup variants (62: 1.6 x slower)
     return true;
   }
   if (a->c_dt != CSTS_BF16 || a->residual != nullptr) return false;
   const int64_t rows = cdiv(a->M, 128);
+  {   // the same 64 x 192 form for the bf16 outputs of those problems (whole tiles only: the specialised epilogues)
+    static const bool t64b = [] { const char* e = getenv("CSTS_GEMM4_T64"); return e && (e[0] == '2' || e[0] == '3'); }();
+    if (t64b && a->N % 192 == 0 && a->M % 64 == 0 && a->K >= 384 && rows * (a->N / 192) <= 128 && (a->M / 64) * (a->N / 192) >= 64 && a->row_scale == nullptr) {
+      *variant = 73;
+      return true;
+    }
+  }
   if (a->N % 192 == 0 && rows * (a->N / 192) >= 256) {
     *variant = (a->K >= 1536 && rows * (a->N / 192) <= 256) ? 63 : 62;
     // short K, many row tiles, whole tiles: the wave-specialised form (4 producer waves; gemm4.hip) -- OFF by default:

@@ -112,7 +112,7 @@ def test_gemm_nt_persistent_kernel(algo, M, N, K):
     assert rel_l2(out32[:M], (pre - b) * hf.grad) < 1e-3
 
 
-@pytest.mark.parametrize("algo", [0, 462, 463])
+@pytest.mark.parametrize("algo", [0, 462, 463, 473])
 @pytest.mark.parametrize("rps", [512, 100])
 def test_gemm4_fp32_residual_form(algo, rps):
     """gemm4 FORM 5 (fp32 C = (A W^T + bias) * drop-path scale + fp32 residual on unswapped MFMA operands: attention.py:238-248 proj / fc2
@@ -139,6 +139,37 @@ def test_gemm4_fp32_residual_form(algo, rps):
         base = torch.empty(M, N, device=DEV)
         ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, base, N, M, N, K, compute=L.BF16, bias=b, residual=res, ldr=N, row_scale=rs, rows_per_scale=rps, algo=2)
         assert torch.equal(base, out[:M])
+
+
+@pytest.mark.parametrize("algo", [0, 472, 473, 474])
+def test_gemm4_64_row_tiles(algo):
+    """gemm4 on 64 x 192 tiles / 4-wave workgroups (round 5: the M = 8192 / 2048 problems of the 384- / 768-channel stages, which have at most
+    128 tiles of 128 x 192): every specialised epilogue form (bias, bias + GELU with the kept pre-activation, plain, x gelu') forced
+    and as the library's own pick for this shape, against fp32 torch and bit for bit against the register-staged kernel."""
+    M, N, K = 2048, 768, 768
+    dt = torch.bfloat16
+    A, W, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.1).to(dt), rnd(N, seed=3)
+    pre = A.float() @ W.float().t() + b
+
+    def run(alg, **kw):
+        out = torch.full((M + 1, N), 7.0, device=DEV, dtype=dt)
+        ops.gemm(L.GEMM_NT, A, 0, K, W, 0, K, out, N, M, N, K, compute=L.BF16, algo=alg, **kw)
+        assert (out[M] == 7).all()
+        return out[:M]
+
+    aux, aux2 = torch.empty(M, N, device=DEV, dtype=dt), torch.empty(M, N, device=DEV, dtype=dt)
+    got = run(algo, bias=b, epilogue=L.EPI_GELU, aux=aux)
+    assert rel_l2(aux.float(), pre) < 6e-3 and rel_l2(got.float(), F.gelu(pre)) < 6e-3
+    assert torch.equal(got, run(2, bias=b, epilogue=L.EPI_GELU, aux=aux2)) and torch.equal(aux, aux2)
+    got = run(algo, bias=b)
+    assert rel_l2(got.float(), pre) < 6e-3 and torch.equal(got, run(2, bias=b))
+    got = run(algo)
+    assert rel_l2(got.float(), pre - b) < 6e-3 and torch.equal(got, run(2))
+    h = rnd(M, N, seed=7).to(dt)
+    got = run(algo, epilogue=L.EPI_DGELU, aux=h)
+    hf = h.float().requires_grad_(True)
+    F.gelu(hf).sum().backward()
+    assert rel_l2(got.float(), (pre - b) * hf.grad) < 6e-3 and torch.equal(got, run(2, epilogue=L.EPI_DGELU, aux=h))
 
 
 @pytest.mark.parametrize("algo", [0, 500])
