@@ -1244,6 +1244,10 @@ bool pick4(const csts_gemm_args* a, int split, int* variant) {
 bool pick5(const csts_gemm_args* a, int split) {
   static const bool enabled = [] { const char* e = getenv("CSTS_GEMM5"); return !(e && e[0] == '0'); }();
   if (!enabled || a->algo != 0 || a->tile_rows != 0 || a->M < 16384) return false;
+  // the four-chunk ring (K = 384, N <= 384; six waves beside 75 KB of weights): isolated 1.06 - 1.13 x on the bf16 forms, 0.9 - 1.0 x on the fp32
+  // residual form; inside the step 20.21 -> 20.24 ms (gpurun_out/r5ak): OFF, CSTS_GEMM5_K384=1 or algo 500 opts in
+  static const bool k384 = [] { const char* e = getenv("CSTS_GEMM5_K384"); return e && e[0] == '1'; }();
+  if (a->K == 384 && !k384) return false;
   return csts_gemm5_ok(a, split);
 }
 

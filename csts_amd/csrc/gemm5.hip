@@ -49,6 +49,7 @@ __global__ __launch_bounds__((G5<KCH, NB, W>::NTHR), 2) void gemm5_kernel(Params
   typedef G5<KCH, NB, W> G;
   constexpr int K = G::K, BL = G::BL, CHUNK = G::CHUNK, NPAIR = G::NPAIR, NSINGLE = G::NSINGLE, NDMA = G::NDMA;
   constexpr bool C32 = FORM >= 3, RES = FORM == 3, GELU = FORM == 1, DGELU = FORM == 2;
+  static_assert(KCH == 1 || KCH == 2 || (KCH == 4 && !DGELU), "K = 96, 192, or 384 without the x gelu' form");
   __shared__ __attribute__((aligned(1024))) char smem[G::LDS];
   const int tid = threadIdx.x, lane = tid & 63, r32 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,10 +85,10 @@ __global__ __launch_bounds__((G5<KCH, NB, W>::NTHR), 2) void gemm5_kernel(Params
     soff[i] = (unsigned)(row * (int)p.lda * 2 + c * 16);
   }
   const char* const Ag = reinterpret_cast<const char*>(p.A);
-  // chunk j of the unit with sequence number `it` lives in ring slot (K = 96) it & 1, (K = 192) j
+  // chunk j of the unit with sequence number `it` lives in ring slot (K = 96) it & 1, (K = 192) j, (K = 384) j & 1
   auto issue_chunk = [&](int u, int it, int j) {
     const char* base = Ag + (int64_t)u * 32 * p.lda * 2 + j * 192;
-    char* dst = As + (KCH == 1 ? (it & 1) : j) * CHUNK;
+    char* dst = As + (KCH == 1 ? (it & 1) : (j & 1)) * CHUNK;
 #pragma unroll
     for (int i = 0; i < 6; ++i) lds_dma16(base, soff[i], dst + i * 1024);
   };
@@ -118,7 +119,7 @@ __global__ __launch_bounds__((G5<KCH, NB, W>::NTHR), 2) void gemm5_kernel(Params
   int u = gw;
   if (u < units) {
 #pragma unroll
-    for (int j = 0; j < KCH; ++j) issue_chunk(u, 0, j);
+    for (int j = 0; j < (KCH < 2 ? KCH : 2); ++j) issue_chunk(u, 0, j);
   }
   __syncthreads();                                  // weights staged; no barrier after this one
 
@@ -169,13 +170,13 @@ __global__ __launch_bounds__((G5<KCH, NB, W>::NTHR), 2) void gemm5_kernel(Params
       // ---- (1) this unit's epilogue operands; (2) its A rows have landed: everything older than the operands just requested is complete
       request(u);
       wait_vm<MinC<NRL>::v>();
-    } else {
+    } else if constexpr (KCH <= 2) {
       // ---- (1, 2) this unit's A rows (and epilogue operands) have landed: they were requested before the previous unit's stores
       if (it == 0) wait_vm<0>();
       else wait_vm<MinC<NST>::v>();
     }
     // (the LDS-DMA writes of THIS wave are visible to its own ds_reads once vmcnt says so: no other wave touches this ring)
-    if constexpr (AHEAD) {
+    if constexpr (AHEAD && KCH <= 2) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -198,7 +199,16 @@ __global__ __launch_bounds__((G5<KCH, NB, W>::NTHR), 2) void gemm5_kernel(Params
     const bool more = u + nw < units;
 #pragma unroll
     for (int j = 0; j < KCH; ++j) {
-      const char* a_img = As + (KCH == 1 ? (it & 1) : j) * CHUNK;
+      const char* a_img = As + (KCH == 1 ? (it & 1) : (j & 1)) * CHUNK;
+      if constexpr (KCH == 4) {
+        // K = 384: four chunks through TWO slots, each refilled two chunks ahead.  Chunk j has landed once at most the wave instructions issued
+        // AFTER its DMA are outstanding (in-order retirement; lower bounds): j = 0, 1 were requested in the previous unit before its epilogue
+        // (operand requests NRL_A, stores NST) with one younger DMA (6); j = 2, 3 in this unit with one younger DMA
+        constexpr int NRL_A = AHEAD ? NRL : 0;
+        if (j < 2) { if (it == 0) wait_vm<MinC<6 + NRL_A>::v>(); else wait_vm<MinC<6 + NRL_A + NST>::v>(); }
+        else if (j == 2) wait_vm<6>();
+        else { if (more) wait_vm<6>(); else wait_vm<0>(); }
+      }
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_img + aoff[ks]);
@@ -210,10 +220,26 @@ __global__ __launch_bounds__((G5<KCH, NB, W>::NTHR), 2) void gemm5_kernel(Params
       }
       // ---- (4) the same chunk of the next unit: K = 96 into the other slot (consumed one unit ago); K = 192 into the slot whose fragments
       // have just been read (every ds_read above has returned: its MFMA has issued)
-      if (more) {
+      if constexpr (KCH == 4) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j < 2) issue_chunk(u, it, j + 2);
+        else if (more) issue_chunk(u + nw, it + 1, j - 2);
+      } else if (more) {
         if (KCH > 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue_chunk(u + nw, it + 1, j);
       }
+    }
+    if constexpr (AHEAD && KCH == 4) {
+      // this unit's epilogue operands (requested before the previous unit's stores) have landed: behind them sit those stores and four DMAs
+      if (it == 0) { if (more) wait_vm<24>(); else wait_vm<12>(); }
+      else { if (more) wait_vm<MinC<24 + NST>::v>(); else wait_vm<MinC<12 + NST>::v>(); }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) rp[r][j] = rp_n[r][j];
+        if constexpr (NSINGLE) rs1[r] = rs1_n[r];
+      }
+      rsc = rsc_n;
     }
     // ---- (5) the next unit's epilogue operands / this unit's have landed (only the DMA just issued may still be in flight)
     if (AHEAD && more) request(u + nw);
@@ -307,7 +333,9 @@ bool launch5(const Params& p, int form, hipStream_t s) {
   switch (form) {
     case 0: hipLaunchKernelGGL((gemm5_kernel<KCH, NB, W, 0>), grid, block, 0, s, p, nt_n, units); return true;
     case 1: hipLaunchKernelGGL((gemm5_kernel<KCH, NB, W, 1>), grid, block, 0, s, p, nt_n, units); return true;
-    case 2: hipLaunchKernelGGL((gemm5_kernel<KCH, NB, W, 2>), grid, block, 0, s, p, nt_n, units); return true;
+    case 2:
+      if constexpr (KCH != 4) { hipLaunchKernelGGL((gemm5_kernel<KCH, NB, W, 2>), grid, block, 0, s, p, nt_n, units); return true; }
+      return false;
     case 3:                                                    // the residual stream runs on 96-column tiles only (gemm5_nb): two register sets of residual rows
       if constexpr (NB == 3) { hipLaunchKernelGGL((gemm5_kernel<KCH, NB, W, 3>), grid, block, 0, s, p, nt_n, units); return true; }
       return false;
@@ -324,6 +352,7 @@ int gemm5_nb(const csts_gemm_args* a) {
   static const int wide192 = [] { const char* e = getenv("CSTS_GEMM5_WIDE192"); return e ? atoi(e) : 0; }();
   if (gemm5_form(a) == 3) return 3;                            // two register sets of residual rows: 96 columns
   if (a->K == 96) return a->N % 192 == 0 ? 6 : 3;
+  if (a->K == 384) return 3;
   return (a->N % 192 == 0 && (a->algo % 1000 == 506 || (a->algo % 1000 != 503 && wide192))) ? 6 : 3;
 }
 
@@ -332,8 +361,9 @@ int gemm5_nb(const csts_gemm_args* a) {
 // Can this kernel run the problem at all (forced algo 500)?
 bool csts_gemm5_ok(const csts_gemm_args* a, int split) {
   if (a->layout != CSTS_GEMM_NT || a->compute != CSTS_BF16 || a->a_dt != CSTS_BF16 || a->b_dt != CSTS_BF16 || split != 1) return false;
-  if (a->colsum != nullptr || (a->K != 96 && a->K != 192) || a->N % 96 != 0 || a->N > 768 || a->M % 32 != 0 || a->M < 32) return false;
+  if (a->colsum != nullptr || (a->K != 96 && a->K != 192 && a->K != 384) || a->N % 96 != 0 || a->N > 768 || a->M % 32 != 0 || a->M < 32) return false;
   if (gemm5_form(a) < 0) return false;
+  if (a->K == 384 && (gemm5_form(a) == 2 || a->N > 384)) return false;          // four-chunk ring: no x gelu' form; 75 KB of weights per 96 columns
   auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!al(a->A) || !al(a->B) || !al(a->C) || a->lda % 8 != 0 || a->ldb % 8 != 0 || a->ldc % 2 != 0) return false;
   if (a->aux != nullptr && (!al(a->aux) || a->ldaux % 2 != 0)) return false;
@@ -346,12 +376,13 @@ bool csts_gemm5_ok(const csts_gemm_args* a, int split) {
 bool csts_gemm5_launch(const csts_gemm_params& p, const csts_gemm_args* a, hipStream_t s) {
   const int form = gemm5_form(a), nb = gemm5_nb(a);
   if (a->K == 96) return nb == 6 ? launch5<1, 6>(p, form, s) : launch5<1, 3>(p, form, s);
+  if (a->K == 384) return launch5<4, 3, 6>(p, form, s);
   return nb == 6 ? launch5<2, 6, 6>(p, form, s) : launch5<2, 3>(p, form, s);
 }
 
 // the kernel csts_gemm5_launch starts, as rocprofv3 prints it
 bool csts_gemm5_name(const csts_gemm_args* a, char* buf, int buflen) {
   const int nb = gemm5_nb(a);
-  snprintf(buf, buflen, "gemm5_kernel<%d, %d, %d, %d>", (int)(a->K / 96), nb, (a->K == 192 && nb == 6) ? 6 : 8, gemm5_form(a));
+  snprintf(buf, buflen, "gemm5_kernel<%d, %d, %d, %d>", (int)(a->K / 96), nb, ((a->K == 192 && nb == 6) || a->K == 384) ? 6 : 8, gemm5_form(a));
   return true;
 }

@@ -174,13 +174,14 @@ def test_gemm4_64_row_tiles(algo):
 
 @pytest.mark.parametrize("algo", [0, 500])
 @pytest.mark.parametrize("M,N,K", [(16384, 96, 96), (16416, 384, 96), (16384, 192, 96), (20000 // 32 * 32, 96, 192), (16384, 288, 192),
-                                   (16384, 768, 96)])
+                                   (16384, 768, 96), (16384 + 32 * 7, 96, 384), (16384, 288, 384)])
 def test_gemm5_streaming_thin_kernel(algo, M, N, K):
     """gemm5 (weights resident in LDS, one LDS-DMA stream per wave, register epilogue on column pairs): every epilogue form it carries
     -- bias / bias + GELU with the kept pre-activation / x gelu'(aux) / fp32 residual stream with per-sample drop-path scales / plain fp32
     (reference nn.Linear + GELU + drop-path + residual: attention.py:130,159,238-248; common.py:26-34) -- forced (algo 500) and as the
     library's own pick for these shapes, against fp32 torch AND bit for bit against the tiled kernel (same arithmetic, same order);
-    one / two / three / eight column tiles, K = 96 and 192, unit counts that do and do not divide over the waves."""
+    one / two / three / eight column tiles, K = 96, 192 and 384 (the four-chunk ring; no x gelu' form there), unit counts that do and do not
+    divide over the waves."""
     dt = torch.bfloat16
     A, W, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.2).to(dt), rnd(N, seed=3)
     pre = A.float() @ W.float().t() + b
@@ -202,11 +203,12 @@ def test_gemm5_streaming_thin_kernel(algo, M, N, K):
     assert rel_l2(got.float(), pre - b) < 6e-3 and torch.equal(got, run(2))
     got = run(algo, bias=b)
     assert rel_l2(got.float(), pre) < 6e-3 and torch.equal(got, run(2, bias=b))
-    h = rnd(M, N, seed=7).to(dt)                                                  # data gradient through GELU
-    got = run(algo, epilogue=L.EPI_DGELU, aux=h)
-    hf = h.float().requires_grad_(True)
-    F.gelu(hf).sum().backward()
-    assert rel_l2(got.float(), (pre - b) * hf.grad) < 6e-3 and torch.equal(got, run(2, epilogue=L.EPI_DGELU, aux=h))
+    if not (K == 384 and algo == 500):
+        h = rnd(M, N, seed=7).to(dt)                                              # data gradient through GELU
+        got = run(algo, epilogue=L.EPI_DGELU, aux=h)
+        hf = h.float().requires_grad_(True)
+        F.gelu(hf).sum().backward()
+        assert rel_l2(got.float(), (pre - b) * hf.grad) < 6e-3 and torch.equal(got, run(2, epilogue=L.EPI_DGELU, aux=h))
     res = rnd(M, N, seed=4)                                                       # the fp32 residual stream
     rps = 4096 + 32
     rs = rnd((M + rps - 1) // rps, seed=5).abs() + 0.5
