@@ -320,6 +320,7 @@ WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "8192"))
 # Round 5: the thin layers (output and input features multiples of 96 that the 192 x 384 class does not take; bf16 dY) as 96 x 96 tiles, one
 # (tile, token chunk) item per WAVE of csts_wgrad_grouped5 (wgrad5.hip: every wave its own LDS-DMA stream, no workgroup barrier)
 WG_DUMP = os.environ.get("CSTS_WGRAD_DUMP", "")
+WGRAD_CAST_F32 = os.environ.get("CSTS_WGRAD_CAST_F32", "1") != "0"
 WGRAD5 = os.environ.get("CSTS_WGRAD5", "1") != "0"
 WGRAD5_CHUNK = int(os.environ.get("CSTS_WGRAD5_CHUNK", "4096"))
 WGRAD5_STRIDED = os.environ.get("CSTS_WGRAD5_STRIDED", "1") != "0"
@@ -514,6 +515,18 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
             launch_stream.wait_event(ev)
         _wg_side_used[0] = True
     _wg_prod.clear()
+    # Round 5: fp32 dY of layers the LDS-DMA classes can take (a handful per step: the stage-transition projections, whose output gradient
+    # has no 16-bit copy) is cast to the 16-bit type first -- the 128-wide fp32-dY class rounds it the same way while staging, but as 4
+    # problems / ~330 workgroups of its own it took 0.28 ms per step for 153 MB (profiles/r5_final_mfma_util.txt); as 16-bit operands
+    # they ride in the 192 x 384 / 96 x 96 launches.  CSTS_WGRAD_CAST_F32=0 keeps the fp32 class.
+    if WGRAD_CAST_F32:
+        with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
+            for i, t in enumerate(q):
+                if t[0].dtype == torch.float32 and (_is_w8(t[1], t[4], t[5], t[6]) or
+                                                    (WGRAD5 and t[5] % 96 == 0 and t[6] % 96 == 0 and t[4] % 16 == 0 and min(t[5], t[6]) >= WGRAD5_MIN)):
+                    d16 = torch.empty(t[0].shape, dtype=L.half_dtype(), device=t[0].device)
+                    cast_into(d16, t[0])
+                    q[i] = (d16,) + tuple(t[1:])
     # tile classes: 192 x 384 on 8-wave workgroups where it divides the layer (the 384- and 768-channel stages: half the
     # operand bytes per FLOP of a 128 x 128 tile); else 256 x 128 where 256 divides the output rows; else 128 x 128
     def tile_class(t):
