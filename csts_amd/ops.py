@@ -320,7 +320,7 @@ WGRAD8_CHUNK = int(os.environ.get("CSTS_WGRAD8_CHUNK", "8192"))
 # Round 5: the thin layers (output and input features multiples of 96 that the 192 x 384 class does not take; bf16 dY) as 96 x 96 tiles, one
 # (tile, token chunk) item per WAVE of csts_wgrad_grouped5 (wgrad5.hip: every wave its own LDS-DMA stream, no workgroup barrier)
 WG_DUMP = os.environ.get("CSTS_WGRAD_DUMP", "")
-WGRAD_CAST_F32 = os.environ.get("CSTS_WGRAD_CAST_F32", "1") != "0"
+WGRAD_CAST_F32 = os.environ.get("CSTS_WGRAD_CAST_F32", "0") == "1"      # measured neutral (19.39 vs 19.39 ms, gpurun_out/r5al): off
 WGRAD5 = os.environ.get("CSTS_WGRAD5", "1") != "0"
 WGRAD5_CHUNK = int(os.environ.get("CSTS_WGRAD5_CHUNK", "4096"))
 WGRAD5_STRIDED = os.environ.get("CSTS_WGRAD5_STRIDED", "1") != "0"
@@ -518,7 +518,8 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
     # Round 5: fp32 dY of layers the LDS-DMA classes can take (a handful per step: the stage-transition projections, whose output gradient
     # has no 16-bit copy) is cast to the 16-bit type first -- the 128-wide fp32-dY class rounds it the same way while staging, but as 4
     # problems / ~330 workgroups of its own it took 0.28 ms per step for 153 MB (profiles/r5_final_mfma_util.txt); as 16-bit operands
-    # they ride in the 192 x 384 / 96 x 96 launches.  CSTS_WGRAD_CAST_F32=0 keeps the fp32 class.
+    # they ride in the 192 x 384 / 96 x 96 launches.  Whole step: neutral -- the fp32 class runs beside the stencil weight gradients, which bound that
+    # part of the tail either way -- so this is opt-in (CSTS_WGRAD_CAST_F32=1).
     if WGRAD_CAST_F32:
         with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
             for i, t in enumerate(q):
