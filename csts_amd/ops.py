@@ -161,6 +161,10 @@ def reset_deferred():
         _sw_used[0] = False
     _sw_keep.clear()
     _swq.clear()
+    _swq_count[0] = 0
+    _sw_prod.clear()
+    _swq_early_keep.clear()
+    _swq_early_used[0] = False
     _deferred.clear()
     _assign.clear()
     _wgq.clear()
@@ -249,6 +253,8 @@ def flush_deferred():
     _w8_count[0] = 0
     # the grouped stencil weight gradients (0.8 ms of load-latency-bound work, no matrix math) run on a side stream BESIDE the
     # grouped Linear weight gradients (MFMA-bound, one persistent workgroup per CU whose last items leave most CUs idle)
+    _swq_count[0] = 0
+    _sw_prod.clear()
     tail = None
     if _swq and _wgq and STENCIL_TAIL_SIDE and _swq[0][5][0].is_cuda:
         cur = torch.cuda.current_stream()
@@ -264,6 +270,11 @@ def flush_deferred():
         del keep        # allocated on this stream, read on `tail`: alive until the join above
     else:
         flush_stencil_wgrads()
+    if _swq_early_used[0]:
+        for st in _tail_side.values():
+            torch.cuda.current_stream().wait_stream(st)
+        _swq_early_used[0] = False
+        _swq_early_keep.clear()
     _join_wgrad_side()
     _join_stencil_side()
     if not _deferred:
@@ -618,6 +629,11 @@ WGRAD8_LAST = os.environ.get("CSTS_WGRAD8_LAST", "1") != "0"
 STENCIL_TAIL_SIDE = os.environ.get("CSTS_STENCIL_TAIL_SIDE", "1") != "0"
 _tail_side = {}         # device index -> stream
 _swq = []               # (DwconvGeom copy, fine ptr, coarse ptr, workspace ptr, dt, (tensors kept alive))
+SWG_EARLY = int(os.environ.get("CSTS_SWG_EARLY", "0"))
+_swq_count = [0]        # stencil problems queued so far in this backward pass
+_sw_prod = {}           # raw id -> stream: the streams that queued them
+_swq_early_keep = []    # operands of an early launch, alive until the final join
+_swq_early_used = [False]
 _swq_tables = {}        # device index -> HostTable
 
 
@@ -631,6 +647,23 @@ def _queue_stencil_wgrad(g, fine, fine_off, coarse, coarse_off, ws):
     gg = L.DwconvGeom()
     C.memmove(C.byref(gg), C.byref(g), C.sizeof(L.DwconvGeom))
     _swq.append((gg, _p(fine, fine_off), _p(coarse, coarse_off), _p(ws), _dt(fine), (fine, coarse, ws)))
+    cur = torch.cuda.current_stream()
+    _sw_prod[cur.cuda_stream] = cur
+    _swq_count[0] += 1
+    if SWG_EARLY > 0 and _swq_count[0] == SWG_EARLY and fine.is_cuda:
+        # Round 5 experiment (CSTS_SWG_EARLY=n): the first n problems of this backward pass (the head's and the late stages' pools: their
+        # operands are complete long before the pass ends) go out NOW as one grouped launch on the tail side stream, beside the rest of
+        # backward -- ONE fork; the join is the final flush's (the per-pool side launches of round 4 paid 34 fork / join pairs)
+        tail = _tail_side.get(cur.device.index)
+        if tail is None:
+            tail = _tail_side[cur.device.index] = torch.cuda.Stream(device=cur.device)
+        for st in _sw_prod.values():
+            ev = torch.cuda.Event()
+            ev.record(st)
+            tail.wait_event(ev)
+        with torch.cuda.stream(tail):
+            _swq_early_keep.append(flush_stencil_wgrads())
+        _swq_early_used[0] = True
 
 
 def flush_stencil_wgrads():
