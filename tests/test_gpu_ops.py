@@ -219,7 +219,7 @@ def test_gemm5_streaming_thin_kernel(algo, M, N, K):
     assert rel_l2(got, pre - b + res) < 1e-4 and torch.equal(got, run(2, odt=torch.float32, residual=res, ldr=N))
     got = run(algo, odt=torch.float32, bias=b)                                    # plain fp32 output
     assert rel_l2(got, pre) < 1e-4 and torch.equal(got, run(2, odt=torch.float32, bias=b))
-    if algo == 0:                                                                 # the library does route these shapes to gemm5
+    if algo == 0 and K != 384:                                                    # the library does route these shapes to gemm5 (K = 384: opt-in)
         a = L.GemmArgs()
         a.layout, a.M, a.N, a.K, a.compute = L.GEMM_NT, M, N, K, L.BF16
         a.A, a.a_dt, a.lda, a.B, a.b_dt, a.ldb = A.data_ptr(), L.BF16, K, W.data_ptr(), L.BF16, K
