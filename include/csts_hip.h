@@ -69,7 +69,7 @@ typedef struct {
   void* workspace; size_t ws_bytes;   /* optional: makes split_k deterministic (partial slabs + finishing pass) */
   float* colsum;   /* optional, TN + bf16 v2 kernel only: colsum[m] = sum_k A[k,m] (the bias gradient of a Linear) */
   int tile_rows;   /* 0 = library heuristic; 64 / 128 / 256 force the bf16 kernel's row tile (tuning sweeps) */
-  int algo;        /* 0 = library heuristic; 2 = register-staged kernel; 1000 * wg_per_cu + 300 + 10 * (tile_rows / 64) + stages = persistent LDS-DMA NT kernel; 1000 * wg_per_cu + 400 + variant = 8-wave LDS-DMA NT kernel, needs K % 64 == 0 (tuning sweeps) */
+  int algo;        /* 0 = library heuristic; 2 = register-staged kernel; 1000 * wg_per_cu + 300 + 10 * (tile_rows / 64) + stages = persistent LDS-DMA NT kernel; 1000 * wg_per_cu + 400 + variant = 8-wave LDS-DMA NT kernel, needs K % 64 == 0 (tuning sweeps); 500 = the streaming thin-operand NT kernel (gemm5.hip: K = 96 / 192 / 384, N % 96 == 0, M % 32 == 0; 503 / 506: 96 / 192 columns per workgroup at K = 192) */
   int res_up[6];   /* {Ti, Hi, Wi, To, Ho, Wo}; all 0 = plain residual */
 } csts_gemm_args;
 int csts_gemm(const csts_gemm_args* args, hipStream_t stream);
