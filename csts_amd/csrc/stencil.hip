@@ -460,6 +460,164 @@ __global__ __launch_bounds__(256, POOL_LN_WGS) void pool_ln_fwd_kernel(RowGeom r
   }
 }
 
+// Round 5: the same kernel with TWELVE channels per lane (head dims 96 / 192: 8 / 16 lanes per item, every lane active -- with 8 channels per lane
+// a 96-wide head keeps 12 of its 16 lanes busy -- and 32 / 16 items per workgroup instead of 16 / 8: the 384-channel stage's launches become 512
+// workgroups, ONE round at three workgroups per CU instead of 1024 = 1.33 rounds).  Same arithmetic per channel, same order of taps: bit-identical
+// conv rows; the LayerNorm sums run over a different lane tree (8 / 16 lanes of 12 instead of 16 / 32 of 8): equal to rounding.
+template <bool F32> struct Raw12;
+template <> struct Raw12<true> { float4 a, b, c; };
+template <> struct Raw12<false> { uint4 a; uint2 b; };
+template <bool F32> __device__ __forceinline__ Raw12<F32> raw12_load(const void* base, int i) {
+  Raw12<F32> r;
+  if constexpr (F32) {
+    const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i);
+    r.a = q[0]; r.b = q[1]; r.c = q[2];
+  } else {
+    const char* q = reinterpret_cast<const char*>(reinterpret_cast<const bf16*>(base) + i);      // 24 k bytes: 8-byte aligned
+    uint2 lo = *reinterpret_cast<const uint2*>(q), mid = *reinterpret_cast<const uint2*>(q + 8);
+    r.a = make_uint4(lo.x, lo.y, mid.x, mid.y);
+    r.b = *reinterpret_cast<const uint2*>(q + 16);
+  }
+  return r;
+}
+template <bool F32> __device__ __forceinline__ void raw12_cvt(const Raw12<F32>& r, float (&o)[12]) {
+  if constexpr (F32) {
+    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+    o[8] = r.c.x; o[9] = r.c.y; o[10] = r.c.z; o[11] = r.c.w;
+  } else {
+    o[0] = h16_lo(r.a.x); o[1] = h16_hi(r.a.x); o[2] = h16_lo(r.a.y); o[3] = h16_hi(r.a.y);
+    o[4] = h16_lo(r.a.z); o[5] = h16_hi(r.a.z); o[6] = h16_lo(r.a.w); o[7] = h16_hi(r.a.w);
+    o[8] = h16_lo(r.b.x); o[9] = h16_hi(r.b.x); o[10] = h16_lo(r.b.y); o[11] = h16_hi(r.b.y);
+  }
+}
+template <bool F32> __device__ __forceinline__ void st12t(void* base, int64_t i, const float (&o)[12]) {
+  if constexpr (F32) {
+    float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + i);
+    q[0] = make_float4(o[0], o[1], o[2], o[3]);
+    q[1] = make_float4(o[4], o[5], o[6], o[7]);
+    q[2] = make_float4(o[8], o[9], o[10], o[11]);
+  } else {
+    bf16x4 v[3];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j >> 2][j & 3] = (bf16)o[j];
+    uint2* q = reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(base) + i);                        // 8-byte aligned
+    q[0] = __builtin_bit_cast(uint2, v[0]); q[1] = __builtin_bit_cast(uint2, v[1]); q[2] = __builtin_bit_cast(uint2, v[2]);
+  }
+}
+
+// ALL27: all 27 taps of an item in flight at once (one memory round trip per item instead of three) at TWO workgroups per CU -- every launch of
+// this form is at most 512 workgroups, one round either way.
+template <int GL, bool F32, bool ALL27>
+__global__ __launch_bounds__(256, (ALL27 ? 2 : POOL_LN_WGS)) void pool_ln_fwd12_kernel(RowGeom rg, PoolLnSlots sl, int nslots, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [nslots][28][HD + WPAD]
+  const Geom& g = rg.g;
+  const int HD = g.HD, H = g.C / HD;                          // HD == 12 GL (host-checked)
+  const int lane_in = threadIdx.x % GL;
+  const int c12 = lane_in * 12;
+  constexpr int groups_per_block = 256 / GL;
+  const int ntok = g.Tc * g.Hc * g.Wc;
+  const int per_slot = g.B * ntok * H;
+  const int total = per_slot * nslots;
+  const int fts = (int)g.f_ts, cts = (int)g.c_ts;
+  const float invHD = 1.f / HD;
+  for (int s2 = 0; s2 < nslots; ++s2) stage_weight_rows<false>(sl.w[s2], wl + s2 * 28 * (HD + WPAD), HD, blockDim.x, threadIdx.x);
+  __syncthreads();
+  const int item0 = blockIdx.x * groups_per_block + threadIdx.x / GL;
+  for (int item = item0; item < total; item += gridDim.x * groups_per_block) {
+    const int slot = item >= per_slot ? 1 : 0;            // (nslots <= 2)
+    int r = item - slot * per_slot;
+    const int bt = fdiv(r, rg.dHeads);
+    const int head = r - bt * H;
+    int b, ot, oh, ow;
+    decompf(bt, rg.dNc, rg.dHc, rg.dWc, b, ot, oh, ow);
+    const int c = head * HD + c12;
+    int hof[3], xof[3];
+    bool hv[3], xv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int h = oh * g.sh - 1 + k, x = ow * g.sw - 1 + k;
+      hv[k] = (unsigned)h < (unsigned)g.Hf; hof[k] = min(max(h, 0), g.Hf - 1) * g.Wf * fts;
+      xv[k] = (unsigned)x < (unsigned)g.Wf; xof[k] = min(max(x, 0), g.Wf - 1) * fts + c;
+    }
+    const void* fb = bptr<F32>(sl.fine[slot], (int64_t)b * g.f_bs);
+    const float* wls = wl + slot * 28 * (HD + WPAD) + c12;
+    float acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+    auto slice_load = [&](int kt, Raw12<F32> (&raw)[9], bool& tvk) {
+      const int t = ot * g.st - 1 + kt;
+      tvk = (unsigned)t < (unsigned)g.Tf;
+      const int tofk = min(max(t, 0), g.Tf - 1) * g.Hf * g.Wf * fts;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = raw12_load<F32>(fb, tofk + hof[kh] + xof[kw]);
+    };
+    auto slice_mac = [&](int kt, const Raw12<F32> (&raw)[9], bool tvk) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (tvk && hv[kh] && xv[kw]) ? kt * 9 + kh * 3 + kw : 27;
+          const float* wr = &wls[tap * (HD + WPAD)];
+          const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4), w2 = *reinterpret_cast<const float4*>(wr + 8);
+          float v[12];
+          raw12_cvt<F32>(raw[kh * 3 + kw], v);
+          acc[0] += v[0] * w0.x; acc[1] += v[1] * w0.y; acc[2] += v[2] * w0.z; acc[3] += v[3] * w0.w;
+          acc[4] += v[4] * w1.x; acc[5] += v[5] * w1.y; acc[6] += v[6] * w1.z; acc[7] += v[7] * w1.w;
+          acc[8] += v[8] * w2.x; acc[9] += v[9] * w2.y; acc[10] += v[10] * w2.z; acc[11] += v[11] * w2.w;
+        }
+    };
+    if constexpr (ALL27) {
+      Raw12<F32> r0[9], r1[9], r2[9];
+      bool t0, t1, t2;
+      slice_load(0, r0, t0); slice_load(1, r1, t1); slice_load(2, r2, t2);
+      slice_mac(0, r0, t0); slice_mac(1, r1, t1); slice_mac(2, r2, t2);
+    } else {
+#pragma unroll 1
+      for (int kt = 0; kt < 3; ++kt) {           // a real loop: one temporal slice (9 taps) in flight at a time, as in pool_ln_fwd_kernel
+        Raw12<F32> raw[9];
+        bool tvk;
+        slice_load(kt, raw, tvk);
+        slice_mac(kt, raw, tvk);
+      }
+    }
+    if constexpr (!F32) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc[j] = (float)(bf16)acc[j];
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s1 += acc[j];
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    const float mu = s1 * invHD;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { const float d = acc[j] - mu; s2 += d * d; }
+#pragma unroll
+    for (int o = GL / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rs = rsqrtf(s2 * invHD + eps);
+    const int64_t off = (int64_t)b * g.c_bs + (int64_t)(bt - b * ntok) * cts + c;
+    st12t<F32>(sl.conv[slot], off, acc);
+    const float* gp = sl.gamma[slot] + c12;
+    const float* bp = sl.beta[slot] + c12;
+    float y[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float4 gq = *reinterpret_cast<const float4*>(gp + 4 * q), bq = *reinterpret_cast<const float4*>(bp + 4 * q);
+      y[4 * q + 0] = (acc[4 * q + 0] - mu) * rs * gq.x + bq.x; y[4 * q + 1] = (acc[4 * q + 1] - mu) * rs * gq.y + bq.y;
+      y[4 * q + 2] = (acc[4 * q + 2] - mu) * rs * gq.z + bq.z; y[4 * q + 3] = (acc[4 * q + 3] - mu) * rs * gq.w + bq.w;
+    }
+    st12t<F32>(sl.y[slot], off, y);
+    if (lane_in == 0) {
+      const int64_t row = (int64_t)bt * H + head;       // row index of the (B*N, H) x HD LayerNorm
+      sl.mean[slot][row] = mu;
+      sl.rstd[slot][row] = rs;
+    }
+  }
+}
+
 // candidate taps of one axis of the transposed form: k with (f + 1 - k) % s == 0, o = (f + 1 - k) / s.
 // stride 1: three candidates, stride 2: two (parity), stride >= 4: at most one.
 template <int N>
@@ -1399,8 +1557,29 @@ extern "C" int csts_pool_ln_fwd(const csts_pool_ln_args* a, hipStream_t stream) 
     sl.conv[i] = a->conv_out[i]; sl.y[i] = a->y[i]; sl.mean[i] = a->mean[i]; sl.rstd[i] = a->rstd[i];
   }
   RowGeom rg; fill_geom(gm, rg);
-  const int gl = gm->HD <= 128 ? 16 : 32;
   const int64_t items = (int64_t)gm->B * gm->Tc * gm->Hc * gm->Wc * (gm->C / gm->HD) * a->nslots;
+  // twelve channels per lane for the 96- / 192-wide heads (CSTS_POOLLN_CPL12=0: the 8-channel form for every head dim; 1, default: nine taps
+  // in flight; 2: all 27).  Whole step, same box, 3 rounds: 19.92 -> 19.75 (1) / 19.77 (2) ms; another box 19.54 -> 19.46 (gpurun_out/r5ao, r5ap)
+  static const int cpl12 = [] { const char* e = getenv("CSTS_POOLLN_CPL12"); return e ? atoi(e) : 1; }();
+  if (cpl12 > 0 && (gm->HD == 96 || gm->HD == 192) && (((uintptr_t)a->fine[0] | (uintptr_t)a->conv_out[0] | (uintptr_t)a->y[0]) & 7) == 0) {
+    const int gl12 = gm->HD / 12, gpb12 = 256 / gl12;
+    const dim3 grid12((unsigned)std::min<int64_t>(cdiv(items, gpb12), grid_for_staged((int64_t)1 << 40))), block12(256);
+    const size_t sm12 = (size_t)a->nslots * (gm->HD + WPAD) * 28 * 4;
+    const bool f32_12 = a->dt == CSTS_F32;
+#define CSTS_PL12(GLv, F32v, ALLv) hipLaunchKernelGGL((pool_ln_fwd12_kernel<GLv, F32v, ALLv>), grid12, block12, sm12, stream, rg, sl, a->nslots, a->eps)
+    const bool all27 = cpl12 >= 2 && grid12.x <= 512 && !f32_12;       // (fp32 operands: 27 x 12 registers of taps do not fit)
+    if (gl12 == 8) {
+      if (f32_12) { if (all27) CSTS_PL12(8, true, true); else CSTS_PL12(8, true, false); }
+      else { if (all27) CSTS_PL12(8, false, true); else CSTS_PL12(8, false, false); }
+    } else {
+      if (f32_12) { if (all27) CSTS_PL12(16, true, true); else CSTS_PL12(16, true, false); }
+      else { if (all27) CSTS_PL12(16, false, true); else CSTS_PL12(16, false, false); }
+    }
+#undef CSTS_PL12
+    CSTS_LAUNCH_CHECK();
+    return 0;
+  }
+  const int gl = gm->HD <= 128 ? 16 : 32;
   const int gpb = 256 / gl;
   const dim3 grid((unsigned)std::min<int64_t>(cdiv(items, gpb), grid_for_staged((int64_t)1 << 40))), block(256);
   const size_t sm = (size_t)a->nslots * (gm->HD + WPAD) * 28 * 4;
