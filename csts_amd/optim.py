@@ -13,11 +13,15 @@ from __future__ import annotations
 import ctypes as C
 from typing import Dict, List
 
+import os
+
 import torch
 
 from . import lib as L
 
-CHUNK = 65536        # elements per workgroup: 256 KiB of fp32 gradient
+# elements per workgroup of the clip / AdamW launches.  Round 5: 16384 (64 KiB of fp32 gradient, ~3400 workgroups for the trunk parameters) instead of
+# 65536 (~1100): clip + AdamW 1.245 -> 1.165 ms, step -0.07 ms (8192 / 4096 alike, 131072 alike, 262144 +0.17 ms; gpurun_out/r5as, r5at).  A/B: CSTS_OPT_CHUNK
+CHUNK = int(os.environ.get("CSTS_OPT_CHUNK", "16384"))
 
 
 class FusedAdamW:
