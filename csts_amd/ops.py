@@ -262,8 +262,14 @@ def flush_deferred():
         if tail is None:
             tail = _tail_side[cur.device.index] = torch.cuda.Stream(device=cur.device)
         tail.wait_stream(cur)
+        if W8_PARALLEL:
+            # Round 5 experiment: the 192 x 384 class (310 items on 256 CUs: its second round fills a fifth of the chip) FIRST and alone on this
+            # stream, every other weight-gradient launch on the side stream -- they can take the CUs its second round leaves idle
+            flush_wgrads(w8="only")
         with torch.cuda.stream(tail):
             keep = flush_stencil_wgrads()
+            if W8_PARALLEL:
+                flush_wgrads(w8="exclude")
     flush_wgrads()
     if tail is not None:
         torch.cuda.current_stream().wait_stream(tail)
@@ -479,16 +485,18 @@ def _wg_plan(sig, rows=128, cols=128, chunk_tokens=None, strided=False):
     return plan
 
 
-def flush_wgrads(side: bool = False, only_w8: bool = False):
+def flush_wgrads(side: bool = False, only_w8: bool = False, w8: str = "all"):
     """Launch the queued weight gradients: on the current stream (end of backward), or -- side=True, from queue_wgrad in
     the middle of backward -- on the side stream, after everything the producing streams have enqueued so far.  only_w8: just the
     192 x 384-class problems (on W8_EARLY_WGS workgroups); everything else stays queued."""
     if not _wgq:
         return
     import numpy as np
-    if only_w8:
+    if only_w8 or w8 != "all":      # w8 = "only" / "exclude": the 192 x 384 class alone (a full launch) / everything but it; the rest stays queued
         q = [t for t in _wgq if _is_w8(t[0], t[4], t[5], t[6])]
         rest = [t for t in _wgq if not _is_w8(t[0], t[4], t[5], t[6])]
+        if w8 == "exclude":
+            q, rest = rest, q
         _wgq.clear()
         _wgq.extend(rest)
         if not q:
@@ -502,7 +510,9 @@ def flush_wgrads(side: bool = False, only_w8: bool = False):
             for t in q:
                 f.write(f"{'f32' if t[0].dtype == torch.float32 else 'h16'} {t[4]} {t[5]} {t[6]} {t[0].stride(0)} {t[1].stride(0)} {int(t[3] is not None)}\n")
     dev = q[0][0].device
-    key = (dev.index, side)
+    # (w8 = "exclude" runs on the tail side stream CONCURRENTLY with the "only" launch of the main stream: its own device table -- one table
+    # for both let the second upload overwrite the items the first launch was still reading: a GPU memory fault, round 5)
+    key = (dev.index, "x" if w8 == "exclude" else side)
     tab = _wg_tables.get(key)
     if tab is None:
         tab = _wg_tables[key] = HostTable(C.sizeof(L.WgradItem) * 24576, dev, ring=8, captures=40 if side else 16)
@@ -626,6 +636,7 @@ STENCIL_WGRAD_GROUPED = os.environ.get("CSTS_STENCIL_WGRAD_GROUPED", "1") != "0"
 # (profiles/r5_wgrad_tail_ab.txt).  What made the same side stream neutral in round 4 was the ORDER: the 192 x 384 class went first, and
 # its one 144 KB-LDS workgroup per CU leaves no room for anything else -- it now goes last (WGRAD8_LAST).  =0 restores either.
 WGRAD8_LAST = os.environ.get("CSTS_WGRAD8_LAST", "1") != "0"
+W8_PARALLEL = os.environ.get("CSTS_W8_PARALLEL", "0") == "1"
 STENCIL_TAIL_SIDE = os.environ.get("CSTS_STENCIL_TAIL_SIDE", "1") != "0"
 _tail_side = {}         # device index -> stream
 _swq = []               # (DwconvGeom copy, fine ptr, coarse ptr, workspace ptr, dt, (tensors kept alive))
